@@ -1,0 +1,55 @@
+// Shared internals of libdynaboa_hip.so (gfx950 / CDNA4 only).
+// Public C ABI lives in include/dynaboa_hip.h; this header is private to csrc/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DYB_OK 0
+#define DYB_ERR_ARG (-1)      // bad pointer / dimension
+#define DYB_ERR_LAUNCH (-2)   // hipGetLastError() after a launch
+#define DYB_ERR_UNSUPPORTED (-3)
+#define DYB_ERR_WORKSPACE (-4)
+
+#define DYB_GN_GROUPS 4       // reference model/hmr.py:18  GroupNorm(32 // 8, planes)
+#define DYB_GN_EPS 1e-5f
+
+#define DYB_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return DYB_ERR_LAUNCH; \
+  } while (0)
+
+#define DYB_REQUIRE(cond, code) \
+  do {                          \
+    if (!(cond)) return (code); \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int dyb_ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline bool dyb_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int dyb_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// 64-lane butterfly sum (wave = 64 on gfx950).
+__device__ __forceinline__ float dyb_wave_sum(float v) {
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+// ---- cross-file internals (not part of the C ABI) ----------------------------------------
+struct ConvDesc {
+  int N, H, W, C, K, R, S, stride, pad;
+};
+// forward conv that may leave `*nslabs` (>1) un-reduced split-K slabs in `ws` for the GroupNorm
+// statistics kernel to fold (igemm_conv.hip)
+int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y, void* ws, size_t ws_bytes,
+                     int* nslabs, hipStream_t st);

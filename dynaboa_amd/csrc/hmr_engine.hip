@@ -1,0 +1,410 @@
+// Native HMR engine: a static execution plan for the ResNet-50(GN) backbone + 3-iteration SMPL
+// regressor of reference model/hmr.py:63-181, forward and backward, over
+//   * ONE flat fp32 parameter arena (conv weights re-laid [R][S][Cin][Cout], fc1 rows padded to
+//     2208, the three decoder heads fused into one [160][1024] matrix),
+//   * ONE activation arena per forward call (every conv output + every GroupNorm output is kept:
+//     that is exactly what backward needs; 22.2 M floats = 89 MB per image),
+//   * a workspace (split-K slabs, norm partials, four ping-pong gradient buffers).
+// One C call = one whole forward (or backward): ~180 (~330) stream-ordered launches, no host
+// syncs, no allocation, capturable in a hipGraph.  PyTorch only owns the memory and the stream.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "dyb_common.h"
+
+// ---- low-level entry points defined in the sibling files -----------------------------------
+extern "C" {
+size_t dyb_conv2d_workspace_bytes(int, int, int, int, int, int, int, int, int);
+int dyb_conv2d_nhwc_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int,
+                          void*, size_t, hipStream_t);
+int dyb_conv2d_nhwc_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t,
+                          hipStream_t);
+size_t dyb_groupnorm_workspace_bytes(int, int, int);
+int dyb_groupnorm_fwd(const float*, int, float*, const float*, const float*, const float*, float*, float*, int, int, int,
+                      int, void*, size_t, hipStream_t);
+int dyb_groupnorm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                      float*, int, int, int, int, void*, size_t, hipStream_t);
+int dyb_nchw3_to_nhwc4(const float*, float*, int, int, int, hipStream_t);
+int dyb_maxpool3x3s2_fwd(const float*, float*, uint32_t*, int, int, int, int, hipStream_t);
+int dyb_maxpool3x3s2_bwd(const float*, const uint32_t*, float*, int, int, int, int, hipStream_t);
+int dyb_avgpool_fwd(const float*, float* const*, int, int, int, int, int, hipStream_t);
+int dyb_avgpool_bwd(const float*, int, float*, int, int, int, hipStream_t);
+int dyb_linear_fwd(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int,
+                   hipStream_t);
+size_t dyb_linear_bwd_workspace_bytes(int, int, int);
+int dyb_linear_bwd_dx(const float*, int, const float*, int, int, int, int, float*, int, int, int, float*, int,
+                      const float*, int, void*, size_t, hipStream_t);
+int dyb_linear_bwd_dw(const float* const*, const int*, const float* const*, const int*, int, int, int, int, float*, int,
+                      float*, hipStream_t);
+int dyb_rot6d_fwd(const float*, int, float*, int, hipStream_t);
+int dyb_rot6d_bwd(const float*, int, const float*, float*, int, int, hipStream_t);
+}
+
+#define FC1_IN_PAD 2208
+#define FEAT 2048
+#define STATE_LD 160     // pose 144 | shape 10 | cam 3 | pad 3
+#define HID 1024
+#define MAX_ITER 3
+
+enum TensorKind { K_CONV_W = 0, K_NORM_W = 1, K_NORM_B = 2, K_FC_W = 3, K_FC_B = 4, K_DEC_W = 5, K_DEC_B = 6 };
+
+struct TensorInfo {
+  std::string name;
+  int kind;
+  size_t offset;     // floats into the parameter arena
+  int dims[4];       // conv: Cout,Cin(reference),R,S ; fc: out,in(reference),ld,0 ; norm: C
+  int cin_pad;
+};
+
+struct ConvL {
+  int H, W, C, K, R, S, stride, pad, Ho, Wo;
+  size_t w, gam, bet;          // parameter offsets
+  size_t y, out, stats;        // activation offsets (conv output, normalised output, [B][4][2])
+};
+struct BlockL {
+  int c1, c2, c3, cd;          // indices into convs (cd = -1: identity shortcut)
+};
+
+struct HmrPlan {
+  int B, H, W;
+  std::vector<ConvL> convs;
+  std::vector<BlockL> blocks;
+  int layer_last_block[4];
+  std::vector<TensorInfo> tensors;
+  size_t n_params;
+  size_t fc1_w, fc1_b, fc2_w, fc2_b, dec_w, dec_b;
+  // activation arena
+  size_t a_x4, a_pool, a_poolidx, a_xc[MAX_ITER], a_h1[MAX_ITER], a_h2[MAX_ITER], a_state, a_rot;
+  size_t act_floats;
+  int poolH, poolW;            // max-pool output
+  int featHW;                  // spatial size of the last feature map (7*7)
+  // workspace carve (bytes)
+  size_t ws_conv, ws_gn, ws_lin, ws_grad_each, ws_reg, ws_total;
+};
+
+static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+static int add_conv(HmrPlan& P, const std::string& cname, const std::string& nname, int H, int W, int Cin_ref, int Cout,
+                    int k, int stride, int pad, size_t& poff, size_t& aoff) {
+  ConvL c{};
+  int cin_pad = Cin_ref < 4 ? 4 : Cin_ref;
+  c.H = H; c.W = W; c.C = cin_pad; c.K = Cout; c.R = k; c.S = k; c.stride = stride; c.pad = pad;
+  c.Ho = (H + 2 * pad - k) / stride + 1;
+  c.Wo = (W + 2 * pad - k) / stride + 1;
+  c.w = poff;
+  P.tensors.push_back({cname + ".weight", K_CONV_W, poff, {Cout, Cin_ref, k, k}, cin_pad});
+  poff = align64(poff + (size_t)k * k * cin_pad * Cout);
+  c.gam = poff;
+  P.tensors.push_back({nname + ".weight", K_NORM_W, poff, {Cout, 0, 0, 0}, 0});
+  poff = align64(poff + Cout);
+  c.bet = poff;
+  P.tensors.push_back({nname + ".bias", K_NORM_B, poff, {Cout, 0, 0, 0}, 0});
+  poff = align64(poff + Cout);
+  size_t n = (size_t)P.B * c.Ho * c.Wo * Cout;
+  c.y = aoff; aoff = align64(aoff + n);
+  c.out = aoff; aoff = align64(aoff + n);
+  c.stats = aoff; aoff = align64(aoff + (size_t)P.B * DYB_GN_GROUPS * 2);
+  P.convs.push_back(c);
+  return (int)P.convs.size() - 1;
+}
+
+static HmrPlan* build_plan(int B, int H, int W) {
+  HmrPlan* pp = new HmrPlan();
+  HmrPlan& P = *pp;
+  P.B = B; P.H = H; P.W = W;
+  size_t poff = 0, aoff = 0;
+  P.a_x4 = aoff; aoff = align64(aoff + (size_t)B * H * W * 4);
+  int stem = add_conv(P, "conv1", "bn1", H, W, 3, 64, 7, 2, 3, poff, aoff);
+  int h = P.convs[stem].Ho, w = P.convs[stem].Wo;
+  P.poolH = (h + 2 - 3) / 2 + 1;
+  P.poolW = (w + 2 - 3) / 2 + 1;
+  P.a_pool = aoff; aoff = align64(aoff + (size_t)B * P.poolH * P.poolW * 64);
+  P.a_poolidx = aoff; aoff = align64(aoff + (size_t)B * P.poolH * P.poolW * 16);   // uint32 per float4
+  h = P.poolH; w = P.poolW;
+  const int nblocks[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+  int inplanes = 64;
+  for (int li = 0; li < 4; ++li) {
+    for (int bi = 0; bi < nblocks[li]; ++bi) {
+      std::string pre = "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+      int stride = (bi == 0 && li > 0) ? 2 : 1;
+      BlockL b{};
+      b.c1 = add_conv(P, pre + "conv1", pre + "bn1", h, w, inplanes, planes[li], 1, 1, 0, poff, aoff);
+      b.c2 = add_conv(P, pre + "conv2", pre + "bn2", h, w, planes[li], planes[li], 3, stride, 1, poff, aoff);
+      int h2 = P.convs[b.c2].Ho, w2 = P.convs[b.c2].Wo;
+      b.c3 = add_conv(P, pre + "conv3", pre + "bn3", h2, w2, planes[li], planes[li] * 4, 1, 1, 0, poff, aoff);
+      b.cd = -1;
+      if (bi == 0)
+        b.cd = add_conv(P, pre + "downsample.0", pre + "downsample.1", h, w, inplanes, planes[li] * 4, 1, stride, 0, poff,
+                        aoff);
+      P.blocks.push_back(b);
+      inplanes = planes[li] * 4;
+      h = h2; w = w2;
+    }
+    P.layer_last_block[li] = (int)P.blocks.size() - 1;
+  }
+  P.featHW = h * w;
+  P.fc1_w = poff; P.tensors.push_back({"fc1.weight", K_FC_W, poff, {HID, FEAT + 157, FC1_IN_PAD, 0}, 0});
+  poff = align64(poff + (size_t)HID * FC1_IN_PAD);
+  P.fc1_b = poff; P.tensors.push_back({"fc1.bias", K_FC_B, poff, {HID, 0, 0, 0}, 0});
+  poff = align64(poff + HID);
+  P.fc2_w = poff; P.tensors.push_back({"fc2.weight", K_FC_W, poff, {HID, HID, HID, 0}, 0});
+  poff = align64(poff + (size_t)HID * HID);
+  P.fc2_b = poff; P.tensors.push_back({"fc2.bias", K_FC_B, poff, {HID, 0, 0, 0}, 0});
+  poff = align64(poff + HID);
+  P.dec_w = poff; P.tensors.push_back({"dec.weight", K_DEC_W, poff, {STATE_LD, HID, HID, 0}, 0});
+  poff = align64(poff + (size_t)STATE_LD * HID);
+  P.dec_b = poff; P.tensors.push_back({"dec.bias", K_DEC_B, poff, {STATE_LD, 0, 0, 0}, 0});
+  poff = align64(poff + STATE_LD);
+  P.n_params = poff;
+  for (int t = 0; t < MAX_ITER; ++t) {
+    P.a_xc[t] = aoff; aoff = align64(aoff + (size_t)B * FC1_IN_PAD);
+    P.a_h1[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
+    P.a_h2[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
+  }
+  P.a_state = aoff; aoff = align64(aoff + (size_t)B * STATE_LD);
+  P.a_rot = aoff; aoff = align64(aoff + (size_t)B * 24 * 9);
+  P.act_floats = aoff;
+
+  size_t wc = 0, wg = 0, maxact = 0;
+  for (auto& c : P.convs) {
+    size_t s = dyb_conv2d_workspace_bytes(B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad);
+    if (s > wc) wc = s;
+    size_t g = dyb_groupnorm_workspace_bytes(B, c.Ho * c.Wo, c.K);
+    if (g > wg) wg = g;
+    size_t n = (size_t)B * c.Ho * c.Wo * c.K;
+    if (n > maxact) maxact = n;
+    size_t nin = (size_t)B * c.H * c.W * c.C;
+    if (nin > maxact) maxact = nin;
+  }
+  size_t wl = dyb_linear_bwd_workspace_bytes(B, FC1_IN_PAD, HID);
+  size_t wl2 = dyb_linear_bwd_workspace_bytes(B, HID, HID);
+  if (wl2 > wl) wl = wl2;
+  P.ws_conv = align64(wc / 4) * 4;
+  P.ws_gn = align64(wg / 4) * 4;
+  P.ws_lin = align64(wl / 4) * 4;
+  P.ws_grad_each = align64(maxact) * 4;
+  // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
+  P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
+  P.ws_total = P.ws_conv + P.ws_gn + P.ws_lin + 4 * P.ws_grad_each + P.ws_reg;
+  return pp;
+}
+
+extern "C" int dyb_hmr_plan_create(int B, int H, int W, void** plan) {
+  DYB_REQUIRE(plan && B > 0 && B <= 64 && H > 0 && W > 0, DYB_ERR_ARG);
+  HmrPlan* p = build_plan(B, H, W);
+  *plan = p;
+  return DYB_OK;
+}
+extern "C" void dyb_hmr_plan_destroy(void* plan) { delete reinterpret_cast<HmrPlan*>(plan); }
+extern "C" size_t dyb_hmr_param_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->n_params; }
+extern "C" size_t dyb_hmr_act_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->act_floats; }
+extern "C" size_t dyb_hmr_workspace_bytes(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->ws_total; }
+extern "C" int dyb_hmr_num_tensors(const void* plan) { return (int)reinterpret_cast<const HmrPlan*>(plan)->tensors.size(); }
+extern "C" int dyb_hmr_tensor_info(const void* plan, int i, char* name, int name_cap, int* kind, long long* offset,
+                                   int* dims4, int* cin_pad) {
+  const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
+  DYB_REQUIRE(P && i >= 0 && i < (int)P->tensors.size() && name && kind && offset && dims4 && cin_pad, DYB_ERR_ARG);
+  const TensorInfo& t = P->tensors[i];
+  strncpy(name, t.name.c_str(), name_cap - 1);
+  name[name_cap - 1] = 0;
+  *kind = t.kind; *offset = (long long)t.offset; *cin_pad = t.cin_pad;
+  for (int k = 0; k < 4; ++k) dims4[k] = t.dims[k];
+  return DYB_OK;
+}
+// Activation-arena locations of the 15 "features" of HMR.forward(need_feature=True)
+// (reference model/hmr.py:139-168).  which: 0 = conv1 output, 1..4 = layer1..4 outputs (NHWC),
+// 5 = pooled vector (row stride 2208), 6+3t / 7+3t = fc1 output of iteration t, 8+3t = fc2 output.
+extern "C" int dyb_hmr_feature_info(const void* plan, int which, long long* offset, int* dims4, int* row_stride) {
+  const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
+  DYB_REQUIRE(P && offset && dims4 && row_stride && which >= 0 && which < 15, DYB_ERR_ARG);
+  dims4[0] = P->B; dims4[1] = dims4[2] = dims4[3] = 0;
+  if (which == 0) {
+    const ConvL& c = P->convs[0];
+    *offset = (long long)c.y; dims4[1] = c.Ho; dims4[2] = c.Wo; dims4[3] = c.K; *row_stride = c.K;
+  } else if (which <= 4) {
+    const ConvL& c = P->convs[P->blocks[P->layer_last_block[which - 1]].c3];
+    *offset = (long long)c.out; dims4[1] = c.Ho; dims4[2] = c.Wo; dims4[3] = c.K; *row_stride = c.K;
+  } else if (which == 5) {
+    *offset = (long long)P->a_xc[0]; dims4[1] = FEAT; *row_stride = FC1_IN_PAD;
+  } else {
+    int t = (which - 6) / 3, r = (which - 6) % 3;
+    *offset = (long long)(r == 2 ? P->a_h2[t] : P->a_h1[t]); dims4[1] = HID; *row_stride = HID;
+  }
+  return DYB_OK;
+}
+extern "C" long long dyb_hmr_act_offset_rotmat(const void* plan) { return (long long)reinterpret_cast<const HmrPlan*>(plan)->a_rot; }
+extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long long)reinterpret_cast<const HmrPlan*>(plan)->a_state; }
+
+#define RUN(x)                  \
+  do {                          \
+    int rc__ = (x);             \
+    if (rc__ != DYB_OK) return rc__; \
+  } while (0)
+
+struct WsCarve {
+  char *conv, *gn, *lin;
+  float* g[4];
+  float* reg;
+};
+static WsCarve carve(const HmrPlan& P, void* ws) {
+  WsCarve c;
+  char* b = reinterpret_cast<char*>(ws);
+  c.conv = b; b += P.ws_conv;
+  c.gn = b; b += P.ws_gn;
+  c.lin = b; b += P.ws_lin;
+  for (int i = 0; i < 4; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
+  c.reg = reinterpret_cast<float*>(b);
+  return c;
+}
+
+static int conv_gn(const HmrPlan& P, const ConvL& c, const float* params, float* acts, const float* x, const float* res,
+                   int relu, const WsCarve& w, hipStream_t st) {
+  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
+  int nslabs = 1;
+  RUN(dyb_conv_fwd_raw(d, x, params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
+  RUN(dyb_groupnorm_fwd(reinterpret_cast<const float*>(w.conv), nslabs, acts + c.y, params + c.gam, params + c.bet, res,
+                        acts + c.out, acts + c.stats, P.B, c.Ho * c.Wo, c.K, relu, w.gn, P.ws_gn, st));
+  return DYB_OK;
+}
+
+// image: [B][3][H][W] fp32 (NCHW, as the reference's dataloader produces it); init_state:
+// [B][160] = init_pose | init_shape | init_cam | 0.  Results land in the activation arena.
+extern "C" int dyb_hmr_forward(const void* plan, const float* params, const float* image, const float* init_state,
+                               int n_iter, float* acts, void* ws, size_t ws_bytes, hipStream_t st) {
+  const HmrPlan* Pp = reinterpret_cast<const HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && image && init_state && acts && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  const HmrPlan& P = *Pp;
+  DYB_REQUIRE(ws_bytes >= P.ws_total, DYB_ERR_WORKSPACE);
+  DYB_REQUIRE(P.featHW == 49, DYB_ERR_UNSUPPORTED);        // AvgPool2d(7) on a 7x7 map
+  WsCarve w = carve(P, ws);
+  const int B = P.B;
+  RUN(dyb_nchw3_to_nhwc4(image, acts + P.a_x4, B, P.H, P.W, st));
+  const ConvL& stem = P.convs[0];
+  RUN(conv_gn(P, stem, params, acts, acts + P.a_x4, nullptr, 1, w, st));
+  RUN(dyb_maxpool3x3s2_fwd(acts + stem.out, acts + P.a_pool, reinterpret_cast<uint32_t*>(acts + P.a_poolidx), B, stem.Ho,
+                           stem.Wo, stem.K, st));
+  const float* x = acts + P.a_pool;
+  for (const BlockL& b : P.blocks) {
+    const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
+    RUN(conv_gn(P, c1, params, acts, x, nullptr, 1, w, st));
+    RUN(conv_gn(P, c2, params, acts, acts + c1.out, nullptr, 1, w, st));
+    const float* res = x;
+    if (b.cd >= 0) {
+      const ConvL& cd = P.convs[b.cd];
+      RUN(conv_gn(P, cd, params, acts, x, nullptr, 0, w, st));
+      res = acts + cd.out;
+    }
+    RUN(conv_gn(P, c3, params, acts, acts + c2.out, res, 1, w, st));
+    x = acts + c3.out;
+  }
+  float* dsts[MAX_ITER];
+  for (int t = 0; t < n_iter; ++t) dsts[t] = acts + P.a_xc[t];
+  RUN(dyb_avgpool_fwd(x, dsts, n_iter, FC1_IN_PAD, B, P.featHW, FEAT, st));
+  if (hipMemcpy2DAsync(acts + P.a_xc[0] + FEAT, FC1_IN_PAD * sizeof(float), init_state, STATE_LD * sizeof(float),
+                       STATE_LD * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return DYB_ERR_LAUNCH;
+  for (int t = 0; t < n_iter; ++t) {
+    const float* xc = acts + P.a_xc[t];
+    RUN(dyb_linear_fwd(xc, FC1_IN_PAD, params + P.fc1_w, FC1_IN_PAD, params + P.fc1_b, nullptr, 0, acts + P.a_h1[t], HID, B,
+                       FC1_IN_PAD, HID, st));
+    RUN(dyb_linear_fwd(acts + P.a_h1[t], HID, params + P.fc2_w, HID, params + P.fc2_b, nullptr, 0, acts + P.a_h2[t], HID, B,
+                       HID, HID, st));
+    float* nxt = (t + 1 < n_iter) ? acts + P.a_xc[t + 1] + FEAT : acts + P.a_state;
+    int ldn = (t + 1 < n_iter) ? FC1_IN_PAD : STATE_LD;
+    RUN(dyb_linear_fwd(acts + P.a_h2[t], HID, params + P.dec_w, HID, params + P.dec_b, xc + FEAT, FC1_IN_PAD, nxt, ldn, B,
+                       HID, STATE_LD, st));
+  }
+  RUN(dyb_rot6d_fwd(acts + P.a_state, STATE_LD, acts + P.a_rot, B, st));
+  return DYB_OK;
+}
+
+static int gn_conv_bwd(const HmrPlan& P, const ConvL& c, const float* params, const float* acts, float* grads,
+                       const float* conv_in, const float* dout, int relu, float* dy_buf, float* dres, float* dx,
+                       const float* dx_addend, const WsCarve& w, hipStream_t st) {
+  RUN(dyb_groupnorm_bwd(dout, acts + c.out, acts + c.y, acts + c.stats, params + c.gam, dy_buf, dres, grads + c.gam,
+                        grads + c.bet, P.B, c.Ho * c.Wo, c.K, relu, w.gn, P.ws_gn, st));
+  RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv,
+                            P.ws_conv, st));
+  if (dx)
+    RUN(dyb_conv2d_nhwc_dgrad(dy_buf, params + c.w, dx, dx_addend, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad,
+                              w.conv, P.ws_conv, st));
+  return DYB_OK;
+}
+
+// d_rotmat: [B][24][9]; d_state: [B][160], only columns 144..156 (shape, cam) are read.
+// grads: parameter-arena-shaped buffer, every tensor's span is overwritten (pad gaps untouched:
+// zero them once at allocation).
+extern "C" int dyb_hmr_backward(const void* plan, const float* params, const float* acts, const float* d_rotmat,
+                                const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes,
+                                hipStream_t st) {
+  const HmrPlan* Pp = reinterpret_cast<const HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && acts && d_rotmat && d_state && grads && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  const HmrPlan& P = *Pp;
+  DYB_REQUIRE(ws_bytes >= P.ws_total, DYB_ERR_WORKSPACE);
+  WsCarve w = carve(P, ws);
+  const int B = P.B;
+  float* d_st[MAX_ITER + 1];
+  float *d_h2[MAX_ITER], *d_h1[MAX_ITER];
+  float* r = w.reg;
+  for (int t = 0; t <= MAX_ITER; ++t) { d_st[t] = r; r += (size_t)B * STATE_LD; }
+  for (int t = 0; t < MAX_ITER; ++t) { d_h2[t] = r; r += (size_t)B * HID; }
+  for (int t = 0; t < MAX_ITER; ++t) { d_h1[t] = r; r += (size_t)B * HID; }
+  float* d_xf = r;                                         // [B][2208], columns < 2048 used
+
+  // ---- regressor
+  if (hipMemcpyAsync(d_st[n_iter], d_state, (size_t)B * STATE_LD * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return DYB_ERR_LAUNCH;
+  RUN(dyb_rot6d_bwd(acts + P.a_state, STATE_LD, d_rotmat, d_st[n_iter], STATE_LD, B, st));
+  for (int t = n_iter - 1; t >= 0; --t) {
+    RUN(dyb_linear_bwd_dx(d_st[t + 1], STATE_LD, params + P.dec_w, HID, B, HID, STATE_LD, d_h2[t], HID, 0, HID, nullptr, 0,
+                          nullptr, 0, w.lin, P.ws_lin, st));
+    RUN(dyb_linear_bwd_dx(d_h2[t], HID, params + P.fc2_w, HID, B, HID, HID, d_h1[t], HID, 0, HID, nullptr, 0, nullptr, 0,
+                          w.lin, P.ws_lin, st));
+    RUN(dyb_linear_bwd_dx(d_h1[t], HID, params + P.fc1_w, FC1_IN_PAD, B, FC1_IN_PAD, HID, d_xf, FC1_IN_PAD,
+                          t < n_iter - 1 ? 1 : 0, FEAT, d_st[t], STATE_LD, d_st[t + 1], STATE_LD, w.lin, P.ws_lin, st));
+  }
+  {
+    const float *dys[MAX_ITER], *xs[MAX_ITER];
+    int ldd[MAX_ITER], ldx[MAX_ITER];
+    for (int t = 0; t < n_iter; ++t) { dys[t] = d_st[t + 1]; ldd[t] = STATE_LD; xs[t] = acts + P.a_h2[t]; ldx[t] = HID; }
+    RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, HID, STATE_LD, grads + P.dec_w, HID, grads + P.dec_b, st));
+    for (int t = 0; t < n_iter; ++t) { dys[t] = d_h2[t]; ldd[t] = HID; xs[t] = acts + P.a_h1[t]; ldx[t] = HID; }
+    RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, HID, HID, grads + P.fc2_w, HID, grads + P.fc2_b, st));
+    for (int t = 0; t < n_iter; ++t) { dys[t] = d_h1[t]; ldd[t] = HID; xs[t] = acts + P.a_xc[t]; ldx[t] = FC1_IN_PAD; }
+    RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, FC1_IN_PAD, HID, grads + P.fc1_w, FC1_IN_PAD, grads + P.fc1_b, st));
+  }
+
+  // ---- backbone, last block first.  Four ping-pong buffers:
+  //   cur  = d(block output), T1 = d(conv output), T2 = d(residual edge), T3 = d(conv input)
+  float *cur = w.g[0], *T1 = w.g[1], *T2 = w.g[2], *T3 = w.g[3];
+  RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, cur, B, P.featHW, FEAT, st));
+  for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
+    const BlockL& b = P.blocks[bi];
+    const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
+    const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
+    // out = relu(gn3(conv3(a2)) + res)
+    RUN(gn_conv_bwd(P, c3, params, acts, grads, acts + c2.out, cur, 1, T1, T2, T3, nullptr, w, st));
+    RUN(gn_conv_bwd(P, c2, params, acts, grads, acts + c1.out, T3, 1, T1, nullptr, cur, nullptr, w, st));
+    // now: cur = d(a1), T2 = d(residual edge), T1/T3 free
+    if (b.cd >= 0) {
+      const ConvL& cd = P.convs[b.cd];
+      // shortcut branch first: T3 <- dgrad_d ; then main branch adds it
+      RUN(gn_conv_bwd(P, cd, params, acts, grads, xin, T2, 0, T1, nullptr, T3, nullptr, w, st));
+      RUN(gn_conv_bwd(P, c1, params, acts, grads, xin, cur, 1, T1, nullptr, T2, T3, w, st));
+    } else {
+      RUN(gn_conv_bwd(P, c1, params, acts, grads, xin, cur, 1, T1, nullptr, T3, T2, w, st));
+      float* tmp = T2; T2 = T3; T3 = tmp;
+    }
+    // result is in T2 -> becomes cur
+    float* tmp = cur; cur = T2; T2 = tmp;
+  }
+  // ---- stem: maxpool -> GN/ReLU -> conv1 (no data gradient needed for the image)
+  const ConvL& stem = P.convs[0];
+  RUN(dyb_maxpool3x3s2_bwd(cur, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), T3, B, stem.Ho, stem.Wo, stem.K, st));
+  RUN(gn_conv_bwd(P, stem, params, acts, grads, acts + P.a_x4, T3, 1, T1, nullptr, nullptr, nullptr, w, st));
+  return DYB_OK;
+}

@@ -1,0 +1,388 @@
+// NHWC implicit-GEMM convolution on the fp32 matrix cores of gfx950:
+//   forward, data-gradient and weight-gradient as three gather flavours of one tiled GEMM
+//   built on v_mfma_f32_32x32x2_f32 (exact fp32, same numerics as an fmaf chain).
+//
+// Replaces, for the ResNet-50(GN) backbone of reference model/hmr.py:40-60,138-153, what the
+// reference gets from cuDNN through nn.Conv2d (all 53 convs are bias-free) and its autograd.
+//
+// Layouts (all fp32):
+//   activations  x[N][H][W][C]          (C = Cin, multiple of 4; the 3-channel image is padded to 4)
+//   weights      w[R][S][C][K]          (K = Cout)  == GEMM "B" matrix [R*S*C][K] row-major
+//   outputs      y[N][Ho][Wo][K]
+// GEMM views:
+//   fwd   : Y[m=(n,ho,wo)][k]        = sum_{(r,s,c)}  X(m;(r,s,c)) * W[(r,s,c)][k]
+//   dgrad : dX[m=(n,h,w)][c]         = sum_{(r,s,k)}  dY(m;(r,s,k)) * W[(r,s,c)][k]
+//   wgrad : dW[i=(r,s,c)][k]         = sum_{p=(n,ho,wo)} X(p;i) * dY[p][k]
+//
+// Tiling: 256 threads = 4 waves per workgroup, block tile 64x64, K-step 16, each wave owns one
+// 32x32 accumulator (16 VGPRs).  Operands are staged through LDS k-major ([16][64+4]) so the
+// MFMA fragment read (lane -> row lane&31, k = lane>>5) is a conflict-free ds_read_b32 and the
+// "contiguous along the tile row" sources are written with one ds_write_b128.  Global loads are
+// 16 B per lane and register-prefetched one K-step ahead of the MFMAs (two LDS buffers, one
+// barrier per step).  At batch 1 most layers have only 1..50 output tiles, so the K loop is
+// split over blockIdx.z into fp32 slabs that a second kernel (or the GroupNorm statistics
+// kernel) folds - deterministic, no atomics.
+#include "dyb_common.h"
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDS_LD (64 + 4)
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+struct IgemmArgs {
+  const float* A;        // fwd: x      dgrad: dy     wgrad: x
+  const float* B;        // fwd: w      dgrad: w      wgrad: dy
+  float* out;            // result, or slab base when nsplit > 1
+  const float* addend;   // optional, only honoured when nsplit == 1 (out = acc + addend)
+  int N, H, W, C;        // input activation geometry
+  int K;                 // Cout
+  int R, S, stride, pad;
+  int Ho, Wo;
+  int logC, logK;
+  int M, Ncols, Kdim;    // GEMM sizes for this mode
+  int ktiles, tiles_per_split, nsplit;
+};
+
+// ---- tile loaders: each returns the 16 bytes this thread contributes to the K-step tile ----
+
+// rows = output pixels, k = (r,s,c) with c fastest                       (fwd A)
+struct FwdARow {
+  int base_n, hi0, wi0;
+  bool valid;
+};
+__device__ __forceinline__ FwdARow fwd_a_row(const IgemmArgs& g, int m) {
+  FwdARow r;
+  r.valid = m < g.M;
+  int mm = r.valid ? m : 0;
+  int wo = mm % g.Wo;
+  int t = mm / g.Wo;
+  int ho = t % g.Ho;
+  int n = t / g.Ho;
+  r.base_n = n * g.H * g.W;
+  r.hi0 = ho * g.stride - g.pad;
+  r.wi0 = wo * g.stride - g.pad;
+  return r;
+}
+__device__ __forceinline__ float4 fwd_a_load(const IgemmArgs& g, const FwdARow& row, int k) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row.valid && k < g.Kdim) {
+    int rs = k >> g.logC;
+    int c = k & (g.C - 1);
+    int r = rs / g.S;
+    int s = rs - r * g.S;
+    int hi = row.hi0 + r, wi = row.wi0 + s;
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
+      v = *reinterpret_cast<const float4*>(g.A + (((size_t)(row.base_n + hi * g.W + wi)) << g.logC) + c);
+  }
+  return v;
+}
+
+// rows = input pixels, k = (r,s,ko) with ko fastest                      (dgrad A)
+struct DgARow {
+  int n, h, w;
+  bool valid;
+};
+__device__ __forceinline__ DgARow dg_a_row(const IgemmArgs& g, int m) {
+  DgARow r;
+  r.valid = m < g.M;
+  int mm = r.valid ? m : 0;
+  r.w = mm % g.W;
+  int t = mm / g.W;
+  r.h = t % g.H;
+  r.n = t / g.H;
+  return r;
+}
+__device__ __forceinline__ float4 dg_a_load(const IgemmArgs& g, const DgARow& row, int kk) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row.valid && kk < g.Kdim) {
+    int rs = kk >> g.logK;
+    int ko = kk & (g.K - 1);
+    int r = rs / g.S;
+    int s = rs - r * g.S;
+    int th = row.h + g.pad - r, tw = row.w + g.pad - s;
+    int sm = g.stride - 1;                       // stride is 1 or 2
+    if (th >= 0 && tw >= 0 && (th & sm) == 0 && (tw & sm) == 0) {
+      int ho = th >> (g.stride >> 1), wo = tw >> (g.stride >> 1);
+      if (ho < g.Ho && wo < g.Wo)
+        v = *reinterpret_cast<const float4*>(g.A + (((size_t)((row.n * g.Ho + ho) * g.Wo + wo)) << g.logK) + ko);
+    }
+  }
+  return v;
+}
+// rows = cin, k = (r,s,ko) with ko fastest: W[(rs*C + c)*K + ko]         (dgrad B, transposing)
+__device__ __forceinline__ float4 dg_b_load(const IgemmArgs& g, int c, int kk) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < g.Ncols && kk < g.Kdim) {
+    int rs = kk >> g.logK;
+    int ko = kk & (g.K - 1);
+    v = *reinterpret_cast<const float4*>(g.B + ((((size_t)rs << g.logC) + c) << g.logK) + ko);
+  }
+  return v;
+}
+// direct [k][n] row-major matrix with leading dimension ld               (fwd B, wgrad B)
+__device__ __forceinline__ float4 direct_load(const float* base, int ld, int rows, int cols, int k, int n) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < rows && n < cols) v = *reinterpret_cast<const float4*>(base + (size_t)k * ld + n);
+  return v;
+}
+// rows i = (r,s,c) (4 consecutive c per thread), column p = pixel        (wgrad A, direct)
+struct WgARow {
+  int r, s, c;
+  bool valid;
+};
+__device__ __forceinline__ WgARow wg_a_row(const IgemmArgs& g, int i) {
+  WgARow w;
+  w.valid = i < g.M;
+  int ii = w.valid ? i : 0;
+  int rs = ii >> g.logC;
+  w.c = ii & (g.C - 1);
+  w.r = rs / g.S;
+  w.s = rs - w.r * g.S;
+  return w;
+}
+__device__ __forceinline__ float4 wg_a_load(const IgemmArgs& g, const WgARow& row, int p) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row.valid && p < g.Kdim) {
+    int wo = p % g.Wo;
+    int t = p / g.Wo;
+    int ho = t % g.Ho;
+    int n = t / g.Ho;
+    int hi = ho * g.stride - g.pad + row.r, wi = wo * g.stride - g.pad + row.s;
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
+      v = *reinterpret_cast<const float4*>(g.A + (((size_t)((n * g.H + hi) * g.W + wi)) << g.logC) + row.c);
+  }
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int kt_begin = blockIdx.z * g.tiles_per_split;
+  int kt_end = kt_begin + g.tiles_per_split;
+  if (kt_end > g.ktiles) kt_end = g.ktiles;
+
+  // "transposing" mapping: one tile row, 4 consecutive k          (t_row, t_kq)
+  // "direct" mapping     : one k, 4 consecutive tile columns       (d_k, d_q)
+  const int t_row = tid >> 2, t_kq = (tid & 3) * 4;
+  const int d_k = tid >> 4, d_q = (tid & 15) * 4;
+
+  FwdARow fa;
+  DgARow da;
+  WgARow wa;
+  if constexpr (MODE == MODE_FWD) fa = fwd_a_row(g, m0 + t_row);
+  if constexpr (MODE == MODE_DGRAD) da = dg_a_row(g, m0 + t_row);
+  if constexpr (MODE == MODE_WGRAD) wa = wg_a_row(g, m0 + d_q);
+
+  auto load_a = [&](int kt) -> float4 {
+    if constexpr (MODE == MODE_FWD) return fwd_a_load(g, fa, kt * BK + t_kq);
+    else if constexpr (MODE == MODE_DGRAD) return dg_a_load(g, da, kt * BK + t_kq);
+    else return wg_a_load(g, wa, kt * BK + d_k);
+  };
+  auto load_b = [&](int kt) -> float4 {
+    if constexpr (MODE == MODE_FWD) return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + d_k, n0 + d_q);
+    else if constexpr (MODE == MODE_DGRAD) return dg_b_load(g, n0 + t_row, kt * BK + t_kq);
+    else return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + d_k, n0 + d_q);
+  };
+  auto store_a = [&](int buf, float4 v) {
+    if constexpr (MODE == MODE_WGRAD) {
+      *reinterpret_cast<float4*>(&As[buf][d_k][d_q]) = v;
+    } else {
+      As[buf][t_kq + 0][t_row] = v.x;
+      As[buf][t_kq + 1][t_row] = v.y;
+      As[buf][t_kq + 2][t_row] = v.z;
+      As[buf][t_kq + 3][t_row] = v.w;
+    }
+  };
+  auto store_b = [&](int buf, float4 v) {
+    if constexpr (MODE == MODE_DGRAD) {
+      Bs[buf][t_kq + 0][t_row] = v.x;
+      Bs[buf][t_kq + 1][t_row] = v.y;
+      Bs[buf][t_kq + 2][t_row] = v.z;
+      Bs[buf][t_kq + 3][t_row] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(&Bs[buf][d_k][d_q]) = v;
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  if (kt_begin < kt_end) {
+    float4 ra = load_a(kt_begin), rb = load_b(kt_begin);
+    store_a(0, ra);
+    store_b(0, rb);
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = (kt + 1) < kt_end;
+      if (more) {
+        ra = load_a(kt + 1);
+        rb = load_b(kt + 1);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < BK; k2 += 2) {
+        float a = As[buf][k2 + khalf][arow];
+        float b = Bs[buf][k2 + khalf][bcol];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      if (more) {
+        store_a(buf ^ 1, ra);
+        store_b(buf ^ 1, rb);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // C/D fragment of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* outp = g.out + (g.nsplit > 1 ? (size_t)blockIdx.z * g.M * g.Ncols : 0);
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col < g.Ncols) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < g.M) {
+        size_t o = (size_t)row * g.Ncols + col;
+        float v = acc[r];
+        if (g.nsplit == 1 && g.addend) v += g.addend[o];
+        outp[o] = v;
+      }
+    }
+  }
+}
+
+// out[i] = sum_z slab[z][i] (+ addend[i]);  n4 = element count / 4
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ slabs, const float4* __restrict__ addend,
+                                                             float4* __restrict__ out, int nsplit, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += step) {
+    float4 s = slabs[i];
+    for (int z = 1; z < nsplit; ++z) {
+      float4 t = slabs[(size_t)z * n4 + i];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (addend) {
+      float4 t = addend[i];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    out[i] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
+  DYB_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(dyb_is_pow2(d.C) && d.C >= 4 && dyb_is_pow2(d.K) && d.K >= 4, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(d.stride == 1 || d.stride == 2, DYB_ERR_UNSUPPORTED);
+  g.N = d.N; g.H = d.H; g.W = d.W; g.C = d.C; g.K = d.K; g.R = d.R; g.S = d.S;
+  g.stride = d.stride; g.pad = d.pad;
+  g.Ho = conv_out_dim(d.H, d.R, d.stride, d.pad);
+  g.Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
+  g.logC = dyb_ilog2(d.C); g.logK = dyb_ilog2(d.K);
+  if (mode == MODE_FWD) { g.M = d.N * g.Ho * g.Wo; g.Ncols = d.K; g.Kdim = d.R * d.S * d.C; }
+  else if (mode == MODE_DGRAD) { g.M = d.N * d.H * d.W; g.Ncols = d.C; g.Kdim = d.R * d.S * d.K; }
+  else { g.M = d.R * d.S * d.C; g.Ncols = d.K; g.Kdim = d.N * g.Ho * g.Wo; }
+  g.ktiles = dyb_cdiv(g.Kdim, BK);
+  return DYB_OK;
+}
+
+// Split-K policy: aim for >= ~3 workgroups per CU (768) while keeping >= 4 K-steps per split.
+static int choose_split(const IgemmArgs& g, size_t ws_floats) {
+  int tiles = dyb_cdiv(g.M, BM) * dyb_cdiv(g.Ncols, BN);
+  int want = dyb_cdiv(768, tiles);
+  int cap = g.ktiles / 4;
+  if (cap < 1) cap = 1;
+  int s = want < cap ? want : cap;
+  if (s < 1) s = 1;
+  size_t per = (size_t)g.M * g.Ncols;
+  while (s > 1 && (size_t)s * per > ws_floats) --s;
+  return s;
+}
+
+extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+  // worst case over the three modes: nsplit * M * Ncols floats, nsplit bounded by the policy above
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  size_t best = 0;
+  for (int mode = 0; mode < 3; ++mode) {
+    IgemmArgs g{};
+    if (fill_args(g, d, mode) != DYB_OK) return 0;
+    int s = choose_split(g, (size_t)-1 / 8);
+    size_t need = (s > 1) ? (size_t)s * g.M * g.Ncols * sizeof(float) : 0;
+    if (need > best) best = need;
+  }
+  return best;
+}
+
+// Runs one mode.  If `raw_slabs_out` is non-null and the policy picks nsplit>1 the slabs are left
+// in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
+// GroupNorm statistics kernel); otherwise the result lands in `out`.
+static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B, float* out, const float* addend,
+                     void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st) {
+  DYB_REQUIRE(A && B && out, DYB_ERR_ARG);
+  IgemmArgs g{};
+  int rc = fill_args(g, d, mode);
+  if (rc != DYB_OK) return rc;
+  g.A = A; g.B = B;
+  g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0);
+  g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
+  g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits
+  if (raw_slabs_out) *raw_slabs_out = 1;
+  const bool split = g.nsplit > 1;
+  g.out = split ? reinterpret_cast<float*>(ws) : out;
+  g.addend = split ? nullptr : addend;
+  dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit);
+  if (mode == MODE_FWD) hipLaunchKernelGGL(igemm_mfma_kernel<MODE_FWD>, grid, dim3(256), 0, st, g);
+  else if (mode == MODE_DGRAD) hipLaunchKernelGGL(igemm_mfma_kernel<MODE_DGRAD>, grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(igemm_mfma_kernel<MODE_WGRAD>, grid, dim3(256), 0, st, g);
+  DYB_CHECK_LAUNCH();
+  if (split) {
+    if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
+    size_t n4 = (size_t)g.M * g.Ncols / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
+                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4);
+    DYB_CHECK_LAUNCH();
+  }
+  return DYB_OK;
+}
+
+int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y, void* ws, size_t ws_bytes,
+                     int* nslabs, hipStream_t st) {
+  return run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, nslabs, st);
+}
+
+extern "C" int dyb_conv2d_nhwc_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R,
+                                   int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  return run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, nullptr, st);
+}
+// dx = conv_transpose(dy, w) (+ addend, e.g. the gradient arriving over the residual edge)
+extern "C" int dyb_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                                     size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  return run_igemm(MODE_DGRAD, d, dy, w, dx, addend, ws, ws_bytes, nullptr, st);
+}
+extern "C" int dyb_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K,
+                                     int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  return run_igemm(MODE_WGRAD, d, x, dy, dw, nullptr, ws, ws_bytes, nullptr, st);
+}

@@ -1,0 +1,201 @@
+// Fully-connected layers of the iterative SMPL-parameter regressor (reference model/hmr.py:82-90,
+// 158-172): fc1 2205->1024, fc2 1024->1024 and the three decoder heads (144+10+3 rows, stored as
+// one [160][1024] matrix).  At batch 1..16 these are GEMV-class and bound by streaming the weight
+// rows (fc1 = 9 MB), so: one wave per output row, 16 B per lane, butterfly reduction; the
+// transposed product for backward reads the same rows coalesced and splits the output-row range
+// over blockIdx.y into partial slabs (deterministic fold, no atomics); weight gradients of all
+// three regressor iterations are produced by ONE rank-(3B) outer-product pass per matrix so each
+// dW is written exactly once.
+//
+// Weight layout is the reference's (out_features, in_features) row-major with the row stride
+// `ldw` padded to a multiple of 4 floats (fc1: 2205 -> 2208); pad columns are kept at zero.
+#include "dyb_common.h"
+
+#define LIN_BT 4   // batch tile held in registers
+
+// y[b][o] = bias[o] + W[o][:] . x[b][:] (+ res[b][o]);  grid = ceil(O/4), block = 256 (4 waves)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         int ldw, const float* __restrict__ bias,
+                                                         const float* __restrict__ res, int ldres, float* __restrict__ y,
+                                                         int ldy, int B, int I, int O) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  if (o >= O) return;
+  const float* wr = w + (size_t)o * ldw;
+  const int I4 = I >> 2;
+  for (int b0 = 0; b0 < B; b0 += LIN_BT) {
+    float acc[LIN_BT];
+#pragma unroll
+    for (int t = 0; t < LIN_BT; ++t) acc[t] = 0.f;
+    for (int i4 = lane; i4 < I4; i4 += 64) {
+      float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)i4 * 4);
+#pragma unroll
+      for (int t = 0; t < LIN_BT; ++t) {
+        if (b0 + t < B) {
+          float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + t) * ldx + (size_t)i4 * 4);
+          acc[t] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < LIN_BT; ++t) {
+      float s = dyb_wave_sum(acc[t]);
+      if (lane == 0 && b0 + t < B) {
+        float v = s + bias[o];
+        if (res) v += res[(size_t)(b0 + t) * ldres + o];
+        y[(size_t)(b0 + t) * ldy + o] = v;
+      }
+    }
+  }
+}
+
+extern "C" int dyb_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* res,
+                              int ldres, float* y, int ldy, int B, int I, int O, hipStream_t st) {
+  DYB_REQUIRE(x && w && bias && y && B > 0 && O > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(I % 4 == 0 && ldw % 4 == 0 && ldx % 4 == 0, DYB_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(dyb_cdiv(O, 4)), dim3(256), 0, st, x, ldx, w, ldw, bias, res, ldres, y, ldy,
+                     B, I, O);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// partial[s][b][i] = sum_{o in split s} dy[b][o] * W[o][i]
+// grid (ceil(I/256), nsplit), block 256 = 64 float4-columns x 4 row lanes
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                            int ldw, float* __restrict__ partial, int B, int I, int O,
+                                                            int rows_per_split) {
+  __shared__ float sm[4][64][4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i4 = blockIdx.x * 64 + tx;
+  const bool live = i4 * 4 < I;
+  const int o0 = blockIdx.y * rows_per_split;
+  int o1 = o0 + rows_per_split;
+  if (o1 > O) o1 = O;
+  for (int b0 = 0; b0 < B; b0 += LIN_BT) {
+    float4 acc[LIN_BT];
+#pragma unroll
+    for (int t = 0; t < LIN_BT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      for (int o = o0 + ty; o < o1; o += 4) {
+        float4 wv = *reinterpret_cast<const float4*>(w + (size_t)o * ldw + (size_t)i4 * 4);
+#pragma unroll
+        for (int t = 0; t < LIN_BT; ++t) {
+          if (b0 + t < B) {
+            float d = dy[(size_t)(b0 + t) * lddy + o];
+            acc[t].x += d * wv.x; acc[t].y += d * wv.y; acc[t].z += d * wv.z; acc[t].w += d * wv.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < LIN_BT; ++t) {
+      __syncthreads();
+      sm[ty][tx][0] = acc[t].x; sm[ty][tx][1] = acc[t].y; sm[ty][tx][2] = acc[t].z; sm[ty][tx][3] = acc[t].w;
+      __syncthreads();
+      if (ty == 0 && live && b0 + t < B) {
+        float4 r;
+        r.x = (sm[0][tx][0] + sm[1][tx][0]) + (sm[2][tx][0] + sm[3][tx][0]);
+        r.y = (sm[0][tx][1] + sm[1][tx][1]) + (sm[2][tx][1] + sm[3][tx][1]);
+        r.z = (sm[0][tx][2] + sm[1][tx][2]) + (sm[2][tx][2] + sm[3][tx][2]);
+        r.w = (sm[0][tx][3] + sm[1][tx][3]) + (sm[2][tx][3] + sm[3][tx][3]);
+        *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * B + (b0 + t)) * I + (size_t)i4 * 4) = r;
+      }
+    }
+  }
+}
+
+// dst[b][i] = sum_s partial[s][b][i] (+ add[b][i]); optional second destination for columns >= split_col:
+//   i <  split_col -> dstA[b*ldA + i]           (accumulate into dstA when accA != 0)
+//   i >= split_col -> dstB[b*ldB + i-split_col] = value + addB[b*ldaddB + i-split_col]
+__global__ __launch_bounds__(256) void linear_dx_fold_kernel(const float* __restrict__ partial, int nsplit, int B, int I,
+                                                             float* __restrict__ dstA, int ldA, int accA, int split_col,
+                                                             float* __restrict__ dstB, int ldB, const float* __restrict__ addB,
+                                                             int ldaddB) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * I) return;
+  int b = idx / I, i = idx % I;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += partial[((size_t)z * B + b) * I + i];
+  if (i < split_col) {
+    float* d = dstA + (size_t)b * ldA + i;
+    *d = accA ? (*d + s) : s;
+  } else {
+    int j = i - split_col;
+    dstB[(size_t)b * ldB + j] = s + (addB ? addB[(size_t)b * ldaddB + j] : 0.f);
+  }
+}
+
+static int lin_split(int I, int O) {
+  int cols = dyb_cdiv(I, 256);
+  int s = dyb_cdiv(256, cols);           // ~256 workgroups
+  int cap = O / 16 > 1 ? O / 16 : 1;     // >= 16 rows per split
+  return s < cap ? s : cap;
+}
+extern "C" size_t dyb_linear_bwd_workspace_bytes(int B, int I, int O) {
+  return (size_t)lin_split(I, O) * B * I * sizeof(float);
+}
+// dx = dy @ W, routed: columns [0,split_col) -> dstA (+= when accA), columns [split_col,I) -> dstB (+ addB).
+// Pass split_col = I and dstB = NULL for a plain dx.
+extern "C" int dyb_linear_bwd_dx(const float* dy, int lddy, const float* w, int ldw, int B, int I, int O, float* dstA,
+                                 int ldA, int accA, int split_col, float* dstB, int ldB, const float* addB, int ldaddB,
+                                 void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(dy && w && dstA && ws && B > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(I % 4 == 0 && ldw % 4 == 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(split_col == I || dstB, DYB_ERR_ARG);
+  int ns = lin_split(I, O);
+  DYB_REQUIRE(ws_bytes >= (size_t)ns * B * I * sizeof(float), DYB_ERR_WORKSPACE);
+  int rps = dyb_cdiv(O, ns);
+  ns = dyb_cdiv(O, rps);
+  float* partial = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(dyb_cdiv(I, 256), ns), dim3(256), 0, st, dy, lddy, w, ldw, partial, B, I,
+                     O, rps);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(linear_dx_fold_kernel, dim3(dyb_cdiv(B * I, 256)), dim3(256), 0, st, (const float*)partial, ns, B,
+                     I, dstA, ldA, accA, split_col, dstB, ldB, addB, ldaddB);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// dW[o][i] = sum_{t<T} sum_b dy_t[b][o] * x_t[b][i];  db[o] = sum_t sum_b dy_t[b][o]
+struct OuterArgs {
+  const float* dy[4];
+  const float* x[4];
+  int lddy[4], ldx[4];
+};
+// grid (ceil(I4/64), ceil(O/4)), block 256: 64 float4-columns x 4 rows
+__global__ __launch_bounds__(256) void linear_outer_kernel(OuterArgs a, int T, int B, int I, int O, float* __restrict__ dw,
+                                                           int ldw, float* __restrict__ db) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i4 = blockIdx.x * 64 + tx;
+  const int o = blockIdx.y * 4 + ty;
+  if (o >= O) return;
+  const bool live = i4 * 4 < I;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bs = 0.f;
+  for (int t = 0; t < T; ++t) {
+    for (int b = 0; b < B; ++b) {
+      float d = a.dy[t][(size_t)b * a.lddy[t] + o];
+      bs += d;
+      if (live) {
+        float4 xv = *reinterpret_cast<const float4*>(a.x[t] + (size_t)b * a.ldx[t] + (size_t)i4 * 4);
+        acc.x += d * xv.x; acc.y += d * xv.y; acc.z += d * xv.z; acc.w += d * xv.w;
+      }
+    }
+  }
+  if (live) *reinterpret_cast<float4*>(dw + (size_t)o * ldw + (size_t)i4 * 4) = acc;
+  if (blockIdx.x == 0 && tx == 0) db[o] = bs;
+}
+extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, const float* const* xs, const int* ldxs,
+                                 int T, int B, int I, int O, float* dw, int ldw, float* db, hipStream_t st) {
+  DYB_REQUIRE(dys && xs && dw && db && T >= 1 && T <= 4, DYB_ERR_ARG);
+  DYB_REQUIRE(I % 4 == 0 && ldw % 4 == 0, DYB_ERR_UNSUPPORTED);
+  OuterArgs a{};
+  for (int t = 0; t < T; ++t) {
+    a.dy[t] = dys[t]; a.x[t] = xs[t]; a.lddy[t] = lddys[t]; a.ldx[t] = ldxs[t];
+    DYB_REQUIRE(a.ldx[t] % 4 == 0, DYB_ERR_UNSUPPORTED);
+  }
+  hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4)), dim3(256), 0, st, a, T, B, I, O, dw,
+                     ldw, db);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

@@ -1,0 +1,366 @@
+// Frame-loss head: value AND gradient of
+//     w2d * kp2d_loss + wshape * shape_prior + wpose * pose_prior
+// in one launch (one workgroup per sample), plus stand-alone projection fwd/bwd used by the
+// temporal / teacher terms.
+//
+// Follows reference base_adaptor.py:160-170 (projection), :229,234 (confidence-masked 2-D MSE over
+// the 24 GT-style joints), :401-409 (shape / pose priors), utils/geometry.py:184-306
+// (rotation_matrix_to_angle_axis, kornia-derived 4-branch quaternion formula, NaN -> 0) and
+// utils/smplify/prior.py:181-196 (merged max-mixture GMM).  The analytic backward is the chain
+// rule of exactly that formula (same branch selection), so it matches torch autograd of the
+// reference away from the theta -> 0 singularity (where autograd itself produces inf*0).
+#include "dyb_common.h"
+
+#define NJ 24
+#define NJ49 49
+#define NG 8
+#define ND 69
+#define FOCAL 5000.0f
+#define IMG_RES 224.0f
+
+struct QuatFwd {
+  int branch;
+  float t;        // selected trace term
+  float u[4];     // un-normalised quaternion (one component equals t)
+  float q[4];     // 0.5*u/sqrt(t)
+};
+__device__ __forceinline__ QuatFwd rot_to_quat(const float* R) {
+  const float eps = 1e-6f;
+  float r00 = R[0], r01 = R[1], r02 = R[2], r10 = R[3], r11 = R[4], r12 = R[5], r20 = R[6], r21 = R[7], r22 = R[8];
+  bool d2 = r22 < eps, d01 = r00 > r11, d0n1 = r00 < -r11;
+  QuatFwd f;
+  if (d2 && d01) {
+    f.branch = 0; f.t = 1.f + r00 - r11 - r22;
+    f.u[0] = r21 - r12; f.u[1] = f.t; f.u[2] = r10 + r01; f.u[3] = r02 + r20;
+  } else if (d2) {
+    f.branch = 1; f.t = 1.f - r00 + r11 - r22;
+    f.u[0] = r02 - r20; f.u[1] = r10 + r01; f.u[2] = f.t; f.u[3] = r21 + r12;
+  } else if (d0n1) {
+    f.branch = 2; f.t = 1.f - r00 - r11 + r22;
+    f.u[0] = r10 - r01; f.u[1] = r02 + r20; f.u[2] = r21 + r12; f.u[3] = f.t;
+  } else {
+    f.branch = 3; f.t = 1.f + r00 + r11 + r22;
+    f.u[0] = f.t; f.u[1] = r21 - r12; f.u[2] = r02 - r20; f.u[3] = r10 - r01;
+  }
+  float k = 0.5f / sqrtf(f.t);
+  for (int i = 0; i < 4; ++i) f.q[i] = f.u[i] * k;
+  return f;
+}
+__device__ __forceinline__ void quat_to_aa(const float* q, float* aa) {
+  float w = q[0];
+  float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  float s = sqrtf(s2);
+  float tt = 2.f * (w < 0.f ? atan2f(-s, -w) : atan2f(s, w));
+  float k = s2 > 0.f ? tt / s : 2.f;
+  for (int i = 0; i < 3; ++i) {
+    float v = q[1 + i] * k;
+    aa[i] = (v != v) ? 0.f : v;
+  }
+}
+// dR (9) from g = dL/d(aa)
+__device__ __forceinline__ void aa_bwd(const float* R, const float* g, float* dR) {
+  QuatFwd f = rot_to_quat(R);
+  const float* q = f.q;
+  float w = q[0];
+  float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  float s = sqrtf(s2);
+  float gq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (s2 > 0.f) {
+    float tt = 2.f * (w < 0.f ? atan2f(-s, -w) : atan2f(s, w));
+    float k = tt / s;
+    float gk = g[0] * q[1] + g[1] * q[2] + g[2] * q[3];
+    float den = s2 + w * w;
+    float g_tt = gk / s;
+    float g_s = -gk * tt / s2 + g_tt * (2.f * w / den);
+    gq[0] = g_tt * (-2.f * s / den);
+    float g_s2 = g_s / (2.f * s);
+    for (int i = 0; i < 3; ++i) gq[1 + i] = g[i] * k + 2.f * q[1 + i] * g_s2;
+  } else {
+    for (int i = 0; i < 3; ++i) gq[1 + i] = g[i] * 2.f;
+  }
+  // q = 0.5 * u / sqrt(t)
+  float rt = sqrtf(f.t);
+  float gu[4];
+  float dot = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    gu[i] = 0.5f * gq[i] / rt;
+    dot += gq[i] * f.u[i];
+  }
+  float gt = -0.25f * dot / (f.t * rt);
+  for (int i = 0; i < 9; ++i) dR[i] = 0.f;
+  // index order: r00 0, r01 1, r02 2, r10 3, r11 4, r12 5, r20 6, r21 7, r22 8
+  switch (f.branch) {
+    case 0:
+      gt += gu[1];
+      dR[7] += gu[0]; dR[5] -= gu[0];
+      dR[3] += gu[2]; dR[1] += gu[2];
+      dR[2] += gu[3]; dR[6] += gu[3];
+      dR[0] += gt; dR[4] -= gt; dR[8] -= gt;
+      break;
+    case 1:
+      gt += gu[2];
+      dR[2] += gu[0]; dR[6] -= gu[0];
+      dR[3] += gu[1]; dR[1] += gu[1];
+      dR[7] += gu[3]; dR[5] += gu[3];
+      dR[0] -= gt; dR[4] += gt; dR[8] -= gt;
+      break;
+    case 2:
+      gt += gu[3];
+      dR[3] += gu[0]; dR[1] -= gu[0];
+      dR[2] += gu[1]; dR[6] += gu[1];
+      dR[7] += gu[2]; dR[5] += gu[2];
+      dR[0] -= gt; dR[4] -= gt; dR[8] += gt;
+      break;
+    default:
+      gt += gu[0];
+      dR[7] += gu[1]; dR[5] -= gu[1];
+      dR[2] += gu[2]; dR[6] -= gu[2];
+      dR[3] += gu[3]; dR[1] -= gu[3];
+      dR[0] += gt; dR[4] += gt; dR[8] += gt;
+      break;
+  }
+}
+
+__global__ __launch_bounds__(64) void rotmat_to_aa_kernel(const float* __restrict__ R, float* __restrict__ aa, int n) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  QuatFwd f = rot_to_quat(R + (size_t)i * 9);
+  quat_to_aa(f.q, aa + (size_t)i * 3);
+}
+__global__ __launch_bounds__(64) void rotmat_to_aa_bwd_kernel(const float* __restrict__ R, const float* __restrict__ g,
+                                                              float* __restrict__ dR, int n) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float d[9];
+  aa_bwd(R + (size_t)i * 9, g + (size_t)i * 3, d);
+  for (int k = 0; k < 9; ++k) dR[(size_t)i * 9 + k] = d[k];
+}
+extern "C" int dyb_rotmat_to_aa_fwd(const float* R, float* aa, int n, hipStream_t st) {
+  DYB_REQUIRE(R && aa && n > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(rotmat_to_aa_kernel, dim3(dyb_cdiv(n, 64)), dim3(64), 0, st, R, aa, n);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_rotmat_to_aa_bwd(const float* R, const float* daa, float* dR, int n, hipStream_t st) {
+  DYB_REQUIRE(R && daa && dR && n > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(rotmat_to_aa_bwd_kernel, dim3(dyb_cdiv(n, 64)), dim3(64), 0, st, R, daa, dR, n);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// projection (fwd / bwd), n points per sample
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void projection_fwd_kernel(const float* __restrict__ cam, int ldc,
+                                                            const float* __restrict__ p3, float* __restrict__ p2, int np,
+                                                            int total) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= total) return;
+  int b = i / np;
+  const float* c = cam + (size_t)b * ldc;
+  float tz = 2.f * FOCAL / (IMG_RES * c[0] + 1e-9f);
+  float x = p3[(size_t)i * 3] + c[1], y = p3[(size_t)i * 3 + 1] + c[2], z = p3[(size_t)i * 3 + 2] + tz;
+  p2[(size_t)i * 2] = FOCAL * (x / z) / (IMG_RES * 0.5f);
+  p2[(size_t)i * 2 + 1] = FOCAL * (y / z) / (IMG_RES * 0.5f);
+}
+// dp3 per point; dcam reduced per sample by one workgroup (grid = B)
+__global__ __launch_bounds__(64) void projection_bwd_kernel(const float* __restrict__ cam, int ldc,
+                                                            const float* __restrict__ p3, const float* __restrict__ g2,
+                                                            float* __restrict__ dp3, float* __restrict__ dcam, int lddc,
+                                                            int np) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* c = cam + (size_t)b * ldc;
+  float den = IMG_RES * c[0] + 1e-9f;
+  float tz = 2.f * FOCAL / den;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = t; j < np; j += 64) {
+    size_t i = (size_t)b * np + j;
+    float x = p3[i * 3] + c[1], y = p3[i * 3 + 1] + c[2], z = p3[i * 3 + 2] + tz;
+    float k = FOCAL / (IMG_RES * 0.5f);
+    float gx = g2[i * 2] * k / z, gy = g2[i * 2 + 1] * k / z;
+    float gz = -(gx * x + gy * y) / z;
+    dp3[i * 3] = gx; dp3[i * 3 + 1] = gy; dp3[i * 3 + 2] = gz;
+    sx += gx; sy += gy; sz += gz;
+  }
+  sx = dyb_wave_sum(sx); sy = dyb_wave_sum(sy); sz = dyb_wave_sum(sz);
+  if (t == 0) {
+    float* d = dcam + (size_t)b * lddc;
+    d[0] = sz * (-2.f * FOCAL * IMG_RES / (den * den));
+    d[1] = sx;
+    d[2] = sy;
+  }
+}
+extern "C" int dyb_projection_fwd(const float* cam, int ldc, const float* p3, float* p2, int B, int np, hipStream_t st) {
+  DYB_REQUIRE(cam && p3 && p2 && B > 0 && np > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(projection_fwd_kernel, dim3(dyb_cdiv(B * np, 64)), dim3(64), 0, st, cam, ldc, p3, p2, np, B * np);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_projection_bwd(const float* cam, int ldc, const float* p3, const float* g2, float* dp3, float* dcam,
+                                  int lddc, int B, int np, hipStream_t st) {
+  DYB_REQUIRE(cam && p3 && g2 && dp3 && dcam && B > 0 && np > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(projection_bwd_kernel, dim3(B), dim3(64), 0, st, cam, ldc, p3, g2, dp3, dcam, lddc, np);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused frame losses, value + gradient
+// ------------------------------------------------------------------------------------------
+struct FrameLossArgs {
+  const float* rot;      // [B][24][9]
+  const float* shape;    // [B][lds]  (10 used)
+  const float* cam;      // [B][ldc]  (3 used)
+  const float* joints;   // [B][49][3]
+  const float* kp;       // [B][49][3] (x, y, conf)
+  const float* means;    // [8][69]
+  const float* prec;     // [8][69][69]
+  const float* logw;     // [8]   log(nll_weights)
+  float* parts;          // [B][4]  per-sample (s2d, shape, pose, weighted total) already / B etc.
+  float* drot;           // [B][24][9]
+  float* dshape;         // [B][ldds]
+  float* dcam;           // [B][lddc]
+  float* djoints;        // [B][49][3]
+  int lds, ldc, ldds, lddc, B;
+  float w2d, wshape, wpose;
+};
+
+__global__ __launch_bounds__(256) void frame_losses_kernel(FrameLossArgs a) {
+  __shared__ float sAA[ND], sD[NG][ND], sRow[NG][ND], sCol[NG][ND], sQ[NG], sG[ND];
+  __shared__ float sCamG[NJ][3], sL2d[NJ];
+  __shared__ int sBest;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float invB = 1.0f / (float)a.B;
+  const float* R = a.rot + (size_t)b * NJ * 9;
+
+  // --- pose prior: axis-angle of the 23 body joints
+  if (t < NJ - 1) {
+    QuatFwd f = rot_to_quat(R + (t + 1) * 9);
+    quat_to_aa(f.q, &sAA[t * 3]);
+  }
+  __syncthreads();
+  for (int i = t; i < NG * ND; i += 256) {
+    int m = i / ND, k = i % ND;
+    sD[m][k] = sAA[k] - a.means[i];
+  }
+  __syncthreads();
+  for (int i = t; i < NG * ND; i += 256) {
+    int m = i / ND, k = i % ND;
+    const float* P = a.prec + (size_t)m * ND * ND;
+    float r = 0.f, c = 0.f;
+    for (int j = 0; j < ND; ++j) {
+      float d = sD[m][j];
+      r += P[k * ND + j] * d;
+      c += P[j * ND + k] * d;
+    }
+    sRow[m][k] = r;
+    sCol[m][k] = c;
+  }
+  __syncthreads();
+  if (t < NG) {
+    float q = 0.f;
+    for (int k = 0; k < ND; ++k) q += sRow[t][k] * sD[t][k];
+    sQ[t] = 0.5f * q - a.logw[t];
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    for (int m = 1; m < NG; ++m)
+      if (sQ[m] < sQ[best]) best = m;
+    sBest = best;
+  }
+  __syncthreads();
+  const int mb = sBest;
+  if (t < ND) sG[t] = a.wpose * invB * 0.5f * (sRow[mb][t] + sCol[mb][t]);
+  __syncthreads();
+  if (t < NJ) {
+    float d[9];
+    if (t == 0) {
+      for (int k = 0; k < 9; ++k) d[k] = 0.f;
+    } else {
+      aa_bwd(R + t * 9, &sG[(t - 1) * 3], d);
+    }
+    for (int k = 0; k < 9; ++k) a.drot[((size_t)b * NJ + t) * 9 + k] = d[k];
+  }
+
+  // --- 2-D keypoint loss on joints 25..48
+  const float* c = a.cam + (size_t)b * a.ldc;
+  const float den = IMG_RES * c[0] + 1e-9f;
+  const float tz = 2.f * FOCAL / den;
+  for (int i = t; i < NJ49 * 3; i += 256) a.djoints[(size_t)b * NJ49 * 3 + i] = 0.f;
+  __syncthreads();
+  if (t < NJ) {
+    int j = 25 + t;
+    const float* p = a.joints + ((size_t)b * NJ49 + j) * 3;
+    const float* k = a.kp + ((size_t)b * NJ49 + j) * 3;
+    float x = p[0] + c[1], y = p[1] + c[2], z = p[2] + tz;
+    const float sc = FOCAL / (IMG_RES * 0.5f);
+    float ex = sc * (x / z) - k[0], ey = sc * (y / z) - k[1];
+    float conf = k[2];
+    float norm = invB / (float)(NJ * 2);
+    sL2d[t] = conf * (ex * ex + ey * ey) * norm;
+    float gx2 = a.w2d * 2.f * conf * ex * norm, gy2 = a.w2d * 2.f * conf * ey * norm;
+    float gx = gx2 * sc / z, gy = gy2 * sc / z;
+    float gz = -(gx * x + gy * y) / z;
+    float* dj = a.djoints + ((size_t)b * NJ49 + j) * 3;
+    dj[0] = gx; dj[1] = gy; dj[2] = gz;
+    sCamG[t][0] = gx; sCamG[t][1] = gy; sCamG[t][2] = gz;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float sx = 0.f, sy = 0.f, sz = 0.f, l2d = 0.f;
+    for (int j = 0; j < NJ; ++j) {
+      sx += sCamG[j][0]; sy += sCamG[j][1]; sz += sCamG[j][2];
+      l2d += sL2d[j];
+    }
+    float* dc = a.dcam + (size_t)b * a.lddc;
+    dc[0] = sz * (-2.f * FOCAL * IMG_RES / (den * den));
+    dc[1] = sx;
+    dc[2] = sy;
+    const float* be = a.shape + (size_t)b * a.lds;
+    float lsh = 0.f;
+    for (int l = 0; l < 10; ++l) {
+      lsh += be[l] * be[l];
+      a.dshape[(size_t)b * a.ldds + l] = a.wshape * 2.f * be[l] * invB;
+    }
+    lsh *= invB;
+    float lpo = sQ[mb] * invB;
+    float* o = a.parts + (size_t)b * 4;
+    o[0] = l2d; o[1] = lsh; o[2] = lpo;
+    o[3] = a.w2d * l2d + a.wshape * lsh + a.wpose * lpo;
+  }
+}
+
+// out[0..3] = sum_b parts[b][0..3]
+__global__ void loss_fold_kernel(const float* __restrict__ parts, float* __restrict__ out, int B) {
+  int t = threadIdx.x;
+  if (t < 4) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += parts[b * 4 + t];
+    out[t] = s;
+  }
+}
+
+// losses_out[4] = (s2dloss, shape_prior, pose_prior, weighted total) as the reference defines them
+// (means over the batch); gradients are those of the weighted total.
+extern "C" int dyb_frame_losses(const float* rotmat, const float* shape, int lds, const float* cam, int ldc,
+                                const float* joints49, const float* kp2d, const float* gmm_means,
+                                const float* gmm_prec, const float* gmm_logw, float w2d, float wshape, float wpose,
+                                float* losses_out, float* drot, float* dshape, int ldds, float* dcam, int lddc,
+                                float* djoints49, int B, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(rotmat && shape && cam && joints49 && kp2d && gmm_means && gmm_prec && gmm_logw, DYB_ERR_ARG);
+  DYB_REQUIRE(losses_out && drot && dshape && dcam && djoints49 && ws && B > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(ws_bytes >= (size_t)B * 4 * sizeof(float), DYB_ERR_WORKSPACE);
+  FrameLossArgs a;
+  a.rot = rotmat; a.shape = shape; a.cam = cam; a.joints = joints49; a.kp = kp2d;
+  a.means = gmm_means; a.prec = gmm_prec; a.logw = gmm_logw;
+  a.parts = reinterpret_cast<float*>(ws);
+  a.drot = drot; a.dshape = dshape; a.dcam = dcam; a.djoints = djoints49;
+  a.lds = lds; a.ldc = ldc; a.ldds = ldds; a.lddc = lddc; a.B = B;
+  a.w2d = w2d; a.wshape = wshape; a.wpose = wpose;
+  hipLaunchKernelGGL(frame_losses_kernel, dim3(B), dim3(256), 0, st, a);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)a.parts, losses_out, B);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

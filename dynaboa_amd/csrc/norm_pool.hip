@@ -1,0 +1,505 @@
+// GroupNorm(4 groups)+ReLU(+residual) forward/backward, 3x3/s2 max-pool, 7x7 average pool and the
+// NCHW->NHWC4 image repack, all NHWC fp32, 16 B per lane.
+//
+// Replaces nn.GroupNorm / nn.ReLU / nn.MaxPool2d / nn.AvgPool2d and the `out += residual` of
+// reference model/hmr.py:14-18,40-60,138-156.  HBM-bound elementwise / reduction work: every
+// kernel streams each tensor once, coalesced along channels.
+//
+// GroupNorm is split so that no kernel needs a grid-wide barrier:
+//   gn_stats : per (image, chunk-of-rows, group) partial sum / sum-of-squares (one wave per group);
+//              optionally folds the split-K slabs left by the convolution and writes y.
+//   gn_apply : every workgroup re-reduces the (<= few hundred) partials in double, then
+//              out = relu?((y-mean)*rstd*gamma + beta (+ residual)); saves mean/rstd.
+//   backward : gn_bwd_reduce (per-channel sums of dy and dy*xhat) -> gn_bwd_finalize (dgamma,
+//              dbeta, per-group coefficients) -> gn_bwd_apply (dx, and the residual-edge gradient).
+#include "dyb_common.h"
+
+#define G DYB_GN_GROUPS
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// grid (nchunks, N), block 256 = 4 waves, wave w <-> group w
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ src, float* __restrict__ y, int nslabs,
+                                                       size_t slab_stride, float* __restrict__ partials, int HW,
+                                                       int C, int rows_per_chunk) {
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cqg = C >> 4;                        // float4 columns per group
+  const int row0 = chunk * rows_per_chunk;
+  int row1 = row0 + rows_per_chunk;
+  if (row1 > HW) row1 = HW;
+  const int items = (row1 - row0) * cqg;
+  float s1 = 0.f, s2 = 0.f;
+  for (int idx = lane; idx < items; idx += 64) {
+    int row = row0 + idx / cqg;
+    int cq = wave * cqg + idx % cqg;
+    size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + off);
+    if (nslabs > 1) {
+      for (int z = 1; z < nslabs; ++z) {
+        float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * slab_stride + off);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      *reinterpret_cast<float4*>(y + off) = v;
+    }
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  s1 = dyb_wave_sum(s1);
+  s2 = dyb_wave_sum(s2);
+  if (lane == 0) {
+    float* p = partials + (((size_t)n * nchunks + chunk) * G + wave) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// grid (blocks_per_image, N), block 256
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ partials,
+                                                       int nchunks, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ out, float* __restrict__ stats, int HW, int C,
+                                                       int relu, float eps) {
+  __shared__ float s_mean[G], s_rstd[G];
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    double a = 0.0, b = 0.0;
+    for (int ch = lane; ch < nchunks; ch += 64) {
+      const float* p = partials + (((size_t)n * nchunks + ch) * G + wave) * 2;
+      a += (double)p[0];
+      b += (double)p[1];
+    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    if (lane == 0) {
+      double cnt = (double)HW * (double)(C / G);
+      double mean = a / cnt;
+      double var = b / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+      s_mean[wave] = m;
+      s_rstd[wave] = r;
+      if (blockIdx.x == 0) {
+        stats[((size_t)n * G + wave) * 2 + 0] = m;
+        stats[((size_t)n * G + wave) * 2 + 1] = r;
+      }
+    }
+  }
+  __syncthreads();
+  const int CQ = C >> 2, cqg = C >> 4;
+  const size_t total = (size_t)HW * CQ;
+  const size_t base = (size_t)n * HW * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cq = (int)(i % CQ);
+    int g = cq / cqg;
+    float mean = s_mean[g], rstd = s_rstd[g];
+    float4 v = *reinterpret_cast<const float4*>(y + base + i * 4);
+    float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+    float4 be = *reinterpret_cast<const float4*>(beta + cq * 4);
+    float4 o;
+    o.x = (v.x - mean) * rstd * ga.x + be.x;
+    o.y = (v.y - mean) * rstd * ga.y + be.y;
+    o.z = (v.z - mean) * rstd * ga.z + be.z;
+    o.w = (v.w - mean) * rstd * ga.w + be.w;
+    if (res) {
+      float4 r = *reinterpret_cast<const float4*>(res + base + i * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(out + base + i * 4) = o;
+  }
+}
+
+static int gn_chunks(int HW, int N) {
+  int want = 256 / (N > 0 ? N : 1);
+  if (want < 1) want = 1;
+  int nch = HW < want ? HW : want;
+  int rows = dyb_cdiv(HW, nch);
+  return dyb_cdiv(HW, rows);
+}
+
+extern "C" size_t dyb_groupnorm_workspace_bytes(int N, int HW, int C) {
+  // forward partials [N][nchunks][G][2]; backward partials [N][nchunks][2][C] + coef [N][G][2]
+  size_t nch = (size_t)gn_chunks(HW, N);
+  size_t fwd = (size_t)N * nch * G * 2;
+  size_t bwd = (size_t)N * nch * 2 * C + (size_t)N * G * 2;
+  return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+// y: conv output [N][HW][C] (written here when nslabs > 1 from `slabs`), out: normalised result,
+// stats: [N][G][2] (mean, rstd) saved for backward.
+extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const float* gamma, const float* beta,
+                                 const float* residual, float* out, float* stats, int N, int HW, int C, int relu,
+                                 void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(y && gamma && beta && out && stats && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(nslabs >= 1 && (nslabs == 1 || slabs), DYB_ERR_ARG);
+  int nch = gn_chunks(HW, N);
+  DYB_REQUIRE(ws_bytes >= (size_t)N * nch * G * 2 * sizeof(float), DYB_ERR_WORKSPACE);
+  int rows = dyb_cdiv(HW, nch);
+  float* partials = reinterpret_cast<float*>(ws);
+  const float* src = nslabs > 1 ? slabs : y;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, N), dim3(256), 0, st, src, y, nslabs, (size_t)N * HW * C, partials, HW,
+                     C, rows);
+  DYB_CHECK_LAUNCH();
+  size_t total4 = (size_t)HW * (C / 4);
+  int bpi = (int)((total4 + 1023) / 1024);
+  int cap = 1024 / N > 1 ? 1024 / N : 1;
+  if (bpi > cap) bpi = cap;
+  if (bpi < 1) bpi = 1;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, st, (const float*)y, (const float*)partials, nch,
+                     gamma, beta, residual, out, stats, HW, C, relu, DYB_GN_EPS);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+// grid (CQ/TX, nchunks, N), block 256 = TX x TY.  partial layout [n][chunk][2][C].
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                            const float* __restrict__ y, const float* __restrict__ stats,
+                                                            float* __restrict__ partials, int HW, int C,
+                                                            int rows_per_chunk, int relu, int TX) {
+  __shared__ float sm[256 * 8];
+  const int n = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cq = blockIdx.x * TX + tx;
+  const int g = (cq * 4) / (C / G);
+  const float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+  const int row0 = chunk * rows_per_chunk;
+  int row1 = row0 + rows_per_chunk;
+  if (row1 > HW) row1 = HW;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int row = row0 + ty; row < row1; row += TY) {
+    size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
+    float4 d = *reinterpret_cast<const float4*>(dout + off);
+    float4 v = *reinterpret_cast<const float4*>(y + off);
+    if (relu) {
+      float4 o = *reinterpret_cast<const float4*>(out + off);
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
+      d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+    a[0] += d.x; a[1] += d.y; a[2] += d.z; a[3] += d.w;
+    b[0] += d.x * ((v.x - mean) * rstd); b[1] += d.y * ((v.y - mean) * rstd);
+    b[2] += d.z * ((v.z - mean) * rstd); b[3] += d.w * ((v.w - mean) * rstd);
+  }
+  float* mine = sm + threadIdx.x * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mine[j] = a[j]; mine[4 + j] = b[j]; }
+  __syncthreads();
+  if (ty == 0) {
+    for (int t = 1; t < TY; ++t) {
+      const float* o = sm + (t * TX + tx) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] += o[j]; b[j] += o[4 + j]; }
+    }
+    float* p = partials + ((size_t)n * nchunks + chunk) * 2 * C + (size_t)cq * 4;
+    *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(p + C) = make_float4(b[0], b[1], b[2], b[3]);
+  }
+}
+
+// one workgroup.  dgamma[c] = sum_n B, dbeta[c] = sum_n A; coef[n][g] = (S1/m, S2/m)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nchunks,
+                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef, int N,
+                                                              int HW, int C) {
+  __shared__ float red[4 * 8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cg = C / G;
+  float gam[8], dg[8], db[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = tid + 256 * k;
+    gam[k] = c < C ? gamma[c] : 0.f;
+    dg[k] = 0.f;
+    db[k] = 0.f;
+  }
+  const float inv_m = 1.0f / ((float)cg * (float)HW);
+  for (int n = 0; n < N; ++n) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // s[g] = S1_g, s[4+g] = S2_g
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int c = tid + 256 * k;
+      if (c < C) {
+        float A = 0.f, B = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+          const float* p = partials + ((size_t)n * nchunks + ch) * 2 * C;
+          A += p[c];
+          B += p[C + c];
+        }
+        db[k] += A;
+        dg[k] += B;
+        int g = c / cg;
+        float ga = gam[k] * A, gb = gam[k] * B;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s[q] += (g == q) ? ga : 0.f;
+          s[4 + q] += (g == q) ? gb : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = dyb_wave_sum(s[q]);
+    __syncthreads();                       // red[] reuse across n
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) red[wave * 8 + q] = s[q];
+    }
+    __syncthreads();
+    if (tid < 8) {
+      float t = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+      int g = tid & 3, which = tid >> 2;
+      coef[((size_t)n * G + g) * 2 + which] = t * inv_m;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = tid + 256 * k;
+    if (c < C) {
+      dgamma[c] = dg[k];
+      dbeta[c] = db[k];
+    }
+  }
+}
+
+// grid-stride elementwise over [N][HW][C]
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                           const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ coef, const float* __restrict__ gamma,
+                                                           float* __restrict__ dy, float* __restrict__ dres, int N, int HW,
+                                                           int C, int relu) {
+  const int CQ = C >> 2, cqg = C >> 4;
+  const size_t per = (size_t)HW * CQ, total = (size_t)N * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int n = (int)(i / per);
+    int cq = (int)(i % CQ);
+    int g = cq / cqg;
+    float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+    float c1 = coef[((size_t)n * G + g) * 2], c2 = coef[((size_t)n * G + g) * 2 + 1];
+    float4 d = *reinterpret_cast<const float4*>(dout + i * 4);
+    float4 v = *reinterpret_cast<const float4*>(y + i * 4);
+    float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+    if (relu) {
+      float4 o = *reinterpret_cast<const float4*>(out + i * 4);
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
+      d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+    if (dres) *reinterpret_cast<float4*>(dres + i * 4) = d;
+    float4 r;
+    r.x = rstd * (ga.x * d.x - c1 - ((v.x - mean) * rstd) * c2);
+    r.y = rstd * (ga.y * d.y - c1 - ((v.y - mean) * rstd) * c2);
+    r.z = rstd * (ga.z * d.z - c1 - ((v.z - mean) * rstd) * c2);
+    r.w = rstd * (ga.w * d.w - c1 - ((v.w - mean) * rstd) * c2);
+    *reinterpret_cast<float4*>(dy + i * 4) = r;
+  }
+}
+
+// dout: gradient w.r.t. the kernel's forward output (after residual add / ReLU); out: that forward
+// output (ReLU mask); y/stats: saved conv output and (mean,rstd).  Writes dy (grad w.r.t. y),
+// dgamma, dbeta and, if dres != NULL, the gradient flowing into the residual operand.
+extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const float* y, const float* stats,
+                                 const float* gamma, float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW,
+                                 int C, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(dout && y && stats && gamma && dy && dgamma && dbeta && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  int nch = gn_chunks(HW, N);
+  size_t need = ((size_t)N * nch * 2 * C + (size_t)N * G * 2) * sizeof(float);
+  DYB_REQUIRE(ws_bytes >= need, DYB_ERR_WORKSPACE);
+  int rows = dyb_cdiv(HW, nch);
+  float* partials = reinterpret_cast<float*>(ws);
+  float* coef = partials + (size_t)N * nch * 2 * C;
+  int CQ = C / 4;
+  int TX = CQ < 256 ? CQ : 256;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(CQ / TX, nch, N), dim3(256), 0, st, dout, out, y, stats, partials, HW,
+                     C, rows, relu, TX);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nch, gamma, dgamma,
+                     dbeta, coef, N, HW, C);
+  DYB_CHECK_LAUNCH();
+  size_t total4 = (size_t)N * HW * CQ;
+  int blocks = (int)((total4 + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, stats, (const float*)coef, gamma,
+                     dy, dres, N, HW, C, relu);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pooling and layout
+// ------------------------------------------------------------------------------------------
+// image [N][3][H][W] -> [N][H][W][4] (4th channel 0)
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                             int HW) {
+  size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t n = i / HW, p = i % HW;
+    const float* b = x + n * 3 * HW + p;
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(b[0], b[HW], b[2 * (size_t)HW], 0.f);
+  }
+}
+extern "C" int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, hipStream_t st) {
+  DYB_REQUIRE(x && y && N > 0, DYB_ERR_ARG);
+  size_t total = (size_t)N * H * W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, x, y, N, H * W);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// 3x3 stride 2 pad 1.  idx holds, per channel, the winning tap (0..8) in one byte.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint32_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+  const int CQ = C >> 2;
+  size_t total = (size_t)N * Ho * Wo * CQ;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cq = (int)(i % CQ);
+    size_t t = i / CQ;
+    int wo = (int)(t % Wo);
+    t /= Wo;
+    int ho = (int)(t % Ho);
+    int n = (int)(t / Ho);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uint32_t bi[4] = {255u, 255u, 255u, 255u};
+    for (int r = 0; r < 3; ++r) {
+      int hi = ho * 2 - 1 + r;
+      if (hi < 0 || hi >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        int wi = wo * 2 - 1 + s;
+        if (wi < 0 || wi >= W) continue;
+        float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + hi) * W + wi) * C + (size_t)cq * 4);
+        uint32_t tap = r * 3 + s;
+        if (v.x > best.x || bi[0] == 255u) { best.x = v.x; bi[0] = tap; }
+        if (v.y > best.y || bi[1] == 255u) { best.y = v.y; bi[1] = tap; }
+        if (v.z > best.z || bi[2] == 255u) { best.z = v.z; bi[2] = tap; }
+        if (v.w > best.w || bi[3] == 255u) { best.w = v.w; bi[3] = tap; }
+      }
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = best;
+    idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+  }
+}
+// gather form: every input pixel looks at the (<= 4) windows that contain it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint32_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+  const int CQ = C >> 2;
+  size_t total = (size_t)N * H * W * CQ;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cq = (int)(i % CQ);
+    size_t t = i / CQ;
+    int w = (int)(t % W);
+    t /= W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+      if (ho >= Ho) continue;
+      int r = h - (2 * ho - 1);
+      for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+        if (wo >= Wo) continue;
+        int s = w - (2 * wo - 1);
+        uint32_t tap = (uint32_t)(r * 3 + s);
+        size_t o = (((size_t)n * Ho + ho) * Wo + wo) * CQ + cq;
+        uint32_t k = idx[o];
+        float4 d = *reinterpret_cast<const float4*>(dy + o * 4);
+        if ((k & 255u) == tap) acc.x += d.x;
+        if (((k >> 8) & 255u) == tap) acc.y += d.y;
+        if (((k >> 16) & 255u) == tap) acc.z += d.z;
+        if ((k >> 24) == tap) acc.w += d.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = acc;
+  }
+}
+extern "C" int dyb_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C,
+                                    hipStream_t st) {
+  DYB_REQUIRE(x && y && idx && C % 4 == 0, DYB_ERR_ARG);
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  size_t total = (size_t)N * Ho * Wo * (C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, y, idx, N, H, W, C, Ho, Wo);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W, int C,
+                                    hipStream_t st) {
+  DYB_REQUIRE(dy && dx && idx && C % 4 == 0, DYB_ERR_ARG);
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  size_t total = (size_t)N * H * W * (C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, idx, dx, N, H, W, C, Ho, Wo);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// global average over HW rows; result broadcast to `ndst` destinations (row stride ld floats):
+// the pooled 2048-vector is the head of each of the three regressor inputs xc (model/hmr.py:162).
+struct AvgDst {
+  float* p[4];
+};
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, AvgDst dst, int ndst, int ld, int N,
+                                                          int HW, int C) {
+  const int CQ = C >> 2;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * CQ) return;
+  int n = i / CQ, cq = i % CQ;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < HW; ++p) {
+    float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p) * C + (size_t)cq * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float inv = 1.0f / (float)HW;
+  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+  for (int d = 0; d < ndst; ++d) *reinterpret_cast<float4*>(dst.p[d] + (size_t)n * ld + (size_t)cq * 4) = s;
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dxf, int ld, float* __restrict__ dx,
+                                                          int N, int HW, int C) {
+  const int CQ = C >> 2;
+  size_t total = (size_t)N * HW * CQ;
+  float inv = 1.0f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cq = (int)(i % CQ);
+    int n = (int)(i / ((size_t)HW * CQ));
+    float4 g = *reinterpret_cast<const float4*>(dxf + (size_t)n * ld + (size_t)cq * 4);
+    g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+    *reinterpret_cast<float4*>(dx + i * 4) = g;
+  }
+}
+extern "C" int dyb_avgpool_fwd(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C,
+                               hipStream_t st) {
+  DYB_REQUIRE(x && dsts && ndst >= 1 && ndst <= 4 && C % 4 == 0 && ld % 4 == 0, DYB_ERR_ARG);
+  AvgDst d{};
+  for (int i = 0; i < ndst; ++i) d.p[i] = dsts[i];
+  int blocks = dyb_cdiv(N * (C / 4), 256);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, d, ndst, ld, N, HW, C);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_avgpool_bwd(const float* dxf, int ld, float* dx, int N, int HW, int C, hipStream_t st) {
+  DYB_REQUIRE(dxf && dx && C % 4 == 0 && ld % 4 == 0, DYB_ERR_ARG);
+  size_t total = (size_t)N * HW * (C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxf, ld, dx, N, HW, C);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

@@ -1,0 +1,129 @@
+// Flat-arena parameter updates: the MAML fast-weight step, Adam, the mean-teacher EMA, and the
+// feature cosine that gates the dynamic-BOA loop.  All 169 HMR tensors live in ONE contiguous
+// fp32 arena (27.0 M floats, 108 MB), so each of these is a single streaming launch instead of
+// 169 small ones.  Pure HBM-bound: 16 B per lane, grid-stride, 2048 workgroups.
+//
+//   fast weights : p' = p - lr * g                 learn2learn MAML.adapt (call
+//                                                  sites reference dynaboa_benchmark.py:136,140)
+//   Adam         : torch.optim.Adam single-tensor formula, no amsgrad / weight decay
+//                                                  (reference base_adaptor.py:126, dynaboa_benchmark.py:149-151)
+//   EMA          : t = alpha*t + (1-alpha)*p       reference base_adaptor.py:193-201
+//   cosine       : F.cosine_similarity(a.flatten(), b.flatten(), dim=0, eps)   base_adaptor.py:211-219
+#include "dyb_common.h"
+
+static int stream_blocks(size_t n4) {
+  size_t b = (n4 + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ __launch_bounds__(256) void fastweight_kernel(const float4* __restrict__ p, const float4* __restrict__ g,
+                                                         float4* __restrict__ out, float lr, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = p[i], b = g[i];
+    a.x -= lr * b.x; a.y -= lr * b.y; a.z -= lr * b.z; a.w -= lr * b.w;
+    out[i] = a;
+  }
+}
+extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, hipStream_t st) {
+  DYB_REQUIRE(p && g && out && n % 4 == 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(fastweight_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (const float4*)p, (const float4*)g,
+                     (float4*)out, lr, n / 4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float step_size,
+                                         float bc2_sqrt, float eps) {
+  // exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+  // denom = sqrt(v)/bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size)
+  m = m + (1.f - b1) * (g - m);
+  v = v * b2 + (1.f - b2) * g * g;
+  float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                   float4* __restrict__ v, float b1, float b2, float step_size,
+                                                   float bc2_sqrt, float eps, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2_sqrt, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+// step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t): computed by the caller in double.
+extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, float beta2, float step_size,
+                             float bc2_sqrt, float eps, size_t n, hipStream_t st) {
+  DYB_REQUIRE(p && g && m && v && n % 4 == 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
+                     (float4*)v, beta1, beta2, step_size, bc2_sqrt, eps, n / 4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const float4* __restrict__ p, float alpha, size_t n4) {
+  const float om = 1.f - alpha;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = t[i], b = p[i];
+    a.x = a.x * alpha + om * b.x; a.y = a.y * alpha + om * b.y;
+    a.z = a.z * alpha + om * b.z; a.w = a.w * alpha + om * b.w;
+    t[i] = a;
+  }
+}
+extern "C" int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, hipStream_t st) {
+  DYB_REQUIRE(teacher && p && n % 4 == 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(ema_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (float4*)teacher, (const float4*)p, alpha,
+                     n / 4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// y = a*x + b*y  (gradient accumulation across several forward passes that share theta)
+__global__ __launch_bounds__(256) void axpby_kernel(const float4* __restrict__ x, float4* __restrict__ y, float a, float b,
+                                                    size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 u = x[i], w = y[i];
+    w.x = a * u.x + b * w.x; w.y = a * u.y + b * w.y; w.z = a * u.z + b * w.z; w.w = a * u.w + b * w.w;
+    y[i] = w;
+  }
+}
+extern "C" int dyb_axpby(const float* x, float* y, float a, float b, size_t n, hipStream_t st) {
+  DYB_REQUIRE(x && y && n % 4 == 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(axpby_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (const float4*)x, (float4*)y, a, b, n / 4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// cosine over n floats with arbitrary row strides: element e lives at base + (e / cols) * ld + e % cols
+// (covers both contiguous features and the NHWC activations, whose flattening order does not
+// matter for a cosine).  One workgroup; n <= ~1 M in this model.  out[0] = cos.
+__global__ __launch_bounds__(1024) void cosine_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                      float eps, float* __restrict__ out) {
+  __shared__ float sm[16][3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float ab = 0.f, aa = 0.f, bb = 0.f;
+  for (size_t i = t; i < n; i += 1024) {
+    float x = a[i], y = b[i];
+    ab += x * y; aa += x * x; bb += y * y;
+  }
+  ab = dyb_wave_sum(ab); aa = dyb_wave_sum(aa); bb = dyb_wave_sum(bb);
+  if (lane == 0) { sm[wave][0] = ab; sm[wave][1] = aa; sm[wave][2] = bb; }
+  __syncthreads();
+  if (t == 0) {
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int w = 0; w < 16; ++w) { x += sm[w][0]; y += sm[w][1]; z += sm[w][2]; }
+    // torch: x.y / sqrt(clamp(|x|^2 * |y|^2, eps^2))
+    float den = sqrtf(fmaxf(y * z, eps * eps));
+    out[0] = x / den;
+  }
+}
+extern "C" int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* out, hipStream_t st) {
+  DYB_REQUIRE(a && b && out && n > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(cosine_kernel, dim3(1), dim3(1024), 0, st, a, b, n, eps, out);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

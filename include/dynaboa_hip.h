@@ -1,0 +1,141 @@
+/* libdynaboa_hip.so - C ABI of the MI355X (gfx950) kernels behind DynaBOA's per-frame adaptation
+ * hot path.
+ *
+ * The reference (syguan96/DynaBOA) has no FFI: its boundary for this path is the Python object
+ * surface (hmr()/HMR.forward, SMPL.forward, MAML.clone/adapt, torch.optim.Adam, BaseAdaptor.*;
+ * SURVEY.md 8b).  dynaboa_amd/ reproduces that surface in Python and calls down into the entry
+ * points below; each one names the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the library never
+ *     allocates, frees or retains caller memory; scratch is passed in (`ws`, size from the
+ *     matching *_workspace_bytes);
+ *   - everything is enqueued on `stream` in order; no call synchronises the host;
+ *   - return value: 0 = ok, -1 bad argument, -2 launch failure, -3 unsupported shape,
+ *     -4 workspace too small;
+ *   - one host thread per GPU process; re-entrant across different streams + workspaces.
+ *   - activations are NHWC, conv weights [R][S][Cin][Cout] (Cin padded to >= 4), linear weights
+ *     (out, in) row-major with the row stride padded to a multiple of 4 floats.
+ */
+#ifndef DYNABOA_HIP_H
+#define DYNABOA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dyb_stream_t; /* == hipStream_t */
+
+/* ---- convolution (implicit GEMM on fp32 MFMA) ------------------------------------------------
+ * replaces nn.Conv2d(bias=False) forward and its autograd in the ResNet-50 backbone:
+ * reference model/hmr.py:28-33,40-56 (Bottleneck), :70,110-114,138 (stem / downsample). */
+size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int dyb_conv2d_nhwc_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R, int S,
+                        int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N, int H, int W, int C,
+                          int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+
+/* ---- GroupNorm(4 groups, eps 1e-5) + optional residual add + optional ReLU --------------------
+ * replaces nn.GroupNorm(32//8, C) (reference model/hmr.py:14-18), nn.ReLU and `out += residual`
+ * (:43-58).  `slabs`/`nslabs` let the kernel fold split-K partial sums of the preceding conv.
+ * stats = [N][4][2] (mean, rstd) saved for backward. */
+size_t dyb_groupnorm_workspace_bytes(int N, int HW, int C);
+int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const float* gamma, const float* beta,
+                      const float* residual, float* out, float* stats, int N, int HW, int C, int relu, void* ws,
+                      size_t ws_bytes, dyb_stream_t stream);
+int dyb_groupnorm_bwd(const float* dout, const float* out, const float* y, const float* stats, const float* gamma,
+                      float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW, int C, int relu, void* ws,
+                      size_t ws_bytes, dyb_stream_t stream);
+
+/* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
+ * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
+int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);
+int dyb_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C, dyb_stream_t stream);
+int dyb_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W, int C,
+                         dyb_stream_t stream);
+int dyb_avgpool_fwd(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, dyb_stream_t stream);
+int dyb_avgpool_bwd(const float* dxf, int ld, float* dx, int N, int HW, int C, dyb_stream_t stream);
+
+/* ---- linear layers of the iterative regressor: nn.Linear fc1/fc2/decpose/decshape/deccam
+ * (reference model/hmr.py:82-90,161-172) and their autograd. */
+int dyb_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* res, int ldres,
+                   float* y, int ldy, int B, int I, int O, dyb_stream_t stream);
+size_t dyb_linear_bwd_workspace_bytes(int B, int I, int O);
+int dyb_linear_bwd_dx(const float* dy, int lddy, const float* w, int ldw, int B, int I, int O, float* dstA, int ldA,
+                      int accA, int split_col, float* dstB, int ldB, const float* addB, int ldaddB, void* ws,
+                      size_t ws_bytes, dyb_stream_t stream);
+int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, const float* const* xs, const int* ldxs, int T, int B,
+                      int I, int O, float* dw, int ldw, float* db, dyb_stream_t stream);
+
+/* ---- rotation maps: utils/geometry.py:47-61 (rot6d_to_rotmat) and :184-306
+ * (rotation_matrix_to_angle_axis), forward and backward. */
+int dyb_rot6d_fwd(const float* x6, int ldx, float* rotmat, int B, dyb_stream_t stream);
+int dyb_rot6d_bwd(const float* x6, int ldx, const float* drotmat, float* dx6, int lddx, int B, dyb_stream_t stream);
+int dyb_rotmat_to_aa_fwd(const float* R, float* aa, int n, dyb_stream_t stream);
+int dyb_rotmat_to_aa_bwd(const float* R, const float* daa, float* dR, int n, dyb_stream_t stream);
+
+/* ---- SMPL forward/backward: smplx lbs + vertex joints + J_regressor_extra + 49-joint gather
+ * (reference model/smpl.py:25-37).
+ * tables_f = {v_template[6890*3], shapedirs[6890*3][10], posedirs[207][6890*3], weights_t[24][6890],
+ *             j_template[24*3], j_shapedirs[72][10], j_extra[9][6890]}
+ * tables_i = {parents[24], vertex_joint_ids[21], joint_map[49]}        (device int32) */
+size_t dyb_lbs_saved_floats(int B);
+size_t dyb_lbs_bwd_workspace_bytes(int B);
+int dyb_lbs_fwd(const float* const* tables_f, const int* const* tables_i, const float* betas, int ldb,
+                const float* rotmat, float* verts, float* joints49, float* saved, int B, dyb_stream_t stream);
+int dyb_lbs_bwd(const float* const* tables_f, const int* const* tables_i, const float* rotmat, const float* saved,
+                const float* djoints49, const float* dverts, float* drot, float* dbetas, int lddb, int B, void* ws,
+                size_t ws_bytes, dyb_stream_t stream);
+/* J_regressor_h36m @ vertices of the metric path (reference dynaboa_benchmark.py:220-233) */
+int dyb_regress_joints(const float* reg, const float* verts, float* out, int nj, int B, dyb_stream_t stream);
+
+/* ---- losses: BaseAdaptor.projection (base_adaptor.py:160-170) and the frame-loss block of
+ * lower/upper_level_adaptation (:229-240 / :279-289 with cal_shape_prior :401, cal_pose_prior :405,
+ * MaxMixturePrior.merged_log_likelihood utils/smplify/prior.py:181-196).  dyb_frame_losses returns
+ * the three loss values + weighted total AND the gradient of the total in one launch. */
+int dyb_projection_fwd(const float* cam, int ldc, const float* p3, float* p2, int B, int np, dyb_stream_t stream);
+int dyb_projection_bwd(const float* cam, int ldc, const float* p3, const float* g2, float* dp3, float* dcam, int lddc,
+                       int B, int np, dyb_stream_t stream);
+int dyb_frame_losses(const float* rotmat, const float* shape, int lds, const float* cam, int ldc, const float* joints49,
+                     const float* kp2d, const float* gmm_means, const float* gmm_prec, const float* gmm_logw, float w2d,
+                     float wshape, float wpose, float* losses_out, float* drot, float* dshape, int ldds, float* dcam,
+                     int lddc, float* djoints49, int B, void* ws, size_t ws_bytes, dyb_stream_t stream);
+
+/* ---- flat-arena updates: learn2learn MAML.adapt (call sites dynaboa_benchmark.py:136,140),
+ * torch.optim.Adam (base_adaptor.py:126; dynaboa_benchmark.py:149-151), update_teacher
+ * (base_adaptor.py:193-201), cal_feature_diff's cosine (:211-219). n = float count, multiple of 4. */
+int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, dyb_stream_t stream);
+int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, float beta2, float step_size,
+                  float bc2_sqrt, float eps, size_t n, dyb_stream_t stream);
+int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, dyb_stream_t stream);
+int dyb_axpby(const float* x, float* y, float a, float b, size_t n, dyb_stream_t stream);
+int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* out, dyb_stream_t stream);
+
+/* ---- native HMR engine: HMR.forward (reference model/hmr.py:127-181) and its backward over a
+ * static plan.  Parameter / activation arena layouts are queried from the plan. */
+int dyb_hmr_plan_create(int B, int H, int W, void** plan);
+void dyb_hmr_plan_destroy(void* plan);
+size_t dyb_hmr_param_floats(const void* plan);
+size_t dyb_hmr_act_floats(const void* plan);
+size_t dyb_hmr_workspace_bytes(const void* plan);
+int dyb_hmr_num_tensors(const void* plan);
+/* kind: 0 conv weight, 1 norm weight, 2 norm bias, 3 fc weight, 4 fc bias, 5 fused decoder weight
+ * [160][1024] (decpose 0..143 | decshape 144..153 | deccam 154..156), 6 fused decoder bias */
+int dyb_hmr_tensor_info(const void* plan, int i, char* name, int name_cap, int* kind, long long* offset, int* dims4,
+                        int* cin_pad);
+int dyb_hmr_feature_info(const void* plan, int which, long long* offset, int* dims4, int* row_stride);
+long long dyb_hmr_act_offset_rotmat(const void* plan); /* [B][24][9] */
+long long dyb_hmr_act_offset_state(const void* plan);  /* [B][160] pose|shape|cam|pad */
+int dyb_hmr_forward(const void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
+                    float* acts, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_hmr_backward(const void* plan, const float* params, const float* acts, const float* d_rotmat,
+                     const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes, dyb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

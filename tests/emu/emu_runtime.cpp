@@ -1,0 +1,224 @@
+// TEST INFRASTRUCTURE ONLY - cooperative-fiber executor behind tests/emu/include/hip/hip_runtime.h.
+// One fiber per work-item; a workgroup's fibers run round-robin on the calling OS thread and
+// yield at __syncthreads() / cross-lane operations, which gives exactly the barrier semantics the
+// kernels rely on.  Workgroups of a grid run one after another.  x86-64 SysV only.
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+
+#include <cstdio>
+#include <vector>
+
+namespace emu {
+dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_ctx_switch
+.type emu_ctx_switch,@function
+emu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_ctx_switch, .-emu_ctx_switch
+)");
+
+enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+static const size_t kStack = 128 * 1024;
+static const int kMaxThreads = 1024;
+
+struct Fiber {
+  void* sp;
+  int state;
+  dim3 tid;
+  int lane, wave;
+  unsigned long long wait_gen;
+};
+struct Wave {
+  int alive, arrived;
+  unsigned long long gen;
+  unsigned char xbuf[2][64][16];
+  float a[2][64], b[2][64];
+};
+
+static char* g_stacks = nullptr;
+static Fiber g_f[kMaxThreads];
+static Wave g_w[kMaxThreads / 64];
+static void* g_sched_sp;
+static int g_cur, g_n, g_alive, g_arrived;
+static unsigned long long g_gen;
+static void (*g_call)(void*);
+static void* g_ctx;
+
+static void yield_to_sched() { emu_ctx_switch(&g_f[g_cur].sp, g_sched_sp); }
+
+static void release_block_if_complete() {
+  if (g_alive > 0 && g_arrived == g_alive) {
+    g_arrived = 0;
+    ++g_gen;
+  }
+}
+static void release_wave_if_complete(Wave& w) {
+  if (w.alive > 0 && w.arrived == w.alive) {
+    w.arrived = 0;
+    ++w.gen;
+  }
+}
+
+static void fiber_main() {
+  g_call(g_ctx);
+  Fiber& f = g_f[g_cur];
+  f.state = DONE;
+  --g_alive;
+  Wave& w = g_w[f.wave];
+  --w.alive;
+  release_block_if_complete();   // exited work-items do not take part in later barriers
+  release_wave_if_complete(w);
+  yield_to_sched();
+  fprintf(stderr, "emu: resumed a finished fiber\n");
+  abort();
+}
+
+void syncthreads() {
+  Fiber& f = g_f[g_cur];
+  ++g_arrived;
+  if (g_arrived == g_alive) {
+    g_arrived = 0;
+    ++g_gen;
+    return;
+  }
+  f.wait_gen = g_gen;
+  f.state = WAIT_BLOCK;
+  yield_to_sched();
+}
+
+static void wave_sync(Wave& w) {
+  Fiber& f = g_f[g_cur];
+  ++w.arrived;
+  if (w.arrived == w.alive) {
+    w.arrived = 0;
+    ++w.gen;
+    return;
+  }
+  f.wait_gen = w.gen;
+  f.state = WAIT_WAVE;
+  yield_to_sched();
+}
+
+int lane_id() { return g_f[g_cur].lane; }
+
+void wave_exchange(const void* mine, void* theirs, int src_lane, int bytes) {
+  Fiber& f = g_f[g_cur];
+  Wave& w = g_w[f.wave];
+  int par = (int)(w.gen & 1);
+  memcpy(w.xbuf[par][f.lane], mine, bytes);
+  wave_sync(w);
+  int nl = g_n - f.wave * 64;
+  if (nl > 64) nl = 64;
+  int src = (src_lane >= 0 && src_lane < nl && g_f[f.wave * 64 + src_lane].state != DONE) ? src_lane : f.lane;
+  memcpy(theirs, w.xbuf[par][src], bytes);
+}
+
+void mfma_32x32x2(float a, float b, float* c) {
+  Fiber& f = g_f[g_cur];
+  Wave& w = g_w[f.wave];
+  int par = (int)(w.gen & 1);
+  w.a[par][f.lane] = a;
+  w.b[par][f.lane] = b;
+  wave_sync(w);
+  // A[i][k] is held by lane i + 32k, B[k][j] by lane j + 32k; D[i][j] in lane j + 32*((i>>2)&1),
+  // register (i&3) + 4*(i>>3)  <=>  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+  int j = f.lane & 31, hi = f.lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    acc = fmaf(w.a[par][i], w.b[par][j], acc);
+    acc = fmaf(w.a[par][i + 32], w.b[par][j + 32], acc);
+    c[r] = acc;
+  }
+}
+
+static void init_fiber(int idx) {
+  char* top = g_stacks + (size_t)(idx + 1) * kStack;
+  void** sp = reinterpret_cast<void**>(top);
+  *--sp = nullptr;                                   // fake return address of fiber_main
+  *--sp = reinterpret_cast<void*>(&fiber_main);      // `ret` target of the first switch
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;       // rbp rbx r12 r13 r14 r15
+  g_f[idx].sp = sp;
+}
+
+void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
+  int n = (int)(block.x * block.y * block.z);
+  if (n <= 0 || n > kMaxThreads) {
+    fprintf(stderr, "emu: bad block size %d\n", n);
+    abort();
+  }
+  if (!g_stacks) {
+    g_stacks = static_cast<char*>(mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE,
+                                       MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+    if (g_stacks == MAP_FAILED) abort();
+  }
+  g_call = call;
+  g_ctx = ctx;
+  g_blockDim = block;
+  g_gridDim = grid;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_blockIdx = dim3(bx, by, bz);
+        g_n = g_alive = n;
+        g_arrived = 0;
+        g_gen = 0;
+        int nw = (n + 63) / 64;
+        for (int w = 0; w < nw; ++w) {
+          int cnt = n - w * 64;
+          g_w[w].alive = cnt > 64 ? 64 : cnt;
+          g_w[w].arrived = 0;
+          g_w[w].gen = 0;
+        }
+        for (int i = 0; i < n; ++i) {
+          init_fiber(i);
+          g_f[i].state = READY;
+          g_f[i].lane = i & 63;
+          g_f[i].wave = i >> 6;
+          g_f[i].tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+        }
+        int done = 0;
+        while (done < n) {
+          int progressed = 0;
+          for (int i = 0; i < n; ++i) {
+            Fiber& f = g_f[i];
+            if (f.state == DONE) continue;
+            if (f.state == WAIT_BLOCK) {
+              if (g_gen == f.wait_gen) continue;
+              f.state = READY;
+            } else if (f.state == WAIT_WAVE) {
+              if (g_w[f.wave].gen == f.wait_gen) continue;
+              f.state = READY;
+            }
+            g_cur = i;
+            g_threadIdx = f.tid;
+            emu_ctx_switch(&g_sched_sp, f.sp);
+            ++progressed;
+            if (f.state == DONE) ++done;
+          }
+          if (!progressed) {
+            fprintf(stderr, "emu: deadlock in block (%u,%u,%u): %d of %d work-items finished\n", bx, by, bz, done, n);
+            abort();
+          }
+        }
+      }
+}
+}  // namespace emu

@@ -1,0 +1,106 @@
+// TEST INFRASTRUCTURE ONLY - a host stand-in for <hip/hip_runtime.h>.
+//
+// The product sources under dynaboa_amd/csrc/*.hip are plain HIP for gfx950 and contain no
+// conditional compilation.  To check their indexing / synchronisation logic in the build
+// container (which has no GPU) the `-m "not gpu"` tests compile those same files with the host
+// clang++ and `-I tests/emu/include`, so that this header is found instead of the real one.
+// Every workgroup is executed by cooperative fibers (one per work-item, see emu_runtime.cpp):
+// __syncthreads(), wave-64 shuffles and the 32x32x2 fp32 MFMA are emulated with the hardware's
+// lane -> element maps.  The resulting library (tests/emu/_build/libdynaboa_emu.so) is loaded
+// only by tests; dynaboa_amd/_lib.py never looks for it.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 {
+  float x, y, z, w;
+};
+struct float2 {
+  float x, y;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  memset(d, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind,
+                                          hipStream_t) {
+  for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+  return hipSuccess;
+}
+
+namespace emu {
+extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+void syncthreads();
+void wave_exchange(const void* mine, void* theirs, int src_lane, int bytes);
+void mfma_32x32x2(float a, float b, float* c16);
+int lane_id();
+void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx);
+template <class F>
+void launch(dim3 grid, dim3 block, F body) {
+  run_grid(grid, block, [](void* p) { (*static_cast<F*>(p))(); }, &body);
+}
+}  // namespace emu
+
+#define threadIdx (emu::g_threadIdx)
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+#define __syncthreads() emu::syncthreads()
+
+template <class T>
+static inline T __shfl_xor(T v, int mask) {
+  T r;
+  emu::wave_exchange(&v, &r, emu::lane_id() ^ mask, (int)sizeof(T));
+  return r;
+}
+template <class T>
+static inline T __shfl(T v, int lane) {
+  T r;
+  emu::wave_exchange(&v, &r, lane, (int)sizeof(T));
+  return r;
+}
+template <class T>
+static inline T __shfl_down(T v, int d) {
+  T r;
+  int src = emu::lane_id() + d;
+  emu::wave_exchange(&v, &r, src > 63 ? emu::lane_id() : src, (int)sizeof(T));
+  return r;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z)                          \
+  ({                                                                                    \
+    float emu_c_[16];                                                                   \
+    for (int emu_i_ = 0; emu_i_ < 16; ++emu_i_) emu_c_[emu_i_] = (c)[emu_i_];           \
+    emu::mfma_32x32x2((a), (b), emu_c_);                                                \
+    __typeof__(c) emu_r_;                                                               \
+    for (int emu_i_ = 0; emu_i_ < 16; ++emu_i_) emu_r_[emu_i_] = emu_c_[emu_i_];        \
+    emu_r_;                                                                             \
+  })
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,367 @@
+"""Per-kernel parity cases: the C ABI (through a backend from tests/backends.py) against the CPU
+oracle / plain torch-CPU fp32 ops on the same seeded inputs.  Shapes are parameters so the same
+bodies serve the emulator (tiny) and the GPU box (the real ResNet-50 / SMPL sizes)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from dynaboa_amd._abi import check
+from oracle import ref_cpu as O
+
+TOL = 2e-4        # fp32 accumulation-order differences; north_star tolerance is 1e-3 relative
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+# ---------------------------------------------------------------------------------------- conv
+def case_conv(be, N, H, W, C, K, R, stride, pad, seed=0, c_real=None):
+    rng = _rng(seed)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    if c_real is not None:
+        x[..., c_real:] = 0
+    w = (rng.standard_normal((R, R, C, K)) / np.sqrt(R * R * C)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = rng.standard_normal((N, Ho, Wo, K)).astype(np.float32)
+    add = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wt = torch.from_numpy(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    yt = F.conv2d(xt, wt, stride=stride, padding=pad)
+    gx, gw = torch.autograd.grad(yt, [xt, wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+    y_ref = yt.detach().permute(0, 2, 3, 1).numpy()
+    dx_ref = gx.permute(0, 2, 3, 1).numpy() + add
+    dw_ref = gw.permute(2, 3, 1, 0).numpy()
+
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad)
+    ws = be.empty((max(wsb, 16) // 4,))
+    dx_, dw_, y_ = be.empty(x.shape), be.empty(w.shape), be.empty(dy.shape)
+    X, Wt, DY, ADD = be.dev(x), be.dev(w), be.dev(dy), be.dev(add)
+    check(be.lib.dyb_conv2d_nhwc_fwd(be.ptr(X), be.ptr(Wt), be.ptr(y_), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb,
+                                     be.stream), "conv fwd")
+    check(be.lib.dyb_conv2d_nhwc_dgrad(be.ptr(DY), be.ptr(Wt), be.ptr(dx_), be.ptr(ADD), N, H, W, C, K, R, R, stride, pad,
+                                       be.ptr(ws), wsb, be.stream), "conv dgrad")
+    check(be.lib.dyb_conv2d_nhwc_wgrad(be.ptr(X), be.ptr(DY), be.ptr(dw_), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb,
+                                       be.stream), "conv wgrad")
+    e = dict(fwd=rel_err(be.host(y_), y_ref), dgrad=rel_err(be.host(dx_), dx_ref), wgrad=rel_err(be.host(dw_), dw_ref))
+    assert max(e.values()) < TOL, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- groupnorm
+def case_groupnorm(be, N, HW, C, relu, with_res, nslabs, seed=1):
+    rng = _rng(seed)
+    y = (rng.standard_normal((N, HW, C)) * 1.5 + 0.3).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    res = rng.standard_normal((N, HW, C)).astype(np.float32) if with_res else None
+    dout = rng.standard_normal((N, HW, C)).astype(np.float32)
+    yt = torch.from_numpy(y).permute(0, 2, 1).reshape(N, C, HW, 1).contiguous().requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    o = F.group_norm(yt, 4, gt, bt, 1e-5)
+    rt = None
+    if with_res:
+        rt = torch.from_numpy(res).permute(0, 2, 1).reshape(N, C, HW, 1).contiguous().requires_grad_(True)
+        o = o + rt
+    if relu:
+        o = F.relu(o)
+    ins = [yt, gt, bt] + ([rt] if with_res else [])
+    grads = torch.autograd.grad(o, ins, torch.from_numpy(dout).permute(0, 2, 1).reshape(N, C, HW, 1))
+    out_ref = o.detach().reshape(N, C, HW).permute(0, 2, 1).numpy()
+    dy_ref = grads[0].reshape(N, C, HW).permute(0, 2, 1).numpy()
+
+    wsb = be.lib.dyb_groupnorm_workspace_bytes(N, HW, C)
+    ws = be.empty((wsb // 4,))
+    if nslabs > 1:           # split y into random slabs that sum to it
+        parts = rng.standard_normal((nslabs - 1, N, HW, C)).astype(np.float32)
+        slabs = np.concatenate([parts, (y - parts.sum(0))[None]], 0)
+        y = slabs.sum(0).astype(np.float32)      # exactly what the kernel will form (up to order)
+        S, Y = be.dev(slabs), be.empty((N, HW, C))
+    else:
+        S, Y = None, be.dev(y)
+    OUT, ST = be.empty((N, HW, C)), be.empty((N, 4, 2))
+    check(be.lib.dyb_groupnorm_fwd(be.ptr(S), nslabs, be.ptr(Y), be.ptr(be.dev(gamma)), be.ptr(be.dev(beta)),
+                                   be.ptr(be.dev(res)) if with_res else None, be.ptr(OUT), be.ptr(ST), N, HW, C, relu,
+                                   be.ptr(ws), wsb, be.stream), "gn fwd")
+    e = dict(out=rel_err(be.host(OUT), out_ref))
+    if nslabs > 1:
+        e["y"] = rel_err(be.host(Y), y)
+    DYB, DRES = be.empty((N, HW, C)), (be.empty((N, HW, C)) if with_res else None)
+    DG, DB = be.empty((C,)), be.empty((C,))
+    check(be.lib.dyb_groupnorm_bwd(be.ptr(be.dev(dout)), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(be.dev(gamma)),
+                                   be.ptr(DYB), be.ptr(DRES), be.ptr(DG), be.ptr(DB), N, HW, C, relu, be.ptr(ws), wsb,
+                                   be.stream), "gn bwd")
+    e["dy"] = rel_err(be.host(DYB), dy_ref)
+    e["dgamma"] = rel_err(be.host(DG), grads[1].numpy())
+    e["dbeta"] = rel_err(be.host(DB), grads[2].numpy())
+    if with_res:
+        e["dres"] = rel_err(be.host(DRES), grads[3].reshape(N, C, HW).permute(0, 2, 1).numpy())
+    assert max(e.values()) < 5e-4, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- pooling
+def case_pools(be, N, H, W, C, seed=2):
+    rng = _rng(seed)
+    x = np.maximum(rng.standard_normal((N, H, W, C)), 0).astype(np.float32)      # post-ReLU like the model
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yt = F.max_pool2d(xt, 3, 2, 1)
+    Ho, Wo = yt.shape[2], yt.shape[3]
+    dy = rng.standard_normal((N, Ho, Wo, C)).astype(np.float32)
+    (gx,) = torch.autograd.grad(yt, xt, torch.from_numpy(dy).permute(0, 3, 1, 2))
+    Y, IDX, DX = be.empty((N, Ho, Wo, C)), be.zeros((N, Ho, Wo, C // 4), np.int32), be.empty(x.shape)
+    check(be.lib.dyb_maxpool3x3s2_fwd(be.ptr(be.dev(x)), be.ptr(Y), be.ptr(IDX), N, H, W, C, be.stream), "maxpool fwd")
+    check(be.lib.dyb_maxpool3x3s2_bwd(be.ptr(be.dev(dy)), be.ptr(IDX), be.ptr(DX), N, H, W, C, be.stream), "maxpool bwd")
+    e = dict(max_fwd=rel_err(be.host(Y), yt.detach().permute(0, 2, 3, 1).numpy()))
+    # ties only occur between zeros, whose gradient the preceding ReLU kills: compare where x > 0
+    m = x > 0
+    e["max_bwd"] = rel_err(be.host(DX)[m], gx.permute(0, 2, 3, 1).numpy()[m])
+    # image repack
+    img = rng.standard_normal((N, 3, H, W)).astype(np.float32)
+    X4 = be.empty((N, H, W, 4))
+    check(be.lib.dyb_nchw3_to_nhwc4(be.ptr(be.dev(img)), be.ptr(X4), N, H, W, be.stream), "repack")
+    ref4 = np.concatenate([img.transpose(0, 2, 3, 1), np.zeros((N, H, W, 1), np.float32)], -1)
+    e["repack"] = float(np.abs(be.host(X4) - ref4).max())
+    assert max(e.values()) < 1e-6, e
+    return e
+
+
+def case_avgpool(be, N, HW, C, seed=3):
+    rng = _rng(seed)
+    x = rng.standard_normal((N, HW, C)).astype(np.float32)
+    ld = C + 160
+    d0, d1 = be.zeros((N, ld)), be.zeros((N, ld))
+    arr, p = be.ptr_array([d0, d1])
+    check(be.lib.dyb_avgpool_fwd(be.ptr(be.dev(x)), p, 2, ld, N, HW, C, be.stream), "avgpool fwd")
+    e = dict(fwd=rel_err(be.host(d0)[:, :C], x.mean(1)), fwd2=rel_err(be.host(d1)[:, :C], x.mean(1)))
+    g = rng.standard_normal((N, ld)).astype(np.float32)
+    DX = be.empty((N, HW, C))
+    check(be.lib.dyb_avgpool_bwd(be.ptr(be.dev(g)), ld, be.ptr(DX), N, HW, C, be.stream), "avgpool bwd")
+    e["bwd"] = rel_err(be.host(DX), np.broadcast_to(g[:, None, :C] / HW, (N, HW, C)))
+    assert max(e.values()) < 1e-5, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- linear
+def case_linear(be, B, I_real, O, seed=4):
+    rng = _rng(seed)
+    I = (I_real + 3) // 4 * 4
+    w = np.zeros((O, I), np.float32)
+    w[:, :I_real] = rng.standard_normal((O, I_real)) / np.sqrt(I_real)
+    bias = rng.standard_normal(O).astype(np.float32)
+    x = np.zeros((B, I), np.float32)
+    x[:, :I_real] = rng.standard_normal((B, I_real))
+    res = rng.standard_normal((B, O)).astype(np.float32)
+    Y = be.empty((B, O))
+    Wd = be.dev(w)
+    check(be.lib.dyb_linear_fwd(be.ptr(be.dev(x)), I, be.ptr(Wd), I, be.ptr(be.dev(bias)), be.ptr(be.dev(res)), O, be.ptr(Y), O,
+                                B, I, O, be.stream), "linear fwd")
+    e = dict(fwd=rel_err(be.host(Y), x @ w.T + bias + res))
+    dy = rng.standard_normal((B, O)).astype(np.float32)
+    wsb = be.lib.dyb_linear_bwd_workspace_bytes(B, I, O)
+    ws = be.empty((wsb // 4,))
+    split = I - 8 if I > 64 else I
+    A0 = rng.standard_normal((B, split)).astype(np.float32)
+    DA = be.dev(A0)
+    addB = rng.standard_normal((B, I - split)).astype(np.float32) if split < I else None
+    DB = be.empty((B, I - split)) if split < I else None
+    check(be.lib.dyb_linear_bwd_dx(be.ptr(be.dev(dy)), O, be.ptr(Wd), I, B, I, O, be.ptr(DA), split, 1, split, be.ptr(DB),
+                                   I - split, be.ptr(be.dev(addB)) if addB is not None else None, I - split, be.ptr(ws), wsb,
+                                   be.stream), "linear dx")
+    dx_ref = dy @ w
+    e["dx_acc"] = rel_err(be.host(DA), A0 + dx_ref[:, :split])
+    if split < I:
+        e["dx_tail"] = rel_err(be.host(DB), dx_ref[:, split:] + addB)
+    # rank-(T*B) outer product
+    T = 3
+    dys = [rng.standard_normal((B, O)).astype(np.float32) for _ in range(T)]
+    xs = [rng.standard_normal((B, I)).astype(np.float32) for _ in range(T)]
+    dyb, xb = [be.dev(a) for a in dys], [be.dev(a) for a in xs]
+    ka, pa = be.ptr_array(dyb)
+    kb, pb = be.ptr_array(xb)
+    ld1 = (ctypes.c_int * T)(*([O] * T))
+    ld2 = (ctypes.c_int * T)(*([I] * T))
+    DW, DBI = be.empty((O, I)), be.empty((O,))
+    check(be.lib.dyb_linear_bwd_dw(pa, ctypes.cast(ld1, ctypes.c_void_p), pb, ctypes.cast(ld2, ctypes.c_void_p), T, B, I, O,
+                                   be.ptr(DW), I, be.ptr(DBI), be.stream), "linear dw")
+    e["dw"] = rel_err(be.host(DW), sum(a.T @ b for a, b in zip(dys, xs)))
+    e["db"] = rel_err(be.host(DBI), sum(a.sum(0) for a in dys))
+    assert max(e.values()) < TOL, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- rotations
+def case_rot6d(be, golden):
+    g = golden("g1_geometry.npz")
+    x6 = g["x6"]
+    B = x6.shape[0]
+    R = be.empty((B * 24, 3, 3))
+    X = be.dev(x6)
+    check(be.lib.dyb_rot6d_fwd(be.ptr(X), 144, be.ptr(R), B, be.stream), "rot6d fwd")
+    e = dict(fwd=rel_err(be.host(R), g["rot6d_R"]))
+    DX = be.empty((B, 144))
+    check(be.lib.dyb_rot6d_bwd(be.ptr(X), 144, be.ptr(be.dev(g["rot6d_w"])), be.ptr(DX), 144, B, be.stream), "rot6d bwd")
+    e["bwd"] = rel_err(be.host(DX), g["rot6d_gx"])
+    assert max(e.values()) < 1e-5, e
+    return e
+
+
+def case_rotmat_to_aa(be, golden):
+    g = golden("g1_geometry.npz")
+    R = g["rodrigues_R"]
+    n = R.shape[0]
+    AA, DR = be.empty((n, 3)), be.empty((n, 3, 3))
+    Rd = be.dev(R)
+    check(be.lib.dyb_rotmat_to_aa_fwd(be.ptr(Rd), be.ptr(AA), n, be.stream), "r2aa fwd")
+    check(be.lib.dyb_rotmat_to_aa_bwd(be.ptr(Rd), be.ptr(be.dev(g["r2aa_w"])), be.ptr(DR), n, be.stream), "r2aa bwd")
+    aa = be.host(AA)
+    np.testing.assert_allclose(aa, g["r2aa_out"], rtol=1e-4, atol=2e-6)
+    ref = g["r2aa_gR"]
+    ok = np.isfinite(ref).all(axis=(1, 2))
+    ok[:2] = False                      # theta = 0 and theta ~ 1e-4: singular in the reference's own autograd
+    got = be.host(DR)
+    # rows near theta ~ pi amplify fp32 noise in both implementations: compare with a per-row scale
+    for i in np.nonzero(ok)[0]:
+        assert np.abs(got[i] - ref[i]).max() < 2e-3 * max(1.0, np.abs(ref[i]).max()), (i, got[i], ref[i])
+    return dict(fwd=float(np.abs(aa - g["r2aa_out"]).max()))
+
+
+# ---------------------------------------------------------------------------------------- SMPL
+def smpl_device_tables(be, tab):
+    from dynaboa_amd import constants as C
+    Jr = tab["J_regressor"].astype(np.float64)
+    f = [tab["v_template"], tab["shapedirs"].reshape(-1, 10), tab["posedirs"], np.ascontiguousarray(tab["lbs_weights"].T),
+         (Jr @ tab["v_template"].astype(np.float64)).astype(np.float32),
+         np.einsum("jv,vcl->jcl", Jr, tab["shapedirs"].astype(np.float64)).reshape(72, 10).astype(np.float32),
+         tab["J_regressor_extra"]]
+    i = [tab["parents"].astype(np.int32), np.array(C.VERTEX_JOINT_IDS, np.int32), np.array(C.JOINT_MAP_49, np.int32)]
+    fb = [be.dev(a) for a in f]
+    ib = [be.dev(a, np.int32) for a in i]
+    return fb, ib, be.ptr_array(fb), be.ptr_array(ib)
+
+
+def case_lbs(be, tab, B, seed=5, with_dverts=True):
+    rng = _rng(seed)
+    T = O.smpl_tables_to_torch(tab)
+    betas = torch.from_numpy((rng.standard_normal((B, 10)) * 0.5).astype(np.float32)).requires_grad_(True)
+    rot = O.smplx_rodrigues(torch.from_numpy((rng.standard_normal((B * 24, 3)) * 0.3).astype(np.float32))).view(B, 24, 3, 3)
+    rot = rot.detach().clone().requires_grad_(True)
+    verts, j49 = O.smpl_forward(T, betas, rot[:, 1:], rot[:, 0:1], pose2rot=False)
+    dj = torch.from_numpy(rng.standard_normal((B, 49, 3)).astype(np.float32))
+    dv = torch.from_numpy((rng.standard_normal((B, 6890, 3)) * 0.01).astype(np.float32))
+    loss = (j49 * dj).sum() + ((verts * dv).sum() if with_dverts else 0.0)
+    gb, gr = torch.autograd.grad(loss, [betas, rot])
+
+    fb, ib, (_ka, pf), (_kb, pi) = smpl_device_tables(be, tab)
+    V, J49 = be.empty((B, 6890, 3)), be.empty((B, 49, 3))
+    saved = be.empty((be.lib.dyb_lbs_saved_floats(B),))
+    BE, ROT = be.dev(betas.detach().numpy()), be.dev(rot.detach().numpy())
+    check(be.lib.dyb_lbs_fwd(pf, pi, be.ptr(BE), 10, be.ptr(ROT), be.ptr(V), be.ptr(J49), be.ptr(saved), B, be.stream), "lbs fwd")
+    e = dict(verts=rel_err(be.host(V), verts.detach().numpy()), joints=rel_err(be.host(J49), j49.detach().numpy()))
+    wsb = be.lib.dyb_lbs_bwd_workspace_bytes(B)
+    ws = be.empty((wsb // 4,))
+    DR, DBt = be.empty((B, 24, 3, 3)), be.empty((B, 10))
+    check(be.lib.dyb_lbs_bwd(pf, pi, be.ptr(ROT), be.ptr(saved), be.ptr(be.dev(dj.numpy())),
+                             be.ptr(be.dev(dv.numpy())) if with_dverts else None, be.ptr(DR), be.ptr(DBt), 10, B, be.ptr(ws),
+                             wsb, be.stream), "lbs bwd")
+    e["drot"] = rel_err(be.host(DR), gr.numpy())
+    e["dbetas"] = rel_err(be.host(DBt), gb.numpy())
+    assert max(e.values()) < TOL, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- losses
+def case_frame_losses(be, golden, gmm):
+    """Against golden g4 (the reference's own loss code on the oracle's SMPL joints)."""
+    g = golden("g4_losses.npz")
+    B = g["shape"].shape[0]
+    rot = O.smplx_rodrigues(torch.from_numpy(g["aa"])).view(B, 24, 3, 3).numpy()
+    joints = g["s3d"]
+    # reference gradients w.r.t. (rot, shape, cam) include the path through SMPL; the kernel returns
+    # the partial derivatives w.r.t. its own inputs, so compare against oracle autograd with joints
+    # treated as an input
+    rt = torch.from_numpy(rot).requires_grad_(True)
+    st = torch.from_numpy(g["shape"]).requires_grad_(True)
+    ct = torch.from_numpy(g["cam"]).requires_grad_(True)
+    jt = torch.from_numpy(joints).requires_grad_(True)
+    kp = torch.from_numpy(g["kp"])
+    gm = {k: torch.from_numpy(v) for k, v in gmm.items()}
+    l2d, lsh, lpo = O.kp2d_loss(O.projection(ct, jt), kp), O.shape_prior(st), O.pose_prior(rt, gm)
+    tot = 10.0 * l2d + 2e-6 * lsh + 1e-4 * lpo
+    gr, gs, gc, gj = torch.autograd.grad(tot, [rt, st, ct, jt])
+    L = be.empty((4,))
+    DR, DS, DC, DJ = be.empty((B, 24, 9)), be.empty((B, 10)), be.empty((B, 3)), be.empty((B, 49, 3))
+    ws = be.empty((B * 4,))
+    logw = np.log(gmm["nll_weights"]).astype(np.float32).reshape(-1)
+    check(be.lib.dyb_frame_losses(be.ptr(be.dev(rot)), be.ptr(be.dev(g["shape"])), 10, be.ptr(be.dev(g["cam"])), 3,
+                                  be.ptr(be.dev(joints)), be.ptr(be.dev(g["kp"])), be.ptr(be.dev(gmm["means"])),
+                                  be.ptr(be.dev(gmm["precisions"])), be.ptr(be.dev(logw)), 10.0, 2e-6, 1e-4, be.ptr(L),
+                                  be.ptr(DR), be.ptr(DS), 10, be.ptr(DC), 3, be.ptr(DJ), B, be.ptr(ws), B * 16, be.stream),
+          "frame losses")
+    Lh = be.host(L)
+    e = dict(l2d=abs(Lh[0] - g["l2d"]) / abs(g["l2d"]), lsh=abs(Lh[1] - g["lsh"]) / abs(g["lsh"]),
+             lpo=abs(Lh[2] - g["lpo"]) / abs(g["lpo"]), total=abs(Lh[3] - g["loss"]) / abs(g["loss"]),
+             drot=rel_err(be.host(DR).reshape(B, 24, 3, 3), gr.numpy()), dshape=rel_err(be.host(DS), gs.numpy()),
+             dcam=rel_err(be.host(DC), gc.numpy()), djoints=rel_err(be.host(DJ), gj.numpy()))
+    assert max(e.values()) < 5e-4, e
+    return e
+
+
+def case_projection(be, B=3, npnt=49, seed=6):
+    rng = _rng(seed)
+    cam = torch.tensor([[0.9, 0.02, -0.04]]).repeat(B, 1) + 0.05 * torch.from_numpy(rng.standard_normal((B, 3)).astype(np.float32))
+    cam = cam.clone().requires_grad_(True)
+    p3 = torch.from_numpy((rng.standard_normal((B, npnt, 3)) * 0.4).astype(np.float32)).requires_grad_(True)
+    p2 = O.projection(cam, p3)
+    g2 = torch.from_numpy(rng.standard_normal((B, npnt, 2)).astype(np.float32))
+    gc, gp = torch.autograd.grad(p2, [cam, p3], g2)
+    P2, DP, DC = be.empty((B, npnt, 2)), be.empty((B, npnt, 3)), be.empty((B, 3))
+    C_, P3 = be.dev(cam.detach().numpy()), be.dev(p3.detach().numpy())
+    check(be.lib.dyb_projection_fwd(be.ptr(C_), 3, be.ptr(P3), be.ptr(P2), B, npnt, be.stream), "proj fwd")
+    check(be.lib.dyb_projection_bwd(be.ptr(C_), 3, be.ptr(P3), be.ptr(be.dev(g2.numpy())), be.ptr(DP), be.ptr(DC), 3, B, npnt,
+                                    be.stream), "proj bwd")
+    e = dict(fwd=rel_err(be.host(P2), p2.detach().numpy()), dp=rel_err(be.host(DP), gp.numpy()), dcam=rel_err(be.host(DC), gc.numpy()))
+    assert max(e.values()) < 1e-4, e
+    return e
+
+
+# ---------------------------------------------------------------------------------------- optimiser family
+def case_optim(be, n=4096 * 3, seed=7):
+    rng = _rng(seed)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=3e-6, betas=(0.5, 0.9), foreach=False)
+    P, M, V = be.dev(p0), be.zeros((n,)), be.zeros((n,))
+    for t in range(1, 4):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 2)).astype(np.float32)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        check(be.lib.dyb_adam_step(be.ptr(P), be.ptr(be.dev(g)), be.ptr(M), be.ptr(V), 0.5, 0.9, 3e-6 / (1 - 0.5 ** t),
+                                   (1 - 0.9 ** t) ** 0.5, 1e-8, n, be.stream), "adam")
+    st = opt.state[pt]
+    e = dict(adam_delta=rel_err(be.host(P).astype(np.float64) - p0, pt.detach().numpy().astype(np.float64) - p0),
+             adam_m=rel_err(be.host(M), st["exp_avg"].numpy()), adam_v=rel_err(be.host(V), st["exp_avg_sq"].numpy()))
+    g = rng.standard_normal(n).astype(np.float32)
+    OUT = be.empty((n,))
+    check(be.lib.dyb_fastweight_update(be.ptr(be.dev(p0)), be.ptr(be.dev(g)), be.ptr(OUT), 8e-6, n, be.stream), "fastweight")
+    e["fast"] = rel_err(be.host(OUT).astype(np.float64) - p0, -8e-6 * g.astype(np.float64))
+    Tt = be.dev(p0)
+    check(be.lib.dyb_ema_update(be.ptr(Tt), be.ptr(be.dev(g)), 0.1, n, be.stream), "ema")
+    e["ema"] = rel_err(be.host(Tt), 0.1 * p0 + 0.9 * g)
+    Yb = be.dev(p0)
+    check(be.lib.dyb_axpby(be.ptr(be.dev(g)), be.ptr(Yb), 0.5, 2.0, n, be.stream), "axpby")
+    e["axpby"] = rel_err(be.host(Yb), 0.5 * g + 2.0 * p0)
+    a = rng.standard_normal(5000).astype(np.float32)
+    b = (a + 0.01 * rng.standard_normal(5000)).astype(np.float32)
+    Cs = be.empty((1,))
+    check(be.lib.dyb_cosine_sim(be.ptr(be.dev(a)), be.ptr(be.dev(b)), 5000, 1e-12, be.ptr(Cs), be.stream), "cosine")
+    ref = float(F.cosine_similarity(torch.from_numpy(a), torch.from_numpy(b), dim=0, eps=1e-12))
+    e["cos"] = abs(float(be.host(Cs)[0]) - ref)
+    assert e["adam_delta"] < 3e-2 and e["adam_m"] < 1e-5 and e["adam_v"] < 1e-5, e
+    assert e["fast"] < 1e-2 and e["ema"] < 1e-6 and e["axpby"] < 1e-6 and e["cos"] < 1e-6, e
+    return e

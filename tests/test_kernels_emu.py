@@ -1,0 +1,63 @@
+"""Kernel logic on CPU: the product .hip sources compiled for the host (tests/emu) and run
+work-item by work-item, compared with the oracle.  Small shapes; the real sizes are covered by
+tests/test_kernels_gpu.py on the MI355X."""
+import numpy as np
+import pytest
+
+import kernel_cases as K
+from conftest import golden
+
+
+@pytest.fixture(scope="module")
+def be():
+    from backends import EmuBackend
+    return EmuBackend()
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, K, R, stride, pad
+    (1, 8, 8, 64, 64, 1, 1, 0),        # 1x1, exact tiles
+    (1, 7, 7, 64, 128, 3, 1, 1),       # 3x3, M=49 ragged, split-K engaged
+    (2, 10, 10, 64, 64, 3, 2, 1),      # 3x3 stride 2, batch 2
+    (1, 8, 8, 128, 64, 1, 2, 0),       # 1x1 stride 2 (downsample)
+    (1, 20, 20, 4, 64, 7, 2, 3),       # stem: 7x7 s2, Cin padded 3->4, K=196 ragged
+])
+def test_conv(be, cfg):
+    N, H, W, C, Kc, R, st, pad = cfg
+    K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
+
+
+@pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True, 1), (2, 30, 128, 1, False, 3), (1, 12, 2048, 0, False, 1),
+                                 (1, 300, 64, 1, True, 2)])
+def test_groupnorm(be, cfg):
+    K.case_groupnorm(be, *cfg)
+
+
+def test_pools(be):
+    K.case_pools(be, 2, 12, 12, 64)
+    K.case_avgpool(be, 2, 49, 128)
+
+
+def test_linear(be):
+    K.case_linear(be, 1, 157 + 99, 40)      # ragged in_features -> padded stride
+    K.case_linear(be, 5, 512, 160)          # batch tile > 4
+
+
+def test_rotations(be):
+    K.case_rot6d(be, golden)
+    K.case_rotmat_to_aa(be, golden)
+    K.case_projection(be)
+
+
+def test_lbs(be, smpl_tabs):
+    K.case_lbs(be, smpl_tabs, B=2, with_dverts=True)
+    K.case_lbs(be, smpl_tabs, B=1, with_dverts=False)
+
+
+def test_frame_losses(be):
+    from dynaboa_amd import assets
+    K.case_frame_losses(be, golden, assets.load_gmm_prior())
+
+
+def test_optim(be):
+    K.case_optim(be, n=4096)

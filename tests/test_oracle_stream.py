@@ -1,0 +1,61 @@
+"""Oracle Adapter.adapt_frame vs the reference's own Adaptor.adaptation() (goldens g5_*):
+losses, predictions, and - because lr is 3e-6 and outputs barely move - the Adam moments and
+the (theta_after - theta_before) deltas (SURVEY 8c tolerance notes)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import cosine, golden, rel_err
+from oracle import ref_cpu as O
+from dynaboa_amd import assets
+
+FRAME_ONLY = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0,
+                  use_motion=0, dynamic_boa=0, use_temporal_losses_upper=0)
+STREAMS = {
+    "fo_inner3_frameonly": (dict(FRAME_ONLY, inner_step=3), False),
+    "fo_inner1_frameonly_identity": (dict(FRAME_ONLY, inner_step=1), True),
+    "fo_inner1_full": (dict(inner_step=1, interval=2, optim_steps=2), False),
+    "fo_inner1_full_forced": (dict(inner_step=1, interval=2, optim_steps=2, cos_sim_threshold=-1.0), False),
+}
+SLICE_PARAMS = ["conv1.weight", "layer1.0.conv2.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight",
+                "layer4.0.conv2.weight", "layer4.2.bn3.weight", "fc1.weight", "fc2.weight",
+                "decpose.weight", "decpose.bias", "deccam.bias"]
+
+
+def build(opts, identity_pose, gmm_t, smpl_tabs):
+    mp = assets.make_smpl_mean_params(identity_pose=identity_pose, seed=3)
+    sd = assets.make_synthetic_checkpoint(22, mp, randomize_norm=True, prefix="")["model"]
+    T = O.smpl_tables_to_torch(smpl_tabs)
+    ad = O.Adapter(sd, T, gmm_t, opts)
+    ad.exemplar_fn = lambda step: assets.make_exemplars(step, ad.o["sample_num"])
+    return ad, sd
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", list(STREAMS))
+def test_stream(tag, gmm_t, smpl_tabs):
+    g = golden(f"g5_{tag}.npz")
+    opts, ident = STREAMS[tag]
+    ad, sd0 = build(opts, ident, gmm_t, smpl_tabs)
+    n = int(g["nframes"])
+    torch.set_num_threads(8)
+    for step in range(n):
+        rec = ad.adapt_frame(assets.make_frame(step, 1, seed=22))
+        assert abs(ad.log["ul/s2dloss"] * 10 + ad.log["ul/shape_prior"] * 2e-6
+                   + ad.log["ul/pose_prior"] * 1e-4 - g["upper_loss"][step]) < 2e-5 * abs(g["upper_loss"][step])
+        assert rec["extra_steps"] == int(g["extra_steps"][step])
+        for k in ("rotmat", "shape", "cam", "joints"):
+            assert rel_err(rec["pred"][k], g[f"pred{step}_{k}"]) < 1e-4, (step, k)
+    assert ad.adam_t == int(g["adam_steps"])
+    names = [str(x) for x in g["names"]]
+    dn = np.array([float((ad.theta[k].detach().double() - sd0[k].double()).norm()) for k in names])
+    np.testing.assert_allclose(dn, g["delta_norms"], rtol=2e-3)
+    np.testing.assert_allclose([float(ad.m[k].double().norm()) for k in names], g["m_norms"], rtol=2e-3)
+    np.testing.assert_allclose([float(ad.v[k].double().norm()) for k in names], g["v_norms"], rtol=4e-3)
+    for k in SLICE_PARAMS:
+        d = (ad.theta[k].detach().double() - sd0[k].double()).flatten()[:256]
+        assert cosine(d, g["d_" + k]) > 0.9999, k
+        assert cosine(ad.m[k].flatten()[:256], g["m_" + k]) > 0.9999, k
+    if "teacher_delta_norms" in g.files and ad.o["use_meanteacher"]:
+        tn = np.array([float((ad.teacher[k].double() - sd0[k].double()).norm()) for k in names])
+        np.testing.assert_allclose(tn, g["teacher_delta_norms"], rtol=2e-3)

@@ -356,6 +356,15 @@ def g5(out):
     run_stream("fo_inner1_frameonly_identity", out, dict(frame_only, inner_step=1), 3, identity_pose=True)
     # the reference's full default term set (teacher + motion + labelled exemplars + dynamic loop)
     run_stream("fo_inner1_full", out, dict(inner_step=1, interval=2, optim_steps=2), 5)
+    g5_forced(out)
+
+
+def g5_forced(out):
+    # lr=3e-6 moves features[12] by <1e-7 in cosine, so the dynamic loop of
+    # dynaboa_benchmark.py:161-192 never fires above; a negative threshold forces the branch
+    # (2 extra upper steps per frame, then the optim_steps cut-off).
+    run_stream("fo_inner1_full_forced", out,
+               dict(inner_step=1, interval=2, optim_steps=2, cos_sim_threshold=-1.0), 4)
 
 
 # ---------------------------------------------------------------------------- G6 Procrustes
