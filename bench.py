@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: adapted frames / s on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the per-frame bilevel adaptation (BASELINE.json metric: 3 inner steps +
+1 outer step, batch 1, first-order, frame losses only = configs[1]) over one synthetic frame
+already resident in HBM.  The default schedule is the reference-faithful one of
+dynaboa_benchmark.py:126-157 (initial feature forward, inference() after every inner step and after
+the outer step: 9 forwards + 4 backwards + 13 SMPL forwards per frame); nothing is skipped.
+Each rank owns an independent replica + stream shard (weak scaling, no data-path collective;
+SURVEY 8e); rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_GFLOP = 8.195           # one HMR forward, B=1 (SURVEY 8 header)
+B_GFLOP = 16.15           # dgrad + wgrad
+MIN_SCHEDULE_GFLOP = 4 * (F_GFLOP + B_GFLOP) + F_GFLOP      # 105.6: algorithmic work per adapted frame
+PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md
+
+# the 53 convolutions as (count, H, W, Cin, Cout, k, stride, pad)
+RESNET_CONVS = [
+    (1, 224, 224, 4, 64, 7, 2, 3), (1, 56, 56, 64, 64, 1, 1, 0), (3, 56, 56, 64, 64, 3, 1, 1), (4, 56, 56, 64, 256, 1, 1, 0),
+    (2, 56, 56, 256, 64, 1, 1, 0), (1, 56, 56, 256, 128, 1, 1, 0), (1, 56, 56, 128, 128, 3, 2, 1), (4, 28, 28, 128, 512, 1, 1, 0),
+    (1, 56, 56, 256, 512, 1, 2, 0), (3, 28, 28, 512, 128, 1, 1, 0), (3, 28, 28, 128, 128, 3, 1, 1), (1, 28, 28, 512, 256, 1, 1, 0),
+    (1, 28, 28, 256, 256, 3, 2, 1), (6, 14, 14, 256, 1024, 1, 1, 0), (1, 28, 28, 512, 1024, 1, 2, 0), (5, 14, 14, 1024, 256, 1, 1, 0),
+    (5, 14, 14, 256, 256, 3, 1, 1), (1, 14, 14, 1024, 512, 1, 1, 0), (1, 14, 14, 512, 512, 3, 2, 1), (3, 7, 7, 512, 2048, 1, 1, 0),
+    (1, 14, 14, 1024, 2048, 1, 2, 0), (2, 7, 7, 2048, 512, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1)]
+
+
+def conv_roofline(device, batch, fwd_per_frame, bwd_per_frame, reps=5):
+    """Live HIP-event timing of the dominant kernel family (igemm_mfma_kernel<fwd|dgrad|wgrad>) on
+    torch's current stream, layer by layer at the bench batch size; algorithmic FLOPs = 2*M*N*K of
+    the real (unpadded) convolution.  Returns achieved TFLOP/s over one frame's worth of launches."""
+    from dynaboa_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream(device).cuda_stream
+    tot_flop = tot_ms = 0.0
+    nlaunch = 0
+    for cnt, H, W, C, K, R, s, p in RESNET_CONVS:
+        Ho = (H + 2 * p - R) // s + 1
+        creal = 3 if C == 4 else C
+        flop = 2.0 * batch * Ho * Ho * K * R * R * creal
+        x = torch.randn(batch, H, W, C, device=device)
+        w = torch.randn(R, R, C, K, device=device) * 0.05
+        dy = torch.randn(batch, Ho, Ho, K, device=device)
+        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+        wsb = int(lib.dyb_conv2d_workspace_bytes(batch, H, W, C, K, R, R, s, p))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
+
+        def run(mode):
+            if mode == 0:
+                return lib.dyb_conv2d_nhwc_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
+            if mode == 1:
+                return lib.dyb_conv2d_nhwc_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), None, batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
+            return lib.dyb_conv2d_nhwc_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
+        for mode, per_frame in ((0, fwd_per_frame), (1, bwd_per_frame), (2, bwd_per_frame)):
+            if mode == 1 and C == 4:
+                continue                                   # the image needs no data gradient
+            run(mode)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run(mode)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            tot_ms += ms * cnt * per_frame
+            tot_flop += flop * cnt * per_frame
+            nlaunch += cnt * per_frame
+    return dict(achieved=tot_flop / (tot_ms * 1e-3) / 1e12, conv_ms_per_frame=tot_ms, launches_per_frame=nlaunch,
+                avg_launch_us=tot_ms * 1e3 / nlaunch, gflop_per_frame=tot_flop / 1e9)
+
+
+def cpu_baseline(nframes=4, inner_step=3):
+    """The oracle (a torch-CPU restatement of the reference, validated against it in the build
+    container) on this host's cores, same synthetic stream and options, bounded sample."""
+    from oracle import ref_cpu as O
+    from dynaboa_amd import assets
+    torch.set_num_threads(os.cpu_count() or 8)
+    cores = torch.get_num_threads()
+    mp = assets.make_smpl_mean_params(identity_pose=True)
+    sd = assets.make_synthetic_checkpoint(22, mp, prefix="")["model"]
+    T = O.smpl_tables_to_torch(assets.make_synthetic_smpl(0))
+    gmm = {k: torch.from_numpy(v) for k, v in assets.load_gmm_prior().items()}
+    opts = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0, use_motion=0, dynamic_boa=0,
+                use_temporal_losses_upper=0, inner_step=inner_step)
+    ad = O.Adapter(sd, T, gmm, opts)
+    ad.adapt_frame(assets.make_frame(0, 1))
+    t0 = time.time()
+    for s in range(1, 1 + nframes):
+        ad.adapt_frame(assets.make_frame(s, 1))
+    dt = time.time() - t0
+    return dict(value=nframes / dt, unit="adapted frames/s", cores=cores, kind="port",
+                sample=f"{nframes} frames after 1 warm-up, inner_step={inner_step}, frame losses only, torch-CPU fp32 oracle "
+                       f"(6 fwd + 4 bwd per frame), {dt:.1f}s"), ad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--inner_step", type=int, default=3)
+    ap.add_argument("--schedule", choices=["faithful", "minimal"], default="faithful")
+    ap.add_argument("--full_losses", type=int, default=0, help="1: the reference's default term set (teacher+motion+exemplars+dynamic loop)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    from dynaboa_amd import assets, benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    if args.full_losses:
+        o = DB.parser.parse_args([])
+        o.inner_step = args.inner_step
+    else:
+        o = DB.frame_only_options(inner_step=args.inner_step)
+    o.batch_size = args.batch
+    o.deferred_metrics = 1
+    o.eval_lower = 1 if args.schedule == "faithful" else 0
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
+    total = args.warmup + args.steps
+    # this rank's shard of the synthetic stream, resident in HBM before the clock starts
+    frames = [{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + s, args.batch, seed=22).items()}
+              for s in range(total)]
+    ad.reset_records(total)
+
+    def run(lo, hi):
+        for s in range(lo, hi):
+            ad.global_step = s
+            ad.fit_losses = {}
+            ad.model.eval()
+            ad.adaptation(frames[s])
+
+    run(0, args.warmup)
+    ad.flush_metrics()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, total)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    metrics = ad.flush_metrics()                              # one D2H + batched SVD, outside the clock
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # end-of-stream gather of the per-frame errors over RCCL (the path's only collective)
+        from dynaboa_amd.sharding import gather_frame_metrics
+        pa = torch.tensor(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]) if metrics["pampjpe"] else np.zeros(0),
+                          device=device, dtype=torch.float32)
+        gathered = gather_frame_metrics(pa)
+    else:
+        gathered = None
+    frames_done = args.steps * args.batch * world
+    value = frames_done / dt
+
+    if rank == 0:
+        fwd_pf = (1 + 2 * args.inner_step + 2) if args.schedule == "faithful" else (args.inner_step + 3)
+        out = {"metric": "adapted frames/sec/GPU (3 inner + 1 outer step, bs=1) + PA-MPJPE on 3DPW",
+               "value": value, "unit": "adapted frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
+                                      "inner_step=%d + 1 outer, first-order (reference parity mode), %s; schedule=%s "
+                                      "(%d HMR forwards + %d backwards per frame)" %
+                                      (args.batch, args.inner_step, "reference default loss set" if args.full_losses else "frame losses only",
+                                       args.schedule, fwd_pf, args.inner_step + 1),
+                          "global_batch": args.batch * world, "parallelism": f"replicas{world} (stream sharded by sequence)",
+                          "per_gpu_frames_per_s": value / world,
+                          "pa_mpjpe_mm_synthetic_mean": float(np.mean(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]))) if metrics["pampjpe"] else None,
+                          "gathered_frames": int(gathered.numel()) if gathered is not None else None}}
+        if not args.no_roofline:
+            r = conv_roofline(device, args.batch, fwd_pf, args.inner_step + 1)
+            out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad> (+ split-K fold), per-frame launch mix",
+                               "avg_launch_us": r["avg_launch_us"], "launches_per_frame": r["launches_per_frame"],
+                               "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],
+                               "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3,
+                               "whole_frame_frac": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS}
+        if not args.no_cpu_baseline:
+            cb, _ = cpu_baseline(nframes=4, inner_step=args.inner_step)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,283 @@
+"""BaseAdaptor: model / optimiser / teacher set-up, loss assembly for the lower and upper level of
+the bilevel adaptation, mean-teacher EMA, frame history and exemplar retrieval.
+
+Mirrors the public surface of reference ``base_adaptor.py::BaseAdaptor`` (lines 36-447): same
+constructor argument (the argparse namespace), same method names and return conventions
+(``projection`` -> {'ori','normed'}, ``decode_smpl_params`` -> {'s3d','vts'},
+``lower/upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)`` -> (loss, features),
+``cal_*``), same attributes the drivers read.  What differs is underneath: the model is the native
+HIP engine, SMPL / losses / Adam / EMA are HIP kernels, and the frame history stays on the device
+instead of round-tripping through NumPy (reference :173-180).
+
+Data that the reference reads from fixed paths (checkpoint, SMPL pickles, regressors, retrieval
+clusters) can be injected through ``assets_bundle`` so the path runs on synthetic stand-ins
+(dynaboa_amd.assets) where the licensed files are absent.
+"""
+from __future__ import annotations
+
+import os
+import random
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import assets as A
+from . import constants
+from .hmr import hmr
+from .losses import MaxMixturePrior, frame_losses, pose_prior, projection_normed
+from .maml import MAML
+from .optim import Adam, ema_update
+from .smpl import SMPL
+
+
+def synthetic_bundle(seed: int = 22, identity_pose: bool = True, randomize_norm: bool = False, smpl_seed: int = 0):
+    """Everything BaseAdaptor needs, generated from seeds."""
+    mp = A.make_smpl_mean_params(identity_pose=identity_pose, seed=3)
+    return SimpleNamespace(
+        mean_params=mp,
+        checkpoint=A.make_synthetic_checkpoint(seed, mp, randomize_norm=randomize_norm),
+        smpl_neutral=A.make_synthetic_smpl(smpl_seed), smpl_male=A.make_synthetic_smpl(smpl_seed + 1),
+        smpl_female=A.make_synthetic_smpl(smpl_seed + 2),
+        exemplars=lambda step, n: A.make_exemplars(step, n), dataloader=None, gmm_folder=None)
+
+
+class BaseAdaptor:
+    def __init__(self, options, assets_bundle=None, device=None):
+        self.options = options
+        self.exppath = os.path.join(getattr(options, "expdir", "exps"), getattr(options, "expname", "run"))
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.bundle = assets_bundle
+        self.seed_everything(options.seed)
+        self.options.mixtrain = options.lower_level_mixtrain or options.upper_level_mixtrain
+        self.history: Dict[int, dict] = {}
+        self.fit_losses: Dict[str, torch.Tensor] = {}
+        self.kp2dlosses_lower, self.kp2dlosses_upper = [], {}
+        self.global_step = 0
+        if options.retrieval:
+            self.load_h36_cluster_res()
+        self.set_model_optim()
+        if options.use_meanteacher:
+            self.set_teacher()
+        self.set_dataloader()
+        self.set_criterion()
+        self.setup_smpl()
+
+    # ------------------------------------------------------------------ set-up
+    def seed_everything(self, seed):
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+
+    def _checkpoint(self):
+        if self.bundle is not None:
+            return self.bundle.checkpoint
+        return torch.load(self.options.model_file, map_location="cpu")
+
+    def _mean_params(self):
+        return self.bundle.mean_params if self.bundle is not None else "data/smpl_mean_params.npz"
+
+    def set_model_optim(self):
+        ck = self._checkpoint()["model"]
+        model = hmr(self._mean_params(), seed=0)
+        if self.options.use_boa:
+            self.model = MAML(model, lr=self.options.fastlr, first_order=True).to(self.device)
+            self.model.load_state_dict(ck, strict=True)
+        else:
+            self.model = model.to(self.device)
+            self.model.load_state_dict({k.replace("module.", ""): v for k, v in ck.items()}, strict=True)
+        self.optimizer = Adam(self.model.parameters(), lr=self.options.lr, betas=(self.options.beta1, self.options.beta2))
+
+    def set_teacher(self):
+        teacher = hmr(self._mean_params(), seed=0)
+        for p in teacher.parameters():
+            p.detach_()
+        self.teacher = teacher.to(self.device)
+        ck = self._checkpoint()["model"]
+        self.teacher.load_state_dict({k.replace("module.", ""): v for k, v in ck.items()}, strict=True)
+        # NB: the reference never calls teacher.eval() (base_adaptor.py:151-158), so its teacher runs
+        # with live Dropout; that RNG stream is not reproducible across devices - here the teacher is
+        # deterministic (eval).  Recorded in DESIGN.md.
+        self.teacher.eval()
+
+    def set_dataloader(self):
+        self.dataloader = self.bundle.dataloader if self.bundle is not None else None
+
+    def set_criterion(self):
+        folder = self.bundle.gmm_folder if self.bundle is not None else "data/spin_data"
+        self.gmm_f = MaxMixturePrior(prior_folder=folder, num_gaussians=8).to(self.device)
+
+    def setup_smpl(self):
+        if self.bundle is not None:
+            self.smpl_neutral = SMPL(tables=self.bundle.smpl_neutral).to(self.device)
+            self.smpl_male = SMPL(tables=self.bundle.smpl_male).to(self.device)
+            self.smpl_female = SMPL(tables=self.bundle.smpl_female).to(self.device)
+            self.J_regressor = torch.from_numpy(self.bundle.smpl_neutral["J_regressor_h36m"]).float()
+        else:
+            self.smpl_neutral = SMPL("data/smpl", create_transl=False).to(self.device)
+            self.smpl_male = SMPL("data/smpl", gender="male", create_transl=False).to(self.device)
+            self.smpl_female = SMPL("data/smpl", gender="female", create_transl=False).to(self.device)
+            self.J_regressor = torch.from_numpy(np.load("data/J_regressor_h36m.npy")).float()
+        self.joint_mapper_h36m = list(constants.H36M_TO_J14)
+        self.joint_mapper_gt = list(constants.J24_TO_J14)
+
+    # ------------------------------------------------------------------ retrieval (base_adaptor.py:74-96)
+    def load_h36_cluster_res(self):
+        self.centers = None
+        if self.bundle is None:
+            import joblib
+            res = joblib.load("data/retrieval_res/cluster_res_random_sample_center_10_10_potocol2.pt")
+            self.centers = torch.from_numpy(res["centers"]).float().to(self.device)
+            self.index = res["index"]
+
+    def retrieval(self, feature):
+        if self.bundle is not None:
+            batch = self.bundle.exemplars(self.global_step, self.options.sample_num)
+        else:
+            dists = 1 - F.cosine_similarity(feature, self.centers)
+            cluster = int(torch.argsort(dists)[0])
+            picks = random.sample(self.index[cluster], self.options.sample_num)
+            items = [self.h36m_dataset[i] for i in picks]
+            batch = {k: torch.cat([it[k] for it in items], 0) for k in items[0] if torch.is_tensor(items[0][k])}
+        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    # ------------------------------------------------------------------ geometry helpers
+    def projection(self, cam, s3d, eps=1e-9):
+        normed = projection_normed(cam, s3d)
+        return {"ori": normed * (constants.IMG_RES / 2.0), "normed": normed}
+
+    def decode_smpl_params(self, poses, beta, gender="neutral", pose2rot=False):
+        smpl = {"neutral": self.smpl_neutral, "male": self.smpl_male, "female": self.smpl_female}[gender]
+        out = smpl(betas=beta, body_pose=poses[:, 1:], global_orient=poses[:, 0].unsqueeze(1), pose2rot=pose2rot)
+        return {"s3d": out.joints, "vts": out.vertices}
+
+    # ------------------------------------------------------------------ history (device resident)
+    def save_hist(self, image, s2d):
+        self.history[self.global_step] = {"image": image.detach(), "s2d": s2d.detach()}
+        stale = self.global_step - self.options.interval - 1
+        self.history.pop(stale, None)            # the reference never prunes (602 KB/frame host growth)
+
+    def get_hist(self):
+        h = self.history[self.global_step - self.options.interval]
+        return h["image"], h["s2d"]
+
+    # ------------------------------------------------------------------ teacher
+    def update_teacher(self, teacher, model):
+        ema_update(teacher.parameters(), model.parameters(), self.options.alpha)
+
+    def cal_feature_diff(self, features_i, features_j):
+        sims, mean = {}, 0
+        for i, (a, b) in enumerate(zip(features_i, features_j)):
+            c = F.cosine_similarity(a.flatten(), b.flatten(), dim=0, eps=1e-12)
+            mean = mean + c
+            sims[i] = {"cos": c}
+        self.fit_losses["feat_sim/cos_sim"] = mean / i
+        return sims
+
+    # ------------------------------------------------------------------ losses
+    def cal_shape_prior(self, pred_betas):
+        return (pred_betas ** 2).sum(dim=-1).mean()
+
+    def cal_pose_prior(self, pred_rotmat, betas=None):
+        return pose_prior(pred_rotmat, self.gmm_f)
+
+    def cal_s3d_loss(self, pred_s3d, gt_s3d, conf):
+        gt = gt_s3d - ((gt_s3d[:, 2] + gt_s3d[:, 3]) / 2)[:, None, :]
+        pr = pred_s3d - ((pred_s3d[:, 2] + pred_s3d[:, 3]) / 2)[:, None, :]
+        return (conf * (pr - gt) ** 2).mean()
+
+    def cal_teacher_loss(self, image, pred_rotmat, pred_shape, pred_s2d, pred_s3d):
+        with torch.no_grad():
+            t_rot, t_shape, t_cam = self.teacher(image)
+            t_s3d = self.decode_smpl_params(t_rot, t_shape)["s3d"]
+            t_s2d = self.projection(t_cam, t_s3d)["normed"]
+        terms = dict(s2dloss=F.mse_loss(pred_s2d, t_s2d), s3dloss=F.mse_loss(t_s3d, pred_s3d),
+                     shape_loss=F.mse_loss(pred_shape, t_shape), pose_loss=F.mse_loss(pred_rotmat, t_rot))
+        loss = terms["s2dloss"] * 5 + terms["s3dloss"] * 5 + terms["shape_loss"] * 0.001 + terms["pose_loss"] * 1
+        for k, v in terms.items():
+            self.fit_losses[f"teacher/{k}"] = v
+        self.fit_losses["teacher/loss"] = loss
+        return loss
+
+    def cal_motion_loss(self, model, pred_s2d, gt_s2d, prefix="ul"):
+        hist_image, hist_s2d = self.get_hist()
+        h_rot, h_shape, h_cam = model(hist_image)
+        h_s3d = self.decode_smpl_params(h_rot, h_shape)["s3d"]
+        h_s2d = self.projection(h_cam, h_s3d)["normed"]
+        pred_motion = pred_s2d - h_s2d[:, 25:]
+        gt_motion = gt_s2d[:, :, :-1] - hist_s2d[:, 25:, :-1]
+        conf = ((hist_s2d[:, 25:, -1:] + gt_s2d[:, :, -1:]) == 2).float()
+        loss = (((pred_motion - gt_motion) ** 2) * conf).mean()
+        self.fit_losses[f"{prefix}/motion_loss"] = loss
+        return loss
+
+    def adapt_on_labeled_data(self, model, batch, prefix="ll"):
+        from .geometry import batch_rodrigues
+        gt_s2d = batch["keypoints"]
+        conf = gt_s2d[:, 25:, -1:].clone()
+        rot, shape, cam, feats = model(batch["img"], need_feature=True)
+        s3d = self.decode_smpl_params(rot, shape)["s3d"]
+        gt_rot = batch_rodrigues(batch["pose"].view(-1, 3)).view(-1, 24, 3, 3)
+        s2d = self.projection(cam, s3d)["normed"]
+        terms = dict(labled_s2dloss=(((s2d[:, 25:] - gt_s2d[:, 25:, :-1]) ** 2) * conf).mean(),
+                     labled_s3dloss=self.cal_s3d_loss(s3d[:, 25:], batch["pose_3d"][:, :, :-1], conf),
+                     labled_shape_loss=F.mse_loss(shape, batch["betas"]), labled_pose_loss=F.mse_loss(rot, gt_rot))
+        assert batch["pose_3d"].shape[1] == 24
+        loss = (terms["labled_s2dloss"] * 5 + terms["labled_s3dloss"] * 5 + terms["labled_shape_loss"] * 0.001
+                + terms["labled_pose_loss"] * 1)
+        for k, v in terms.items():
+            self.fit_losses[f"{prefix}/{k}"] = v
+        self.fit_losses[f"{prefix}/labled_loss"] = loss
+        return loss, feats
+
+    def _level(self, level, image, gt_keypoints_2d, h36m_batch, learner):
+        o = self.options
+        tag = "ll" if level == "lower" else "ul"
+        rot, shape, cam, feats = learner(image, need_feature=True)
+        smpl_out = self.decode_smpl_params(rot, shape)
+        s3d = smpl_out["s3d"]
+        loss = None
+        s2d = None
+        if getattr(o, f"use_frame_losses_{level}"):
+            loss, comps = frame_losses(rot, shape, cam, s3d, gt_keypoints_2d, self.gmm_f, o.s2dloss_weight,
+                                       o.shape_prior_weight, o.pose_prior_weight)
+            if level == "lower":
+                self.kp2dlosses_lower.append(comps[0])
+            else:
+                self.kp2dlosses_upper[self.global_step] = comps[0]
+            self.fit_losses[f"{tag}/s2dloss"], self.fit_losses[f"{tag}/shape_prior"] = comps[0], comps[1]
+            self.fit_losses[f"{tag}/pose_prior"], self.fit_losses[f"{tag}/unlabelloss"] = comps[2], loss.detach()
+        if getattr(o, f"use_temporal_losses_{level}"):
+            s2d = self.projection(cam, s3d)["normed"]
+            if o.use_meanteacher:
+                t = self.cal_teacher_loss(image, rot, shape, s2d, s3d) * o.teacherloss_weight
+                loss = t if loss is None else loss + t
+            if o.use_motion and (self.global_step - o.interval) > 0:
+                loss = loss + self.cal_motion_loss(learner, s2d[:, 25:], gt_keypoints_2d[:, 25:], prefix="ul") * o.motionloss_weight
+        if o.retrieval:
+            h36m_batch = self.retrieval(feats[5])
+        if getattr(o, f"{level}_level_mixtrain"):
+            lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag)
+            loss = loss + lab * o.labelloss_weight
+        return loss, feats
+
+    def lower_level_adaptation(self, image, gt_keypoints_2d, h36m_batch, learner=None):
+        return self._level("lower", image, gt_keypoints_2d, h36m_batch, learner)
+
+    def upper_level_adaptation(self, image, gt_keypoints_2d, h36m_batch, learner=None):
+        return self._level("upper", image, gt_keypoints_2d, h36m_batch, learner)
+
+    # ------------------------------------------------------------------ stubs the drivers override
+    def excute(self):
+        pass
+
+    def adaptation(self, batch):
+        pass
+
+    def inference(self, batch, model, need_feature=False):
+        pass
+
+    def write_summaries(self, losses):
+        self.last_summaries = losses

@@ -1,0 +1,238 @@
+"""Drop-in for reference ``dynaboa_benchmark.py``: the same argparse flags (:16-65) and an
+``Adaptor`` with ``excute() / adaptation(batch) / inference(batch, model)`` running the same
+per-frame bilevel schedule (:126-193) and metric path (:204-262) on the HIP kernels.
+
+Differences that do not change results:
+  * per-inference ``joblib.dump`` of 6890x3 vertices (:250-254) is off unless --dump_predictions 1;
+  * with --deferred_metrics 1 the 14-joint sets are kept on the device and PA-MPJPE's per-sample
+    SVD runs once per stream instead of forcing a host sync four times per frame.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._abi import check
+from .base_adaptor import BaseAdaptor
+from .hmr import stream_of
+from .pose_utils import compute_similarity_transform_batch
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--expdir', type=str, default='exps')
+parser.add_argument('--expname', type=str, default='3dpw')
+parser.add_argument('--dataset', type=str, default='3dpw', choices=['3dpw', 'internet'])
+parser.add_argument('--seed', type=int, default=22)
+parser.add_argument('--seq_seed', type=int, default=22)
+parser.add_argument('--model_file', type=str, default='data/basemodel.pt')
+parser.add_argument('--batch_size', type=int, default=1)
+parser.add_argument('--save_res', type=int, default=0, choices=[0, 1])
+parser.add_argument('--lr', type=float, default=3e-6)
+parser.add_argument('--beta1', type=float, default=0.5)
+parser.add_argument('--beta2', type=float, default=0.9)
+parser.add_argument('--use_boa', type=int, default=1, choices=[0, 1])
+parser.add_argument('--fastlr', type=float, default=8e-6)
+parser.add_argument('--inner_step', type=int, default=1)
+parser.add_argument('--record_lowerlevel', type=int, default=1)
+parser.add_argument('--s2dloss_weight', type=float, default=10)
+parser.add_argument('--shape_prior_weight', type=float, default=2e-6)
+parser.add_argument('--pose_prior_weight', type=float, default=1e-4)
+parser.add_argument('--use_frame_losses_lower', type=int, default=1, choices=[0, 1])
+parser.add_argument('--use_frame_losses_upper', type=int, default=1, choices=[0, 1])
+parser.add_argument('--use_temporal_losses_lower', type=int, default=0, choices=[0, 1])
+parser.add_argument('--use_temporal_losses_upper', type=int, default=1, choices=[0, 1])
+parser.add_argument('--sample_num', type=int, default=1)
+parser.add_argument('--retrieval', type=int, default=1, choices=[0, 1])
+parser.add_argument('--dynamic_boa', type=int, default=1, choices=[0, 1])
+parser.add_argument('--cos_sim_threshold', type=float, default=3.1e-4)
+parser.add_argument('--optim_steps', type=int, default=7)
+parser.add_argument('--lower_level_mixtrain', type=int, default=1, choices=[0, 1])
+parser.add_argument('--upper_level_mixtrain', type=int, default=1, choices=[0, 1])
+parser.add_argument('--mixtrain', type=int)
+parser.add_argument('--labelloss_weight', type=float, default=0.1)
+parser.add_argument('--use_meanteacher', type=int, default=1, choices=[0, 1])
+parser.add_argument('--alpha', type=float, default=0.1)
+parser.add_argument('--teacherloss_weight', type=float, default=0.1)
+parser.add_argument('--use_motion', type=int, default=1, choices=[0, 1])
+parser.add_argument('--interval', type=int, default=5)
+parser.add_argument('--motionloss_weight', type=float, default=0.8)
+# additions (not in the reference)
+parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
+parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
+parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
+                    help='run inference() after every inner step like the reference (:142)')
+
+
+def frame_only_options(**over):
+    """The 'frame losses only' configuration of SURVEY 8d config 2."""
+    o = parser.parse_args([])
+    for k, v in dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0, use_motion=0,
+                     dynamic_boa=0, use_temporal_losses_upper=0).items():
+        setattr(o, k, v)
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+class Adaptor(BaseAdaptor):
+    def reset_records(self, nframes: int):
+        self.sims, self.feat_sims, self.optim_step_record = [], {}, []
+        self.mpjpe_statistics, self.pampjpe_statistics = [[] for _ in range(nframes)], [[] for _ in range(nframes)]
+        self.mpjpe_all_lower = [[] for _ in range(self.options.inner_step)]
+        self.pampjpe_all_lower = [[] for _ in range(self.options.inner_step)]
+        self.history, self.kp2dlosses_lower, self.kp2dlosses_upper = {}, [], {}
+        self._pending = []            # deferred metric records
+
+    def excute(self, frames: Optional[Iterable[Dict[str, torch.Tensor]]] = None, nframes: Optional[int] = None):
+        frames = self.dataloader if frames is None else frames
+        nframes = len(frames) if nframes is None else nframes
+        self.reset_records(nframes)
+        mpjpe_all, pampjpe_all, pve_all = [], [], []
+        for step, batch in enumerate(frames):
+            self.global_step = step
+            self.fit_losses = {}
+            batch = {k: v.to(self.device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+            self.model.eval()
+            mpjpe, pampjpe, pve = self.adaptation(batch)
+            self.write_summaries(self.fit_losses)
+            mpjpe_all.append(mpjpe); pampjpe_all.append(pampjpe); pve_all.append(pve)
+        if self.options.deferred_metrics:
+            final = self.flush_metrics()
+            mpjpe_all, pampjpe_all, pve_all = final["mpjpe"], final["pampjpe"], final["pve"]
+        self.results = dict(mpjpe=mpjpe_all, pampjpe=pampjpe_all, pve=pve_all)
+        return self.results
+
+    # ------------------------------------------------------------------ the per-frame bilevel step
+    def adaptation(self, batch):
+        o = self.options
+        image, gt_keypoints_2d = batch['image'], batch['smpl_j2d']
+        self.save_hist(image, gt_keypoints_2d)
+        if not o.use_boa:
+            loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, None, self.model)
+            self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
+            return self.inference(batch, self.model)
+        with torch.no_grad():
+            init_features = self.model(image, need_feature=True)[3]
+        h36m_batch = None
+        learner = self.model.clone()
+        for i in range(o.inner_step):
+            lower_loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
+            learner.adapt(lower_loss)
+            if o.eval_lower:
+                m, p, _ = self.inference(batch, learner, tag=('lower', i))
+                self.mpjpe_all_lower[i].append(m); self.pampjpe_all_lower[i].append(p)
+        upper_loss, _ = self.upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
+        self.optimizer.zero_grad()
+        upper_loss.backward()
+        self.optimizer.step()
+        if o.use_meanteacher:
+            self.update_teacher(self.teacher, self.model)
+        mpjpe, pampjpe, pve = self.inference(batch, self.model, tag=('final', 0))
+        if self.global_step < len(self.mpjpe_statistics):
+            self.mpjpe_statistics[self.global_step] = [mpjpe]
+            self.pampjpe_statistics[self.global_step] = [pampjpe]
+        if o.dynamic_boa:
+            with torch.no_grad():
+                adapted = self.model(image, need_feature=True)[3]
+                sims = self.cal_feature_diff(init_features, adapted)
+                feat_12 = float(sims[12]['cos'])
+                self.feat_sims[self.global_step] = [sims]
+            self.optimized_step = 0
+            while 1 - feat_12 > o.cos_sim_threshold:
+                self.optimized_step += 1
+                if self.optimized_step > o.optim_steps:
+                    break
+                upper_loss, adapted = self.upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, self.model)
+                self.optimizer.zero_grad()
+                upper_loss.backward()
+                self.optimizer.step()
+                if o.use_meanteacher:
+                    self.update_teacher(self.teacher, self.model)
+                with torch.no_grad():
+                    init_features = [f.detach().clone() for f in adapted]
+                    adapted = self.model(image, need_feature=True)[3]
+                    sims = self.cal_feature_diff(init_features, adapted)
+                    feat_12 = float(sims[12]['cos'])
+                    self.feat_sims[self.global_step].append(sims)
+                mpjpe, pampjpe, pve = self.inference(batch, self.model, tag=('final', self.optimized_step))
+            self.optim_step_record.append(self.optimized_step)
+        return mpjpe, pampjpe, pve
+
+    # ------------------------------------------------------------------ metrics
+    def _regress14(self, verts):
+        lib = _lib.load()
+        B = verts.shape[0]
+        if not hasattr(self, "_Jh36m_dev"):
+            self._Jh36m_dev = self.J_regressor.to(self.device).contiguous()
+        out = torch.empty(B, 17, 3, device=self.device)
+        v = verts.contiguous()
+        check(lib.dyb_regress_joints(self._Jh36m_dev.data_ptr(), v.data_ptr(), out.data_ptr(), 17, B, stream_of(v)),
+              "dyb_regress_joints")
+        return out[:, self.joint_mapper_h36m, :] - out[:, [0], :]
+
+    def inference(self, batch, model, need_feature=False, tag=None):
+        image, gt_pose, gt_betas, gender = batch['image'], batch['pose'], batch['betas'], batch['gender']
+        model.eval()
+        with torch.no_grad():
+            out = model(image, need_feature)
+            pred_rotmat, pred_shape, pred_cam = out[0], out[1], out[2]
+            smpl_out = self.decode_smpl_params(pred_rotmat, pred_shape)
+            pred_vertices = smpl_out['vts']
+            gt_vertices = self.smpl_male(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
+            gt_female = self.smpl_female(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
+            gt_vertices = torch.where((gender == 1).view(-1, 1, 1), gt_female, gt_vertices)
+            gt14 = self._regress14(gt_vertices)
+            pred14 = self._regress14(pred_vertices)
+            mpjpe_t = (pred14 - gt14).norm(dim=-1).mean(dim=-1)
+            gt_neutral = self.smpl_neutral(betas=gt_betas, body_pose=gt_pose[:, 3:], global_orient=gt_pose[:, :3],
+                                           pose2rot=True).vertices
+            pve_t = (gt_neutral - pred_vertices).norm(dim=-1).mean()
+        if self.options.dump_predictions:
+            import joblib
+            os.makedirs(os.path.join(self.exppath, 'result'), exist_ok=True)
+            cam_t = torch.stack([pred_cam[:, 1], pred_cam[:, 2], 2 * 5000. / (224 * pred_cam[:, 0] + 1e-9)], dim=-1)
+            joblib.dump({'verts': pred_vertices.cpu().numpy(), 'cam': cam_t.cpu().numpy(),
+                         'rotmat': pred_rotmat.cpu().numpy(), 'beta': pred_shape.cpu().numpy()},
+                        os.path.join(self.exppath, 'result', f'Pred_{self.global_step}.pt'))
+        if self.options.deferred_metrics:
+            self._pending.append(dict(step=self.global_step, tag=tag, pred=pred14, gt=gt14, mpjpe=mpjpe_t, pve=pve_t))
+            res = (mpjpe_t, None, pve_t)
+        else:
+            S1, S2 = pred14.cpu().numpy(), gt14.cpu().numpy()
+            pa = np.sqrt(((compute_similarity_transform_batch(S1, S2) - S2) ** 2).sum(-1)).mean(-1)
+            res = (mpjpe_t.cpu().numpy() * 1000, pa * 1000, float(pve_t) * 1000)
+        return res + (out[3],) if need_feature else res
+
+    def flush_metrics(self):
+        """Resolve deferred records with one device->host transfer (and one batched SVD)."""
+        rec = self._pending
+        self._pending = []
+        if not rec:
+            return dict(mpjpe=[], pampjpe=[], pve=[], records=[])
+        pred = torch.stack([r['pred'] for r in rec]).cpu().numpy()
+        gt = torch.stack([r['gt'] for r in rec]).cpu().numpy()
+        mp = torch.stack([r['mpjpe'] for r in rec]).cpu().numpy() * 1000
+        pve = torch.stack([r['pve'] for r in rec]).cpu().numpy() * 1000
+        n, B = pred.shape[0], pred.shape[1]
+        hat = compute_similarity_transform_batch(pred.reshape(n * B, 14, 3), gt.reshape(n * B, 14, 3))
+        pa = np.sqrt(((hat - gt.reshape(n * B, 14, 3)) ** 2).sum(-1)).mean(-1).reshape(n, B) * 1000
+        out = dict(mpjpe=[], pampjpe=[], pve=[], records=[])
+        for i, r in enumerate(rec):
+            out['records'].append(dict(step=r['step'], tag=r['tag'], mpjpe=mp[i], pampjpe=pa[i], pve=float(pve[i])))
+            if r['tag'] is not None and r['tag'][0] == 'final':
+                if out['mpjpe'] and out['records'][-2]['step'] == r['step'] and out['records'][-2]['tag'][0] == 'final':
+                    out['mpjpe'][-1], out['pampjpe'][-1], out['pve'][-1] = mp[i], pa[i], float(pve[i])
+                else:
+                    out['mpjpe'].append(mp[i]); out['pampjpe'].append(pa[i]); out['pve'].append(float(pve[i]))
+        return out
+
+
+if __name__ == '__main__':
+    options = parser.parse_args()
+    adaptor = Adaptor(options)
+    res = adaptor.excute()
+    print(f"MPJPE:{np.mean(res['mpjpe'])}, PAMPJPE:{np.mean(res['pampjpe'])}, PVE:{np.mean(res['pve'])}")

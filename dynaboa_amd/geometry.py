@@ -1,0 +1,76 @@
+"""Rotation conversions with the reference's names (``utils/geometry.py``): rot6d_to_rotmat (:47-61),
+rotation_matrix_to_angle_axis (:184-213) on HIP kernels with hand-derived backward;
+batch_rodrigues (:9-24) as a few tiny torch ops - it only converts the ground-truth pose of
+retrieved exemplars / metric targets, never a learned quantity."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._abi import check
+from .hmr import stream_of
+
+
+class _Rot6d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        B = x.shape[0]
+        R = torch.empty(B * 24, 3, 3, device=x.device)
+        check(_lib.load().dyb_rot6d_fwd(x.data_ptr(), x.stride(0), R.data_ptr(), B, stream_of(x)), "dyb_rot6d_fwd")
+        ctx.save_for_backward(x)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR):
+        (x,) = ctx.saved_tensors
+        B = x.shape[0]
+        dx = torch.empty_like(x)
+        dR = dR.contiguous().float()
+        check(_lib.load().dyb_rot6d_bwd(x.data_ptr(), x.stride(0), dR.data_ptr(), dx.data_ptr(), dx.stride(0), B,
+                                        stream_of(x)), "dyb_rot6d_bwd")
+        return dx
+
+
+def rot6d_to_rotmat(x):
+    """(B,144) -> (B*24,3,3)."""
+    return _Rot6d.apply(x.reshape(-1, 144))
+
+
+class _R2AA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R):
+        R = R.contiguous().float()
+        n = R.shape[0]
+        aa = torch.empty(n, 3, device=R.device)
+        check(_lib.load().dyb_rotmat_to_aa_fwd(R.data_ptr(), aa.data_ptr(), n, stream_of(R)), "dyb_rotmat_to_aa_fwd")
+        ctx.save_for_backward(R)
+        return aa
+
+    @staticmethod
+    def backward(ctx, g):
+        (R,) = ctx.saved_tensors
+        n = R.shape[0]
+        dR = torch.empty_like(R)
+        g = g.contiguous().float()
+        check(_lib.load().dyb_rotmat_to_aa_bwd(R.data_ptr(), g.data_ptr(), dR.data_ptr(), n, stream_of(R)),
+              "dyb_rotmat_to_aa_bwd")
+        return dR
+
+
+def rotation_matrix_to_angle_axis(R):
+    """(N,3,3) -> (N,3)."""
+    return _R2AA.apply(R.reshape(-1, 3, 3))
+
+
+def batch_rodrigues(theta):
+    ang = (theta + 1e-8).norm(dim=1, keepdim=True)
+    axis = theta / ang
+    half = 0.5 * ang
+    q = torch.cat([half.cos(), half.sin() * axis], 1)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    rows = [w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+            2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
+            2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]
+    return torch.stack(rows, 1).view(-1, 3, 3)

@@ -1,0 +1,188 @@
+"""HMR (ResNet-50/GroupNorm backbone + iterative SMPL-parameter regressor) on the native engine.
+
+Python surface mirrors reference ``model/hmr.py``: ``hmr(smpl_mean_params, pretrained=False)`` builds
+the module; ``HMR.forward(x, need_feature=False, init_pose=None, init_shape=None, init_cam=None,
+n_iter=3)`` returns ``(pred_rotmat (B,24,3,3), pred_shape (B,10), pred_cam (B,3)[, features])``
+(reference ``model/hmr.py:127-181``); ``state_dict()/load_state_dict()`` speak the reference's
+parameter names and shapes.  All arithmetic happens in libdynaboa_hip.so: one C call per forward,
+one per backward, hooked into torch.autograd as a single coarse node whose only differentiable
+input is the flat parameter arena ``theta``.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, assets
+from ._abi import check
+from .hmr_layout import STATE_LD, HmrLayout
+
+_LAYOUTS: Dict[tuple, HmrLayout] = {}
+_WORKSPACES: Dict[tuple, torch.Tensor] = {}
+
+
+def stream_of(t: torch.Tensor):
+    """Raw hipStream_t of torch's current stream on t's device (None for host buffers, which only
+    the emulator build used by the CPU tests accepts)."""
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+def get_layout(batch: int, height: int = 224, width: int = 224) -> HmrLayout:
+    key = (batch, height, width)
+    if key not in _LAYOUTS:
+        _LAYOUTS[key] = HmrLayout(_lib.load(), batch, height, width)
+    return _LAYOUTS[key]
+
+
+def get_workspace(L: HmrLayout, device: torch.device) -> torch.Tensor:
+    key = (L.B, L.H, L.W, str(device))
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.empty(L.ws_bytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _feature_views(L: HmrLayout, acts: torch.Tensor, n_iter: int):
+    """The reference's feature list (model/hmr.py:139-168) as views of the activation arena.
+    Spatial maps are exposed NCHW-shaped (channels-last strides) so shapes match the reference."""
+    out = []
+    for i in range(6 + 3 * n_iter):
+        f = L.features[i]
+        d = [x for x in f["dims"] if x > 0]
+        if len(d) == 4:
+            v = acts[f["offset"]:f["offset"] + d[0] * d[1] * d[2] * d[3]].view(d[0], d[1], d[2], d[3]).permute(0, 3, 1, 2)
+        else:
+            v = torch.as_strided(acts, (d[0], d[1]), (f["row_stride"], 1), f["offset"])
+        out.append(v)
+    return out
+
+
+class _HMRFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, image, init_state, n_iter, need_feature):
+        lib = _lib.load()
+        B, _, H, W = image.shape
+        L = get_layout(B, H, W)
+        if theta.numel() != L.n_params:
+            raise ValueError("parameter arena size does not match the engine plan")
+        image = image.contiguous().float()
+        init_state = init_state.contiguous().float()
+        acts = torch.empty(L.act_floats, dtype=torch.float32, device=theta.device)
+        ws = get_workspace(L, theta.device)
+        check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter,
+                                  acts.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
+        ctx.L, ctx.n_iter = L, n_iter
+        ctx.save_for_backward(theta, acts)
+        rot = acts[L.off_rotmat:L.off_rotmat + B * 216].view(B, 24, 3, 3).clone()
+        st = acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD)
+        shape, cam = st[:, 144:154].clone(), st[:, 154:157].clone()
+        feats = tuple(_feature_views(L, acts, n_iter)) if need_feature else ()
+        ctx.mark_non_differentiable(*feats)
+        return (rot, shape, cam) + feats
+
+    @staticmethod
+    def backward(ctx, d_rot, d_shape, d_cam, *_unused):
+        lib = _lib.load()
+        theta, acts = ctx.saved_tensors
+        L = ctx.L
+        B = L.B
+        d_state = torch.zeros(B, STATE_LD, dtype=torch.float32, device=theta.device)
+        if d_shape is not None:
+            d_state[:, 144:154] = d_shape
+        if d_cam is not None:
+            d_state[:, 154:157] = d_cam
+        d_rot = torch.zeros(B, 24, 3, 3, device=theta.device) if d_rot is None else d_rot.contiguous().float()
+        grads = torch.zeros(L.n_params, dtype=torch.float32, device=theta.device)
+        ws = get_workspace(L, theta.device)
+        check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot.data_ptr(), d_state.data_ptr(),
+                                   ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)),
+              "dyb_hmr_backward")
+        return grads, None, None, None, None
+
+
+def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False):
+    """Functional form used by the MAML learner: forward with an explicit parameter arena."""
+    out = _HMRFunction.apply(theta, image, init_state, n_iter, need_feature)
+    if need_feature:
+        return out[0], out[1], out[2], list(out[3:])
+    return out[0], out[1], out[2]
+
+
+class HMR(nn.Module):
+    """SMPL iterative regressor with ResNet-50(GroupNorm) backbone; parameters live in one arena."""
+
+    def __init__(self, smpl_mean_params, seed: Optional[int] = None):
+        super().__init__()
+        if isinstance(smpl_mean_params, (str, bytes)):
+            mp = np.load(smpl_mean_params)
+            mp = {k: mp[k] for k in ("pose", "shape", "cam")}
+        else:
+            mp = smpl_mean_params
+        self._layout1 = get_layout(1)
+        sd = assets.make_synthetic_checkpoint(seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,))),
+                                              {k: np.asarray(v, np.float32) for k, v in mp.items()}, prefix="")["model"]
+        self.theta = nn.Parameter(self._layout1.pack(sd))
+        self.register_buffer("init_pose", sd["init_pose"].clone())
+        self.register_buffer("init_shape", sd["init_shape"].clone())
+        self.register_buffer("init_cam", sd["init_cam"].clone())
+
+    # ---- reference-named checkpoint I/O --------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False, **kw):
+        out = OrderedDict() if destination is None else destination
+        ref = self._layout1.unpack(self.theta.data)
+        for name, _ in assets.hmr_param_shapes():
+            out[prefix + name] = ref[name].to(self.theta.device)
+        for b in ("init_pose", "init_shape", "init_cam"):
+            out[prefix + b] = getattr(self, b).detach().clone()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        want = [n for n, _ in assets.hmr_param_shapes()] + ["init_pose", "init_shape", "init_cam"]
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for HMR: missing {missing[:5]} unexpected {unexpected[:5]}")
+        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        cur = self.state_dict()
+        for k in missing:
+            sd[k] = cur[k].cpu()
+        with torch.no_grad():
+            self.theta.copy_(self._layout1.pack(sd).to(self.theta.device))
+            for b in ("init_pose", "init_shape", "init_cam"):
+                getattr(self, b).copy_(sd[b].reshape(getattr(self, b).shape).to(self.theta.device))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def named_reference_parameters(self):
+        """The 169 reference-shaped parameter tensors (copies) in ``HMR.parameters()`` order."""
+        ref = self._layout1.unpack(self.theta.data)
+        return [(n, ref[n]) for n, _ in assets.hmr_param_shapes()]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def make_init_state(self, batch_size, init_pose=None, init_shape=None, init_cam=None):
+        dev = self.theta.device
+        st = torch.zeros(batch_size, STATE_LD, dtype=torch.float32, device=dev)
+        st[:, :144] = self.init_pose.expand(batch_size, -1) if init_pose is None else init_pose
+        st[:, 144:154] = self.init_shape.expand(batch_size, -1) if init_shape is None else init_shape
+        st[:, 154:157] = self.init_cam.expand(batch_size, -1) if init_cam is None else init_cam
+        return st
+
+    def forward(self, x, need_feature=False, init_pose=None, init_shape=None, init_cam=None, n_iter=3, theta=None):
+        if self.training:
+            raise NotImplementedError(
+                "HMR.forward in train() mode would need the two nn.Dropout layers of model/hmr.py:84,86; the "
+                "adaptation path always runs model.eval() (dynaboa_benchmark.py:89). Call .eval() first.")
+        st = self.make_init_state(x.shape[0], init_pose, init_shape, init_cam)
+        return hmr_apply(self.theta if theta is None else theta, x, st, n_iter, need_feature)
+
+
+def hmr(smpl_mean_params, pretrained: bool = False, **kwargs) -> HMR:
+    """Constructor with the reference's signature (model/hmr.py:314-323)."""
+    if pretrained:
+        raise NotImplementedError("ImageNet initialisation needs torchvision weights; load a checkpoint instead")
+    return HMR(smpl_mean_params, **kwargs)

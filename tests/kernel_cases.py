@@ -365,3 +365,60 @@ def case_optim(be, n=4096 * 3, seed=7):
     assert e["adam_delta"] < 3e-2 and e["adam_m"] < 1e-5 and e["adam_v"] < 1e-5, e
     assert e["fast"] < 1e-2 and e["ema"] < 1e-6 and e["axpby"] < 1e-6 and e["cos"] < 1e-6, e
     return e
+
+
+# ---------------------------------------------------------------------------------------- HMR engine
+def case_hmr_engine(be, golden, ckpt, check_grads=True):
+    """dyb_hmr_forward/backward vs golden g3 = the REFERENCE's own HMR module (model/hmr.py) on
+    the same seeded checkpoint and frame: outputs, features, and parameter gradients."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr_layout import HmrLayout
+    g = golden("g3_hmr.npz")
+    B = 2
+    L = HmrLayout(be.lib, B)
+    params = be.dev(L.pack(ckpt).numpy())
+    img = assets.make_frame(0, batch_size=B, seed=22)["image"].numpy()
+    init = np.repeat(HmrLayout.init_state(ckpt).numpy(), B, 0)
+    acts = be.empty((L.act_floats,))
+    ws = be.empty((L.ws_bytes // 4,))
+    check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(be.dev(img)), be.ptr(be.dev(init)), 3, be.ptr(acts),
+                                 be.ptr(ws), L.ws_bytes, be.stream), "hmr forward")
+    A = be.host(acts)
+    rot = A[L.off_rotmat:L.off_rotmat + B * 216].reshape(B, 24, 3, 3)
+    st = A[L.off_state:L.off_state + B * 160].reshape(B, 160)
+    e = dict(rotmat=rel_err(rot, g["rotmat"]), shape=rel_err(st[:, 144:154], g["shape"]), cam=rel_err(st[:, 154:157], g["cam"]))
+
+    def feat(i):
+        f = L.features[i]
+        d = [x for x in f["dims"] if x > 0]
+        if len(d) == 4:
+            return A[f["offset"]:f["offset"] + int(np.prod(d))].reshape(d)
+        rows = A[f["offset"]:f["offset"] + d[0] * f["row_stride"]].reshape(d[0], f["row_stride"])
+        return rows[:, :d[1]]
+    e["feat5"] = rel_err(feat(5), g["feat5"])
+    e["feat12"] = rel_err(feat(12), g["feat12"])
+    for i in range(15):
+        e[f"abs{i}"] = abs(float(np.abs(feat(i).astype(np.float64)).sum()) - g["feat_abs"][i]) / g["feat_abs"][i]
+    assert max(e.values()) < 5e-4, e
+    if not check_grads:
+        return e
+    d_state = np.zeros((B, 160), np.float32)
+    d_state[:, 144:154] = g["ws"]
+    d_state[:, 154:157] = g["wc"]
+    grads = be.zeros((L.n_params,))
+    check(be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(be.dev(g["wr"])), be.ptr(be.dev(d_state)), 3,
+                                  be.ptr(grads), be.ptr(ws), L.ws_bytes, be.stream), "hmr backward")
+    G = L.unpack(torch.from_numpy(be.host(grads)))
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([float(G[n].double().norm()) for n in names])
+    # 5e-3: a handful of activations sit within fp32 rounding of zero, so their ReLU mask (and with it
+    # a 3x3 patch of upstream gradient) legitimately differs between summation orders
+    bad = [(n, a, b) for n, a, b in zip(names, norms, g["grad_norms"]) if abs(a - b) > 5e-3 * b]
+    assert not bad, bad[:8]
+    from conftest import cosine
+    for k in g.files:
+        if k.startswith("gs_"):
+            n = k[3:]
+            assert cosine(G[n].flatten()[:256], g[k]) > 0.9999, n
+    e["grad_norm_maxrel"] = float(np.abs(norms / g["grad_norms"] - 1).max())
+    return e

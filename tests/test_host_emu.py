@@ -1,0 +1,126 @@
+"""Host-layer logic (module surface, arena packing, MAML / Adam plumbing, the per-frame schedule)
+exercised on CPU by pointing dynaboa_amd at the emulator build of the kernels (tests/emu).
+The full-frame case is opt-in (DYB_EMU_FULL=1, ~4 min); the GPU suite covers it at speed."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import cosine, golden, rel_err
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    from emu.build_emu import build
+    from dynaboa_amd import _abi, _lib
+    lib = _abi.bind(ctypes.CDLL(build()))
+    saved = _lib._lib
+    _lib.use_library(lib)
+    yield lib
+    _lib._lib = saved
+
+
+def test_abi_header_matches_library(emu_lib):
+    from dynaboa_amd import _abi
+    protos = _abi.parse_header()
+    assert len(protos) >= 45
+    for name in protos:
+        assert hasattr(emu_lib, name), name
+
+
+def test_arena_pack_unpack_roundtrip(emu_lib, ckpt_rand):
+    from dynaboa_amd.hmr_layout import HmrLayout
+    L = HmrLayout(emu_lib, 1)
+    assert L.n_params % 4 == 0
+    flat = L.pack(ckpt_rand)
+    back = L.unpack(flat)
+    n = 0
+    for k, v in ckpt_rand.items():
+        if k.startswith("init_"):
+            continue
+        assert torch.equal(back[k], v), k
+        n += v.numel()
+    assert n == 26_977_501
+    assert float(flat.abs().sum()) == pytest.approx(sum(float(v.abs().sum()) for k, v in ckpt_rand.items()
+                                                        if not k.startswith("init_")), rel=1e-5)
+
+
+def test_maml_adam_plumbing_small(emu_lib):
+    """clone()/adapt() first-order semantics and the fused Adam on a toy 'module' with a flat theta."""
+    from dynaboa_amd.maml import MAML, _FastWeightStep
+    from dynaboa_amd.optim import Adam, ema_update
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.theta = torch.nn.Parameter(torch.linspace(-1, 1, 64))
+
+        def forward(self, x, theta=None):
+            t = self.theta if theta is None else theta
+            return (t * x).sum()
+
+    toy = Toy()
+    m = MAML(toy, lr=0.1, first_order=True)
+    x = torch.arange(64.0) / 64
+    learner = m.clone()
+    inner = (learner(x) - 1.0) ** 2
+    learner.adapt(inner)
+    g_inner = 2 * ((toy.theta.detach() * x).sum() - 1.0) * x
+    assert torch.allclose(learner._theta.detach(), toy.theta.detach() - 0.1 * g_inner, atol=1e-6)
+    outer = (learner(x) ** 2)
+    opt = Adam(m.parameters(), lr=3e-3, betas=(0.5, 0.9))
+    opt.zero_grad()
+    outer.backward()
+    fast = learner._theta.detach()
+    assert torch.allclose(toy.theta.grad, 2 * (fast * x).sum() * x, atol=1e-5)       # FO: grad taken AT the fast weights
+    ref = toy.theta.detach().clone().requires_grad_(True)
+    ropt = torch.optim.Adam([ref], lr=3e-3, betas=(0.5, 0.9))
+    ref.grad = toy.theta.grad.clone()
+    ropt.step()
+    opt.step()
+    assert torch.allclose(toy.theta.detach(), ref.detach(), atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        MAML(toy, 0.1, first_order=False).clone().adapt(outer)
+    t = torch.zeros(64)
+    ema_update([t], [toy.theta.detach()], 0.1)
+    assert torch.allclose(t, 0.9 * toy.theta.detach(), atol=1e-7)
+
+
+def test_smpl_wrapper_surface(emu_lib, smpl_tabs):
+    from dynaboa_amd.smpl import SMPL
+    from oracle import ref_cpu as O
+    smpl = SMPL(tables=smpl_tabs)
+    g = torch.Generator().manual_seed(0)
+    betas = torch.randn(1, 10, generator=g) * 0.5
+    pose = torch.randn(1, 72, generator=g) * 0.2
+    out = smpl(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3])            # pose2rot=True path
+    T = O.smpl_tables_to_torch(smpl_tabs)
+    v, j = O.smpl_forward(T, betas, pose[:, 3:], pose[:, :3], pose2rot=True)
+    assert out.vertices.shape == (1, 6890, 3) and out.joints.shape == (1, 49, 3)
+    assert rel_err(out.vertices.numpy(), v.numpy()) < 1e-5 and rel_err(out.joints.numpy(), j.numpy()) < 1e-5
+
+
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~4 min under the emulator; set DYB_EMU_FULL=1")
+def test_full_frame_on_emulator_matches_reference(emu_lib):
+    from dynaboa_amd import assets
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    g = golden("g5_fo_inner1_frameonly_identity.npz")
+    o = DB.frame_only_options(inner_step=1)
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True, randomize_norm=True), device="cpu")
+    ad.reset_records(1)
+    ad.global_step = 0
+    batch = assets.make_frame(0, 1, seed=22)
+    ad.model.eval()
+    theta0 = ad.model.module.theta.detach().clone()
+    mpjpe, pampjpe, pve = ad.adaptation(batch)
+    up = float(ad.fit_losses["ul/s2dloss"]) * 10 + float(ad.fit_losses["ul/shape_prior"]) * 2e-6 + float(ad.fit_losses["ul/pose_prior"]) * 1e-4
+    assert abs(up - g["upper_loss"][0]) < 1e-4 * abs(g["upper_loss"][0])
+    assert abs(float(np.mean(mpjpe)) - g["mpjpe"][0]) < 1e-3 * g["mpjpe"][0]
+    assert abs(float(np.mean(pampjpe)) - g["pampjpe"][0]) < 2e-3 * g["pampjpe"][0]
+    with torch.no_grad():
+        r, s, c = ad.model(batch["image"])
+    assert rel_err(r.numpy(), g["pred0_rotmat"]) < 1e-3 and rel_err(c.numpy(), g["pred0_cam"]) < 1e-3
+    assert float((ad.model.module.theta.detach() - theta0).abs().max()) > 0

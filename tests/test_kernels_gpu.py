@@ -1,0 +1,122 @@
+"""Parity of every HIP kernel at the REAL sizes of the path (all 23 ResNet-50 conv shapes of
+SURVEY 8a row 2, the SMPL tables, the 27 M-float arena) through the C ABI on cuda:0, against the
+oracle / torch-CPU fp32 ops and the golden vectors."""
+import numpy as np
+import pytest
+
+import kernel_cases as K
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from backends import GpuBackend
+    return GpuBackend()
+
+
+# (H, W, Cin, Cout, k, stride, pad) - the 23 unique shapes, batch 1
+RESNET_SHAPES = [
+    (224, 224, 4, 64, 7, 2, 3), (56, 56, 64, 64, 1, 1, 0), (56, 56, 64, 64, 3, 1, 1), (56, 56, 64, 256, 1, 1, 0),
+    (56, 56, 256, 64, 1, 1, 0), (56, 56, 256, 128, 1, 1, 0), (56, 56, 128, 128, 3, 2, 1), (28, 28, 128, 512, 1, 1, 0),
+    (56, 56, 256, 512, 1, 2, 0), (28, 28, 512, 128, 1, 1, 0), (28, 28, 128, 128, 3, 1, 1), (28, 28, 512, 256, 1, 1, 0),
+    (28, 28, 256, 256, 3, 2, 1), (14, 14, 256, 1024, 1, 1, 0), (28, 28, 512, 1024, 1, 2, 0), (14, 14, 1024, 256, 1, 1, 0),
+    (14, 14, 256, 256, 3, 1, 1), (14, 14, 1024, 512, 1, 1, 0), (14, 14, 512, 512, 3, 2, 1), (7, 7, 512, 2048, 1, 1, 0),
+    (14, 14, 1024, 2048, 1, 2, 0), (7, 7, 2048, 512, 1, 1, 0), (7, 7, 512, 512, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_all_resnet_shapes(be, shape):
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc, c_real=3 if C == 4 else None)
+
+
+@pytest.mark.parametrize("shape", [(56, 56, 64, 64, 3, 1, 1), (28, 28, 512, 1024, 1, 2, 0), (7, 7, 512, 512, 3, 1, 1)])
+def test_conv_batch8(be, shape):
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
+
+
+@pytest.mark.parametrize("cfg", [(1, 12544, 64, 1, False, 1), (1, 3136, 256, 1, True, 1), (1, 784, 512, 1, True, 2),
+                                 (1, 196, 1024, 0, False, 5), (1, 49, 2048, 1, True, 16), (8, 196, 256, 1, False, 1),
+                                 (2, 49, 512, 1, False, 9)])
+def test_groupnorm(be, cfg):
+    K.case_groupnorm(be, *cfg)
+
+
+def test_pools(be):
+    K.case_pools(be, 2, 112, 112, 64)
+    K.case_avgpool(be, 3, 49, 2048)
+
+
+def test_linear(be):
+    K.case_linear(be, 1, 2205, 1024)
+    K.case_linear(be, 8, 1024, 1024)
+    K.case_linear(be, 3, 1024, 160)
+
+
+def test_rotations(be):
+    K.case_rot6d(be, golden)
+    K.case_rotmat_to_aa(be, golden)
+    K.case_projection(be, B=8)
+
+
+def test_lbs(be, smpl_tabs):
+    K.case_lbs(be, smpl_tabs, B=1, with_dverts=False)
+    K.case_lbs(be, smpl_tabs, B=8, with_dverts=True)
+
+
+def test_lbs_known_answers(be, smpl_tabs):
+    """First-principles pins for the third-party (smplx) semantics: identity pose and a rigid root
+    rotation."""
+    import torch
+    from oracle import ref_cpu as O
+    from dynaboa_amd._abi import check
+    B = 2
+    fb, ib, (_a, pf), (_b, pi) = K.smpl_device_tables(be, smpl_tabs)
+    betas = (np.random.default_rng(0).standard_normal((B, 10)) * 0.5).astype(np.float32)
+    rot = np.tile(np.eye(3, dtype=np.float32), (B, 24, 1, 1))
+    R0 = O.smplx_rodrigues(torch.tensor([[0.4, -0.7, 0.3]])).numpy()[0]
+    rot[1, 0] = R0
+    V, J = be.empty((B, 6890, 3)), be.empty((B, 49, 3))
+    saved = be.empty((be.lib.dyb_lbs_saved_floats(B),))
+    check(be.lib.dyb_lbs_fwd(pf, pi, be.ptr(be.dev(betas)), 10, be.ptr(be.dev(rot)), be.ptr(V), be.ptr(J), be.ptr(saved), B,
+                             be.stream), "lbs")
+    v = be.host(V)
+    v_shaped = smpl_tabs["v_template"][None] + np.einsum("bl,vcl->bvc", betas, smpl_tabs["shapedirs"])
+    assert np.abs(v[0] - v_shaped[0]).max() < 2e-6
+    J0 = (smpl_tabs["J_regressor"] @ v_shaped[1])[0]
+    assert np.abs(v[1] - ((v_shaped[1] - J0) @ R0.T + J0)).max() < 5e-6
+
+
+def test_frame_losses(be):
+    from dynaboa_amd import assets
+    K.case_frame_losses(be, golden, assets.load_gmm_prior())
+
+
+def test_optim_full_arena(be):
+    K.case_optim(be, n=26_977_504)
+
+
+def test_conv_linearity_full_size(be):
+    """Size-independent property at the largest layer: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    from dynaboa_amd._abi import check
+    rng = np.random.default_rng(3)
+    N, H, W, C, Kc = 8, 56, 56, 64, 256
+    w = be.dev((rng.standard_normal((1, 1, C, Kc)) / 8).astype(np.float32))
+    x1, x2 = rng.standard_normal((N, H, W, C)).astype(np.float32), rng.standard_normal((N, H, W, C)).astype(np.float32)
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, Kc, 1, 1, 1, 0)
+    ws = be.empty((max(wsb, 16) // 4,))
+    outs = []
+    for x in (x1, x2, 2.5 * x1 + x2):
+        y = be.empty((N, H, W, Kc))
+        check(be.lib.dyb_conv2d_nhwc_fwd(be.ptr(be.dev(x)), be.ptr(w), be.ptr(y), N, H, W, C, Kc, 1, 1, 1, 0, be.ptr(ws), wsb,
+                                         be.stream), "conv")
+        outs.append(be.host(y))
+    assert np.abs(outs[2] - (2.5 * outs[0] + outs[1])).max() < 1e-4 * np.abs(outs[2]).max()
+
+
+def test_hmr_engine_vs_reference_module(be, ckpt_rand):
+    e = K.case_hmr_engine(be, golden, ckpt_rand)
+    print(e)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, kernel trace.  Everything lands in gpurun_out/.
+# usage: tools/gpu_session.sh [stages...]   stages: info tests smoke bench prof
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+export TMPDIR=/tmp
+STAGES=${@:-info tests smoke bench prof}
+for s in $STAGES; do
+  case $s in
+    info)  (rocm-smi --showproductname 2>/dev/null | head -8; nproc; lscpu | grep -E "Model name|Socket|Core") > $OUT/info.txt 2>&1 ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=600 -rA 2>&1 | tail -120 > $OUT/pytest_gpu.log ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ;;
+    bench) timeout 900 python bench.py --steps 40 --warmup 8 > $OUT/bench.json 2> $OUT/bench.err ;;
+    benchmin) timeout 600 python bench.py --steps 40 --warmup 8 --schedule minimal --no_cpu_baseline > $OUT/bench_min.json 2> $OUT/bench_min.err ;;
+    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline) > $OUT/prof.log 2>&1
+           find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/prof.log ;;
+  esac
+  echo "stage $s done rc=$?" >> $OUT/stages.log
+done
+tail -5 $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/smoke.log 2>/dev/null | tail -3; cat $OUT/bench.json 2>/dev/null
