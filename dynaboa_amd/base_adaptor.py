@@ -261,6 +261,9 @@ class BaseAdaptor:
         if getattr(o, f"{level}_level_mixtrain"):
             lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag)
             loss = loss + lab * o.labelloss_weight
+        # the reference builds the sum with in-place `loss += ...` on the tensor it stored as
+        # '<tag>/unlabelloss' (base_adaptor.py:244,250,254,266), so what it logs under that key is this total
+        self.fit_losses[f"{tag}/total"] = loss.detach()
         return loss, feats
 
     def lower_level_adaptation(self, image, gt_keypoints_2d, h36m_batch, learner=None):

@@ -127,11 +127,24 @@ static int gn_chunks(int HW, int N) {
   return dyb_cdiv(HW, rows);
 }
 
+// backward: the finalize kernel walks the chunks serially, so cap them at 32 while keeping
+// >= ~128 workgroups in the reduce kernel
+static int gn_chunks_bwd(int HW, int N, int C) {
+  int CQ = C / 4;
+  int colblocks = CQ > 256 ? CQ / 256 : 1;
+  int want = 128 / (N * colblocks);
+  if (want < 1) want = 1;
+  if (want > 32) want = 32;
+  int nch = HW < want ? HW : want;
+  int rows = dyb_cdiv(HW, nch);
+  return dyb_cdiv(HW, rows);
+}
+
 extern "C" size_t dyb_groupnorm_workspace_bytes(int N, int HW, int C) {
   // forward partials [N][nchunks][G][2]; backward partials [N][nchunks][2][C] + coef [N][G][2]
-  size_t nch = (size_t)gn_chunks(HW, N);
+  size_t nch = (size_t)gn_chunks(HW, N), nchb = (size_t)gn_chunks_bwd(HW, N, C);
   size_t fwd = (size_t)N * nch * G * 2;
-  size_t bwd = (size_t)N * nch * 2 * C + (size_t)N * G * 2;
+  size_t bwd = (size_t)N * nchb * 2 * C + (size_t)N * G * 2;
   return (fwd > bwd ? fwd : bwd) * sizeof(float);
 }
 
@@ -210,66 +223,63 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// one workgroup.  dgamma[c] = sum_n B, dbeta[c] = sum_n A; coef[n][g] = (S1/m, S2/m)
+// one workgroup per group g (grid = 4).  dgamma[c] = sum_n B, dbeta[c] = sum_n A;
+// coef[n][g] = (S1/m, S2/m) with S1 = sum_{c in g} gamma_c A_nc, S2 likewise with B.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nchunks,
                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef, int N,
                                                               int HW, int C) {
-  __shared__ float red[4 * 8];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int cg = C / G;
-  float gam[8], dg[8], db[8];
+  __shared__ float red[4][2];
+  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cg = C / G;                       // <= 512 channels per group -> at most 2 per thread
+  float gam[2], dg[2], db[2];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int c = tid + 256 * k;
-    gam[k] = c < C ? gamma[c] : 0.f;
+  for (int k = 0; k < 2; ++k) {
+    int cl = tid + 256 * k;
+    gam[k] = cl < cg ? gamma[g * cg + cl] : 0.f;
     dg[k] = 0.f;
     db[k] = 0.f;
   }
   const float inv_m = 1.0f / ((float)cg * (float)HW);
   for (int n = 0; n < N; ++n) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // s[g] = S1_g, s[4+g] = S2_g
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      int c = tid + 256 * k;
-      if (c < C) {
-        float A = 0.f, B = 0.f;
-        for (int ch = 0; ch < nchunks; ++ch) {
-          const float* p = partials + ((size_t)n * nchunks + ch) * 2 * C;
-          A += p[c];
-          B += p[C + c];
+    for (int k = 0; k < 2; ++k) {
+      int cl = tid + 256 * k;
+      if (cl < cg) {
+        const float* p = partials + (size_t)n * nchunks * 2 * C + (g * cg + cl);
+        float A0 = 0.f, A1 = 0.f, B0 = 0.f, B1 = 0.f;
+        int ch = 0;
+        for (; ch + 1 < nchunks; ch += 2) {
+          A0 += p[(size_t)ch * 2 * C];
+          B0 += p[(size_t)ch * 2 * C + C];
+          A1 += p[(size_t)(ch + 1) * 2 * C];
+          B1 += p[(size_t)(ch + 1) * 2 * C + C];
         }
+        if (ch < nchunks) {
+          A0 += p[(size_t)ch * 2 * C];
+          B0 += p[(size_t)ch * 2 * C + C];
+        }
+        float A = A0 + A1, B = B0 + B1;
         db[k] += A;
         dg[k] += B;
-        int g = c / cg;
-        float ga = gam[k] * A, gb = gam[k] * B;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s[q] += (g == q) ? ga : 0.f;
-          s[4 + q] += (g == q) ? gb : 0.f;
-        }
+        s1 += gam[k] * A;
+        s2 += gam[k] * B;
       }
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = dyb_wave_sum(s[q]);
-    __syncthreads();                       // red[] reuse across n
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) red[wave * 8 + q] = s[q];
-    }
+    s1 = dyb_wave_sum(s1);
+    s2 = dyb_wave_sum(s2);
     __syncthreads();
-    if (tid < 8) {
-      float t = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
-      int g = tid & 3, which = tid >> 2;
-      coef[((size_t)n * G + g) * 2 + which] = t * inv_m;
-    }
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
+    __syncthreads();
+    if (tid < 2) coef[((size_t)n * G + g) * 2 + tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * inv_m;
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int c = tid + 256 * k;
-    if (c < C) {
-      dgamma[c] = dg[k];
-      dbeta[c] = db[k];
+  for (int k = 0; k < 2; ++k) {
+    int cl = tid + 256 * k;
+    if (cl < cg) {
+      dgamma[g * cg + cl] = dg[k];
+      dbeta[g * cg + cl] = db[k];
     }
   }
 }
@@ -315,7 +325,7 @@ extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const floa
   DYB_REQUIRE(dout && y && stats && gamma && dy && dgamma && dbeta && ws, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
-  int nch = gn_chunks(HW, N);
+  int nch = gn_chunks_bwd(HW, N, C);
   size_t need = ((size_t)N * nch * 2 * C + (size_t)N * G * 2) * sizeof(float);
   DYB_REQUIRE(ws_bytes >= need, DYB_ERR_WORKSPACE);
   int rows = dyb_cdiv(HW, nch);
@@ -326,7 +336,7 @@ extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const floa
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(CQ / TX, nch, N), dim3(256), 0, st, dout, out, y, stats, partials, HW,
                      C, rows, relu, TX);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nch, gamma, dgamma,
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, st, (const float*)partials, nch, gamma, dgamma,
                      dbeta, coef, N, HW, C);
   DYB_CHECK_LAUNCH();
   size_t total4 = (size_t)N * HW * CQ;

@@ -366,6 +366,7 @@ class Adapter:
         if o[f"{level}_level_mixtrain"]:
             ex = self.exemplar_fn(self.global_step)
             loss = loss + self.label_loss(w, ex) * o["labelloss_weight"]
+        self.log[("ll" if level == "lower" else "ul") + "/total"] = float(loss)
         return loss, feats
 
     def adam_step(self, grads: Params):

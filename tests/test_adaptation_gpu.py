@@ -50,8 +50,7 @@ def test_stream_matches_reference(tag):
         batch = {k: v.to(ad.device) for k, v in assets.make_frame(step, 1, seed=22).items()}
         ad.model.eval()
         mpjpe, pampjpe, pve = ad.adaptation(batch)
-        up = float(ad.fit_losses["ul/s2dloss"]) * 10 + float(ad.fit_losses["ul/shape_prior"]) * 2e-6 \
-            + float(ad.fit_losses["ul/pose_prior"]) * 1e-4
+        up = float(ad.fit_losses["ul/total"])      # golden 'ul/unlabelloss' aliases the in-place total (see base_adaptor._level)
         assert abs(up - g["upper_loss"][step]) < 1e-4 * abs(g["upper_loss"][step]), (step, up, g["upper_loss"][step])
         if opts.get("dynamic_boa", 1):
             assert ad.optim_step_record[-1] == int(g["extra_steps"][step])

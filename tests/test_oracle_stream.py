@@ -41,8 +41,8 @@ def test_stream(tag, gmm_t, smpl_tabs):
     torch.set_num_threads(8)
     for step in range(n):
         rec = ad.adapt_frame(assets.make_frame(step, 1, seed=22))
-        assert abs(ad.log["ul/s2dloss"] * 10 + ad.log["ul/shape_prior"] * 2e-6
-                   + ad.log["ul/pose_prior"] * 1e-4 - g["upper_loss"][step]) < 2e-5 * abs(g["upper_loss"][step])
+        # the reference's logged 'ul/unlabelloss' aliases the in-place-accumulated TOTAL upper loss
+        assert abs(ad.log["ul/total"] - g["upper_loss"][step]) < 2e-5 * abs(g["upper_loss"][step])
         assert rec["extra_steps"] == int(g["extra_steps"][step])
         for k in ("rotmat", "shape", "cam", "joints"):
             assert rel_err(rec["pred"][k], g[f"pred{step}_{k}"]) < 1e-4, (step, k)

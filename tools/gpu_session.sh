@@ -15,8 +15,8 @@ for s in $STAGES; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ;;
     bench) timeout 900 python bench.py --steps 40 --warmup 8 > $OUT/bench.json 2> $OUT/bench.err ;;
     benchmin) timeout 600 python bench.py --steps 40 --warmup 8 --schedule minimal --no_cpu_baseline > $OUT/bench_min.json 2> $OUT/bench_min.err ;;
-    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline) > $OUT/prof.log 2>&1
-           find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/prof.log ;;
+    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline) > $OUT/prof.log 2>&1
+           find $OUT/prof -name "*stats*" | head -5 >> $OUT/prof.log ;;
   esac
   echo "stage $s done rc=$?" >> $OUT/stages.log
 done
