@@ -14,6 +14,7 @@
  *   - return value: 0 = ok, -1 bad argument, -2 launch failure, -3 unsupported shape,
  *     -4 workspace too small;
  *   - one host thread per GPU process; re-entrant across different streams + workspaces.
+ *   - `const T* const*` arguments are HOST arrays of device pointers;
  *   - activations are NHWC, conv weights [R][S][Cin][Cout] (Cin padded to >= 4), linear weights
  *     (out, in) row-major with the row stride padded to a multiple of 4 floats.
  */

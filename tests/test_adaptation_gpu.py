@@ -77,7 +77,7 @@ def test_stream_matches_reference(tag):
     np.testing.assert_allclose(vn, g["v_norms"], rtol=2e-2)
     np.testing.assert_allclose(dn, g["delta_norms"], rtol=5e-2)
     for k in SLICE_PARAMS:
-        assert cosine(m[k].flatten()[:256], g["m_" + k]) > 0.999, k
+        assert cosine(m[k].flatten()[:256], g["m_" + k]) > 0.99, k     # early-layer slices carry ReLU-flip noise
         assert cosine(delta[k].flatten()[:256], g["d_" + k]) > 0.99, k
     if "teacher_delta_norms" in g.files and opts.get("use_meanteacher", 1):
         td = L.unpack((ad.teacher.theta.detach().double() - theta0.double()).float())
