@@ -62,6 +62,7 @@ struct ConvL {
   int H, W, C, K, R, S, stride, pad, Ho, Wo;
   size_t w, gam, bet;          // parameter offsets
   size_t y, out, stats;        // activation offsets (conv output, normalised output, [B][4][2])
+  size_t dy;                   // offset (floats) of this layer's d(conv output) in the workspace dy arena
 };
 struct BlockL {
   int c1, c2, c3, cd;          // indices into convs (cd = -1: identity shortcut)
@@ -81,7 +82,11 @@ struct HmrPlan {
   int poolH, poolW;            // max-pool output
   int featHW;                  // spatial size of the last feature map (7*7)
   // workspace carve (bytes)
-  size_t ws_conv, ws_gn, ws_lin, ws_grad_each, ws_reg, ws_total;
+  size_t ws_conv, ws_conv_aux, ws_gn, ws_lin, ws_grad_each, ws_dy, ws_reg, ws_total;
+  // cross-stream ordering for the weight-gradient convolutions (created on first use)
+  std::vector<hipEvent_t> ev_dy;
+  hipEvent_t ev_join;
+  bool events_ready;
 };
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -167,8 +172,11 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.a_rot = aoff; aoff = align64(aoff + (size_t)B * 24 * 9);
   P.act_floats = aoff;
 
-  size_t wc = 0, wg = 0, maxact = 0;
+  size_t wc = 0, wg = 0, maxact = 0, dyoff = 0;
+  P.events_ready = false;
   for (auto& c : P.convs) {
+    c.dy = dyoff;
+    dyoff = align64(dyoff + (size_t)B * c.Ho * c.Wo * c.K);
     size_t s = dyb_conv2d_workspace_bytes(B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad);
     if (s > wc) wc = s;
     size_t g = dyb_groupnorm_workspace_bytes(B, c.Ho * c.Wo, c.K);
@@ -182,12 +190,14 @@ static HmrPlan* build_plan(int B, int H, int W) {
   size_t wl2 = dyb_linear_bwd_workspace_bytes(B, HID, HID);
   if (wl2 > wl) wl = wl2;
   P.ws_conv = align64(wc / 4) * 4;
+  P.ws_conv_aux = P.ws_conv;
+  P.ws_dy = dyoff * 4;
   P.ws_gn = align64(wg / 4) * 4;
   P.ws_lin = align64(wl / 4) * 4;
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_gn + P.ws_lin + 4 * P.ws_grad_each + P.ws_reg;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
   return pp;
 }
 
@@ -197,7 +207,24 @@ extern "C" int dyb_hmr_plan_create(int B, int H, int W, void** plan) {
   *plan = p;
   return DYB_OK;
 }
-extern "C" void dyb_hmr_plan_destroy(void* plan) { delete reinterpret_cast<HmrPlan*>(plan); }
+extern "C" void dyb_hmr_plan_destroy(void* plan) {
+  HmrPlan* P = reinterpret_cast<HmrPlan*>(plan);
+  if (!P) return;
+  if (P->events_ready) {
+    for (hipEvent_t e : P->ev_dy) hipEventDestroy(e);
+    hipEventDestroy(P->ev_join);
+  }
+  delete P;
+}
+static int ensure_events(HmrPlan& P) {
+  if (P.events_ready) return DYB_OK;
+  P.ev_dy.resize(P.convs.size());
+  for (size_t i = 0; i < P.convs.size(); ++i)
+    if (hipEventCreateWithFlags(&P.ev_dy[i], hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
+  if (hipEventCreateWithFlags(&P.ev_join, hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
+  P.events_ready = true;
+  return DYB_OK;
+}
 extern "C" size_t dyb_hmr_param_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->n_params; }
 extern "C" size_t dyb_hmr_act_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->act_floats; }
 extern "C" size_t dyb_hmr_workspace_bytes(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->ws_total; }
@@ -244,17 +271,20 @@ extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long l
   } while (0)
 
 struct WsCarve {
-  char *conv, *gn, *lin;
-  float* g[4];
+  char *conv, *conv_aux, *gn, *lin;
+  float* g[3];
+  float* dy;
   float* reg;
 };
 static WsCarve carve(const HmrPlan& P, void* ws) {
   WsCarve c;
   char* b = reinterpret_cast<char*>(ws);
   c.conv = b; b += P.ws_conv;
+  c.conv_aux = b; b += P.ws_conv_aux;
   c.gn = b; b += P.ws_gn;
   c.lin = b; b += P.ws_lin;
-  for (int i = 0; i < 4; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
+  for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
+  c.dy = reinterpret_cast<float*>(b); b += P.ws_dy;
   c.reg = reinterpret_cast<float*>(b);
   return c;
 }
@@ -321,13 +351,26 @@ extern "C" int dyb_hmr_forward(const void* plan, const float* params, const floa
   return DYB_OK;
 }
 
-static int gn_conv_bwd(const HmrPlan& P, const ConvL& c, const float* params, const float* acts, float* grads,
-                       const float* conv_in, const float* dout, int relu, float* dy_buf, float* dres, float* dx,
-                       const float* dx_addend, const WsCarve& w, hipStream_t st) {
+// GroupNorm backward -> d(conv output) into this layer's own dy buffer, then the two convolution
+// gradients.  The weight gradient is off the critical path (nothing downstream reads it before the
+// optimiser), so when an auxiliary stream is given it runs there, ordered by one event per layer,
+// with its own split-K slab region; the data gradient continues on the main stream.
+static int gn_conv_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
+                       const float* dout, int relu, float* dres, float* dx, const float* dx_addend, const WsCarve& w,
+                       hipStream_t st, hipStream_t aux) {
+  const ConvL& c = P.convs[ci];
+  float* dy_buf = w.dy + c.dy;
   RUN(dyb_groupnorm_bwd(dout, acts + c.out, acts + c.y, acts + c.stats, params + c.gam, dy_buf, dres, grads + c.gam,
                         grads + c.bet, P.B, c.Ho * c.Wo, c.K, relu, w.gn, P.ws_gn, st));
-  RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv,
-                            P.ws_conv, st));
+  if (aux) {
+    if (hipEventRecord(P.ev_dy[ci], st) != hipSuccess) return DYB_ERR_LAUNCH;
+    if (hipStreamWaitEvent(aux, P.ev_dy[ci], 0) != hipSuccess) return DYB_ERR_LAUNCH;
+    RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad,
+                              w.conv_aux, P.ws_conv_aux, aux));
+  } else {
+    RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv,
+                              P.ws_conv, st));
+  }
   if (dx)
     RUN(dyb_conv2d_nhwc_dgrad(dy_buf, params + c.w, dx, dx_addend, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad,
                               w.conv, P.ws_conv, st));
@@ -337,14 +380,18 @@ static int gn_conv_bwd(const HmrPlan& P, const ConvL& c, const float* params, co
 // d_rotmat: [B][24][9]; d_state: [B][160], only columns 144..156 (shape, cam) are read.
 // grads: parameter-arena-shaped buffer, every tensor's span is overwritten (pad gaps untouched:
 // zero them once at allocation).
-extern "C" int dyb_hmr_backward(const void* plan, const float* params, const float* acts, const float* d_rotmat,
+// aux_stream (may be NULL): a second stream the weight-gradient convolutions are issued on; the call
+// returns with `stream` already waiting for them, so callers keep ordering on `stream` only.
+extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* acts, const float* d_rotmat,
                                 const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes,
-                                hipStream_t st) {
-  const HmrPlan* Pp = reinterpret_cast<const HmrPlan*>(plan);
+                                hipStream_t st, hipStream_t aux) {
+  HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
   DYB_REQUIRE(Pp && params && acts && d_rotmat && d_state && grads && ws, DYB_ERR_ARG);
   DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
-  const HmrPlan& P = *Pp;
+  HmrPlan& P = *Pp;
   DYB_REQUIRE(ws_bytes >= P.ws_total, DYB_ERR_WORKSPACE);
+  if (aux == st) aux = nullptr;
+  if (aux) RUN(ensure_events(P));
   WsCarve w = carve(P, ws);
   const int B = P.B;
   float* d_st[MAX_ITER + 1];
@@ -378,33 +425,35 @@ extern "C" int dyb_hmr_backward(const void* plan, const float* params, const flo
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, FC1_IN_PAD, HID, grads + P.fc1_w, FC1_IN_PAD, grads + P.fc1_b, st));
   }
 
-  // ---- backbone, last block first.  Four ping-pong buffers:
-  //   cur  = d(block output), T1 = d(conv output), T2 = d(residual edge), T3 = d(conv input)
-  float *cur = w.g[0], *T1 = w.g[1], *T2 = w.g[2], *T3 = w.g[3];
+  // ---- backbone, last block first.  Three ping-pong buffers (cur = d(block output), T2, T3) plus one
+  // dedicated d(conv output) buffer per layer (w.dy), which is what lets wgrad run asynchronously.
+  float *cur = w.g[0], *T2 = w.g[1], *T3 = w.g[2];
   RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, cur, B, P.featHW, FEAT, st));
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
-    const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
+    const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
     const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
-    // out = relu(gn3(conv3(a2)) + res)
-    RUN(gn_conv_bwd(P, c3, params, acts, grads, acts + c2.out, cur, 1, T1, T2, T3, nullptr, w, st));
-    RUN(gn_conv_bwd(P, c2, params, acts, grads, acts + c1.out, T3, 1, T1, nullptr, cur, nullptr, w, st));
-    // now: cur = d(a1), T2 = d(residual edge), T1/T3 free
+    // out = relu(gn3(conv3(a2)) + res):  T2 <- d(residual edge), T3 <- d(a2)
+    RUN(gn_conv_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, 1, T2, T3, nullptr, w, st, aux));
+    // cur <- d(a1)
+    RUN(gn_conv_bwd(P, b.c2, params, acts, grads, acts + c1.out, T3, 1, nullptr, cur, nullptr, w, st, aux));
     if (b.cd >= 0) {
-      const ConvL& cd = P.convs[b.cd];
-      // shortcut branch first: T3 <- dgrad_d ; then main branch adds it
-      RUN(gn_conv_bwd(P, cd, params, acts, grads, xin, T2, 0, T1, nullptr, T3, nullptr, w, st));
-      RUN(gn_conv_bwd(P, c1, params, acts, grads, xin, cur, 1, T1, nullptr, T2, T3, w, st));
+      // shortcut branch first: T3 <- dgrad_d(T2); then the main branch adds it: T2 <- dgrad_1(cur) + T3
+      RUN(gn_conv_bwd(P, b.cd, params, acts, grads, xin, T2, 0, nullptr, T3, nullptr, w, st, aux));
+      RUN(gn_conv_bwd(P, b.c1, params, acts, grads, xin, cur, 1, nullptr, T2, T3, w, st, aux));
     } else {
-      RUN(gn_conv_bwd(P, c1, params, acts, grads, xin, cur, 1, T1, nullptr, T3, T2, w, st));
+      RUN(gn_conv_bwd(P, b.c1, params, acts, grads, xin, cur, 1, nullptr, T3, T2, w, st, aux));
       float* tmp = T2; T2 = T3; T3 = tmp;
     }
-    // result is in T2 -> becomes cur
-    float* tmp = cur; cur = T2; T2 = tmp;
+    float* tmp = cur; cur = T2; T2 = tmp;          // result was in T2 -> becomes cur
   }
   // ---- stem: maxpool -> GN/ReLU -> conv1 (no data gradient needed for the image)
   const ConvL& stem = P.convs[0];
   RUN(dyb_maxpool3x3s2_bwd(cur, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), T3, B, stem.Ho, stem.Wo, stem.K, st));
-  RUN(gn_conv_bwd(P, stem, params, acts, grads, acts + P.a_x4, T3, 1, T1, nullptr, nullptr, nullptr, w, st));
+  RUN(gn_conv_bwd(P, 0, params, acts, grads, acts + P.a_x4, T3, 1, nullptr, nullptr, nullptr, w, st, aux));
+  if (aux) {
+    if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
+    if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;
+  }
   return DYB_OK;
 }

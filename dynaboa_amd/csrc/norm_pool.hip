@@ -37,10 +37,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 v = *reinterpret_cast<const float4*>(src + off);
     if (nslabs > 1) {
-      for (int z = 1; z < nslabs; ++z) {
+      float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1, v3 = v1;
+      int z = 1;
+      for (; z + 2 < nslabs; z += 3) {
+        float4 a = *reinterpret_cast<const float4*>(src + (size_t)z * slab_stride + off);
+        float4 b = *reinterpret_cast<const float4*>(src + (size_t)(z + 1) * slab_stride + off);
+        float4 c = *reinterpret_cast<const float4*>(src + (size_t)(z + 2) * slab_stride + off);
+        v1.x += a.x; v1.y += a.y; v1.z += a.z; v1.w += a.w;
+        v2.x += b.x; v2.y += b.y; v2.z += b.z; v2.w += b.w;
+        v3.x += c.x; v3.y += c.y; v3.z += c.z; v3.w += c.w;
+      }
+      for (; z < nslabs; ++z) {
         float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * slab_stride + off);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
+      v.x += (v1.x + v2.x) + v3.x; v.y += (v1.y + v2.y) + v3.y; v.z += (v1.z + v2.z) + v3.z; v.w += (v1.w + v2.w) + v3.w;
       *reinterpret_cast<float4*>(y + off) = v;
     }
     s1 += (v.x + v.y) + (v.z + v.w);

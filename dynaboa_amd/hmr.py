@@ -32,6 +32,19 @@ def stream_of(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
 
+_AUX_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def aux_stream_of(t: torch.Tensor):
+    """A per-device side stream for the engine's weight-gradient convolutions (None on host buffers)."""
+    if not t.is_cuda:
+        return None
+    key = str(t.device)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=t.device)
+    return _AUX_STREAMS[key].cuda_stream
+
+
 def get_layout(batch: int, height: int = 224, width: int = 224) -> HmrLayout:
     key = (batch, height, width)
     if key not in _LAYOUTS:
@@ -101,7 +114,8 @@ class _HMRFunction(torch.autograd.Function):
         grads = torch.zeros(L.n_params, dtype=torch.float32, device=theta.device)
         ws = get_workspace(L, theta.device)
         check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot.data_ptr(), d_state.data_ptr(),
-                                   ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)),
+                                   ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta),
+                                   aux_stream_of(theta)),
               "dyb_hmr_backward")
         return grads, None, None, None, None
 

@@ -133,8 +133,10 @@ long long dyb_hmr_act_offset_rotmat(const void* plan); /* [B][24][9] */
 long long dyb_hmr_act_offset_state(const void* plan);  /* [B][160] pose|shape|cam|pad */
 int dyb_hmr_forward(const void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
                     float* acts, void* ws, size_t ws_bytes, dyb_stream_t stream);
-int dyb_hmr_backward(const void* plan, const float* params, const float* acts, const float* d_rotmat,
-                     const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes, dyb_stream_t stream);
+/* aux_stream (may be NULL): second stream for the weight-gradient convolutions, which are off the
+ * critical path; `stream` waits for them before the call returns control of ordering. */
+int dyb_hmr_backward(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
+                     int n_iter, float* grads, void* ws, size_t ws_bytes, dyb_stream_t stream, dyb_stream_t aux_stream);
 
 #ifdef __cplusplus
 }

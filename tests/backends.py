@@ -49,6 +49,9 @@ class EmuBackend:
     def sync(self):
         pass
 
+    def aux_stream(self):
+        return None
+
 
 class GpuBackend:
     name = "gpu"
@@ -96,3 +99,8 @@ class GpuBackend:
 
     def sync(self):
         self.torch.cuda.synchronize()
+
+    def aux_stream(self):
+        if not hasattr(self, "_aux"):
+            self._aux = self.torch.cuda.Stream()
+        return self._aux.cuda_stream

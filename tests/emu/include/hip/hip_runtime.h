@@ -54,6 +54,13 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, siz
   return hipSuccess;
 }
 
+typedef void* hipEvent_t;
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+
 namespace emu {
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void syncthreads();

@@ -407,7 +407,7 @@ def case_hmr_engine(be, golden, ckpt, check_grads=True):
     d_state[:, 154:157] = g["wc"]
     grads = be.zeros((L.n_params,))
     check(be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(be.dev(g["wr"])), be.ptr(be.dev(d_state)), 3,
-                                  be.ptr(grads), be.ptr(ws), L.ws_bytes, be.stream), "hmr backward")
+                                  be.ptr(grads), be.ptr(ws), L.ws_bytes, be.stream, be.aux_stream()), "hmr backward")
     G = L.unpack(torch.from_numpy(be.host(grads)))
     names = [str(n) for n in g["grad_names"]]
     norms = np.array([float(G[n].double().norm()) for n in names])

@@ -16,7 +16,10 @@ for s in $STAGES; do
     bench) timeout 900 python bench.py --steps 40 --warmup 8 > $OUT/bench.json 2> $OUT/bench.err ;;
     benchmin) timeout 600 python bench.py --steps 40 --warmup 8 --schedule minimal --no_cpu_baseline > $OUT/bench_min.json 2> $OUT/bench_min.err ;;
     prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline) > $OUT/prof.log 2>&1
-           find $OUT/prof -name "*stats*" | head -5 >> $OUT/prof.log ;;
+           find $OUT/prof -name "*stats*" | head -5 >> $OUT/prof.log
+           python tools/trace_analyze.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) $OUT/trace_summary.json > $OUT/trace_summary.txt 2>&1
+           rm -f $(find $OUT/prof -name "*kernel_trace.csv") ;;
+    micro) timeout 300 python tools/microbench.py 1 > $OUT/microbench.log 2>&1 ;;
   esac
   echo "stage $s done rc=$?" >> $OUT/stages.log
 done
