@@ -10,8 +10,8 @@
 //              optionally folds the split-K slabs left by the convolution and writes y.
 //   gn_apply : every workgroup re-reduces the (<= few hundred) partials in double, then
 //              out = relu?((y-mean)*rstd*gamma + beta (+ residual)); saves mean/rstd.
-//   backward : gn_bwd_reduce (per-channel sums of dy and dy*xhat) -> gn_bwd_finalize (dgamma,
-//              dbeta, per-group coefficients) -> gn_bwd_apply (dx, and the residual-edge gradient).
+//   backward : gn_bwd_reduce (per-channel sums of dy and dy*xhat + per-group gamma-weighted sums)
+//              -> gn_bwd_apply (coefficients, dx, the residual-edge gradient, dgamma/dbeta).
 #include "dyb_common.h"
 
 #define G DYB_GN_GROUPS
@@ -155,7 +155,7 @@ extern "C" size_t dyb_groupnorm_workspace_bytes(int N, int HW, int C) {
   // forward partials [N][nchunks][G][2]; backward partials [N][nchunks][2][C] + coef [N][G][2]
   size_t nch = (size_t)gn_chunks(HW, N), nchb = (size_t)gn_chunks_bwd(HW, N, C);
   size_t fwd = (size_t)N * nch * G * 2;
-  size_t bwd = (size_t)N * nchb * 2 * C + (size_t)N * G * 2;
+  size_t bwd = (size_t)N * nchb * 2 * C + (size_t)N * nchb * 2 * G * 2;      // + gpart (<= 2 column blocks)
   return (fwd > bwd ? fwd : bwd) * sizeof(float);
 }
 
@@ -187,19 +187,28 @@ extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const
 }
 
 // ------------------------------------------------------------------------------------------
-// backward
+// backward  (two launches)
+//   gn_bwd_reduce : per (image, chunk of rows) per-channel sums A_c = sum dy, B_c = sum dy*xhat
+//                   -> partials [n][chunk][2][C], and per-group sums of gamma*A, gamma*B over the
+//                   workgroup's channel span -> gpart [n][chunk][colblock][G][2]
+//   gn_bwd_apply  : every workgroup folds gpart (<= 32 chunks x <= 2 column blocks) into the two
+//                   per-group coefficients, then dx = rstd*(gamma*dy - c1 - xhat*c2); the first
+//                   ceil(C/256) workgroups also fold the per-channel partials into dgamma / dbeta.
 // ------------------------------------------------------------------------------------------
-// grid (CQ/TX, nchunks, N), block 256 = TX x TY.  partial layout [n][chunk][2][C].
+// grid (CQ/TX, nchunks, N), block 256 = TX x TY
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             const float* __restrict__ y, const float* __restrict__ stats,
-                                                            float* __restrict__ partials, int HW, int C,
-                                                            int rows_per_chunk, int relu, int TX) {
+                                                            const float* __restrict__ gamma, float* __restrict__ partials,
+                                                            float* __restrict__ gpart, int HW, int C, int rows_per_chunk,
+                                                            int relu, int TX) {
   __shared__ float sm[256 * 8];
+  __shared__ float sg[256][2];
   const int n = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cq = blockIdx.x * TX + tx;
-  const int g = (cq * 4) / (C / G);
+  const int cqg = C >> 4;
+  const int g = cq / cqg;
   const float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
   const int row0 = chunk * rows_per_chunk;
   int row1 = row0 + rows_per_chunk;
@@ -231,99 +240,89 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     float* p = partials + ((size_t)n * nchunks + chunk) * 2 * C + (size_t)cq * 4;
     *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
     *reinterpret_cast<float4*>(p + C) = make_float4(b[0], b[1], b[2], b[3]);
+    float4 ga = *reinterpret_cast<const float4*>(gamma + (size_t)cq * 4);
+    sg[tx][0] = (ga.x * a[0] + ga.y * a[1]) + (ga.z * a[2] + ga.w * a[3]);
+    sg[tx][1] = (ga.x * b[0] + ga.y * b[1]) + (ga.z * b[2] + ga.w * b[3]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * G) {
+    // group q's channel-quads inside this workgroup's span [blockIdx.x*TX, +TX)
+    const int q = threadIdx.x >> 1, which = threadIdx.x & 1;
+    int lo = q * cqg - blockIdx.x * TX, hi = lo + cqg;
+    if (lo < 0) lo = 0;
+    if (hi > TX) hi = TX;
+    float s = 0.f;
+    for (int t = lo; t < hi; ++t) s += sg[t][which];
+    gpart[((((size_t)n * nchunks + chunk) * gridDim.x + blockIdx.x) * G + q) * 2 + which] = s;
   }
 }
 
-// one workgroup per group g (grid = 4).  dgamma[c] = sum_n B, dbeta[c] = sum_n A;
-// coef[n][g] = (S1/m, S2/m) with S1 = sum_{c in g} gamma_c A_nc, S2 likewise with B.
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nchunks,
-                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef, int N,
-                                                              int HW, int C) {
-  __shared__ float red[4][2];
-  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int cg = C / G;                       // <= 512 channels per group -> at most 2 per thread
-  float gam[2], dg[2], db[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int cl = tid + 256 * k;
-    gam[k] = cl < cg ? gamma[g * cg + cl] : 0.f;
-    dg[k] = 0.f;
-    db[k] = 0.f;
-  }
-  const float inv_m = 1.0f / ((float)cg * (float)HW);
-  for (int n = 0; n < N; ++n) {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      int cl = tid + 256 * k;
-      if (cl < cg) {
-        const float* p = partials + (size_t)n * nchunks * 2 * C + (g * cg + cl);
-        float A0 = 0.f, A1 = 0.f, B0 = 0.f, B1 = 0.f;
-        int ch = 0;
-        for (; ch + 1 < nchunks; ch += 2) {
-          A0 += p[(size_t)ch * 2 * C];
-          B0 += p[(size_t)ch * 2 * C + C];
-          A1 += p[(size_t)(ch + 1) * 2 * C];
-          B1 += p[(size_t)(ch + 1) * 2 * C + C];
-        }
-        if (ch < nchunks) {
-          A0 += p[(size_t)ch * 2 * C];
-          B0 += p[(size_t)ch * 2 * C + C];
-        }
-        float A = A0 + A1, B = B0 + B1;
-        db[k] += A;
-        dg[k] += B;
-        s1 += gam[k] * A;
-        s2 += gam[k] * B;
-      }
-    }
-    s1 = dyb_wave_sum(s1);
-    s2 = dyb_wave_sum(s2);
-    __syncthreads();
-    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
-    __syncthreads();
-    if (tid < 2) coef[((size_t)n * G + g) * 2 + tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * inv_m;
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int cl = tid + 256 * k;
-    if (cl < cg) {
-      dgamma[g * cg + cl] = dg[k];
-      dbeta[g * cg + cl] = db[k];
-    }
-  }
-}
-
-// grid-stride elementwise over [N][HW][C]
+// grid-stride elementwise over [N][HW][C]; workgroups [0, ceil(C/256)) also write dgamma/dbeta
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ y, const float* __restrict__ stats,
-                                                           const float* __restrict__ coef, const float* __restrict__ gamma,
-                                                           float* __restrict__ dy, float* __restrict__ dres, int N, int HW,
+                                                           const float* __restrict__ partials, const float* __restrict__ gpart,
+                                                           int nchunks, int ncolb, const float* __restrict__ gamma,
+                                                           float* __restrict__ dy, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int HW,
                                                            int C, int relu) {
+  __shared__ float s_coef[16 * G * 2];          // N <= 16 per call path; larger N handled in slices below
   const int CQ = C >> 2, cqg = C >> 4;
-  const size_t per = (size_t)HW * CQ, total = (size_t)N * per;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int n = (int)(i / per);
-    int cq = (int)(i % CQ);
-    int g = cq / cqg;
-    float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
-    float c1 = coef[((size_t)n * G + g) * 2], c2 = coef[((size_t)n * G + g) * 2 + 1];
-    float4 d = *reinterpret_cast<const float4*>(dout + i * 4);
-    float4 v = *reinterpret_cast<const float4*>(y + i * 4);
-    float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
-    if (relu) {
-      float4 o = *reinterpret_cast<const float4*>(out + i * 4);
-      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
-      d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+  const float inv_m = 1.0f / ((float)(C / G) * (float)HW);
+  // dgamma / dbeta: channel c = blockIdx.x*256 + tid
+  {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 < C && c < C) {
+      float A = 0.f, B = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float* p = partials + (size_t)n * nchunks * 2 * C + c;
+        int ch = 0;
+        for (; ch + 3 < nchunks; ch += 4) {
+          float a0 = p[(size_t)ch * 2 * C], a1 = p[(size_t)(ch + 1) * 2 * C], a2 = p[(size_t)(ch + 2) * 2 * C], a3 = p[(size_t)(ch + 3) * 2 * C];
+          float b0 = p[(size_t)ch * 2 * C + C], b1 = p[(size_t)(ch + 1) * 2 * C + C], b2 = p[(size_t)(ch + 2) * 2 * C + C], b3 = p[(size_t)(ch + 3) * 2 * C + C];
+          A += (a0 + a1) + (a2 + a3);
+          B += (b0 + b1) + (b2 + b3);
+        }
+        for (; ch < nchunks; ++ch) { A += p[(size_t)ch * 2 * C]; B += p[(size_t)ch * 2 * C + C]; }
+      }
+      dbeta[c] = A;
+      dgamma[c] = B;
     }
-    if (dres) *reinterpret_cast<float4*>(dres + i * 4) = d;
-    float4 r;
-    r.x = rstd * (ga.x * d.x - c1 - ((v.x - mean) * rstd) * c2);
-    r.y = rstd * (ga.y * d.y - c1 - ((v.y - mean) * rstd) * c2);
-    r.z = rstd * (ga.z * d.z - c1 - ((v.z - mean) * rstd) * c2);
-    r.w = rstd * (ga.w * d.w - c1 - ((v.w - mean) * rstd) * c2);
-    *reinterpret_cast<float4*>(dy + i * 4) = r;
+  }
+  const size_t per = (size_t)HW * CQ, total = (size_t)N * per;
+  for (int n0 = 0; n0 < N; n0 += 16) {
+    const int nn = (N - n0) < 16 ? (N - n0) : 16;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nn * G * 2; e += 256) {
+      int n = n0 + e / (G * 2), q = (e / 2) % G, which = e & 1;
+      const float* gp = gpart + (size_t)n * nchunks * ncolb * G * 2 + q * 2 + which;
+      float s = 0.f;
+      for (int k = 0; k < nchunks * ncolb; ++k) s += gp[(size_t)k * G * 2];
+      s_coef[e] = s * inv_m;
+    }
+    __syncthreads();
+    const size_t lo = (size_t)n0 * per, hi = (size_t)(n0 + nn) * per;
+    for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi && i < total; i += (size_t)gridDim.x * 256) {
+      int n = (int)(i / per);
+      int cq = (int)(i % CQ);
+      int g = cq / cqg;
+      float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+      float c1 = s_coef[((n - n0) * G + g) * 2], c2 = s_coef[((n - n0) * G + g) * 2 + 1];
+      float4 d = *reinterpret_cast<const float4*>(dout + i * 4);
+      float4 v = *reinterpret_cast<const float4*>(y + i * 4);
+      float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+      if (relu) {
+        float4 o = *reinterpret_cast<const float4*>(out + i * 4);
+        d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
+        d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+      }
+      if (dres) *reinterpret_cast<float4*>(dres + i * 4) = d;
+      float4 r;
+      r.x = rstd * (ga.x * d.x - c1 - ((v.x - mean) * rstd) * c2);
+      r.y = rstd * (ga.y * d.y - c1 - ((v.y - mean) * rstd) * c2);
+      r.z = rstd * (ga.z * d.z - c1 - ((v.z - mean) * rstd) * c2);
+      r.w = rstd * (ga.w * d.w - c1 - ((v.w - mean) * rstd) * c2);
+      *reinterpret_cast<float4*>(dy + i * 4) = r;
+    }
   }
 }
 
@@ -337,25 +336,24 @@ extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const floa
   DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   int nch = gn_chunks_bwd(HW, N, C);
-  size_t need = ((size_t)N * nch * 2 * C + (size_t)N * G * 2) * sizeof(float);
+  int CQ = C / 4;
+  int TX = CQ < 256 ? CQ : 256;
+  int ncolb = CQ / TX;
+  size_t need = ((size_t)N * nch * 2 * C + (size_t)N * nch * ncolb * G * 2) * sizeof(float);
   DYB_REQUIRE(ws_bytes >= need, DYB_ERR_WORKSPACE);
   int rows = dyb_cdiv(HW, nch);
   float* partials = reinterpret_cast<float*>(ws);
-  float* coef = partials + (size_t)N * nch * 2 * C;
-  int CQ = C / 4;
-  int TX = CQ < 256 ? CQ : 256;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(CQ / TX, nch, N), dim3(256), 0, st, dout, out, y, stats, partials, HW,
-                     C, rows, relu, TX);
-  DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, st, (const float*)partials, nch, gamma, dgamma,
-                     dbeta, coef, N, HW, C);
+  float* gpart = partials + (size_t)N * nch * 2 * C;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, out, y, stats, gamma, partials,
+                     gpart, HW, C, rows, relu, TX);
   DYB_CHECK_LAUNCH();
   size_t total4 = (size_t)N * HW * CQ;
   int blocks = (int)((total4 + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, stats, (const float*)coef, gamma,
-                     dy, dres, N, HW, C, relu);
+  int minb = dyb_cdiv(C, 256);
+  if (blocks < minb) blocks = minb;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, stats, (const float*)partials,
+                     (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

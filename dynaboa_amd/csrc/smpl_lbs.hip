@@ -10,13 +10,15 @@
 //              24x6890 joint regressor is folded into two small tables on the host, exact up to
 //              fp32 re-association), pose feature R[1:]-I, the 24-step kinematic chain run
 //              12 lanes wide, skinning transforms A = [G_R | G_t - G_R J].
-//   lbs_skin   (256 vertices / workgroup): A, pose feature and betas staged in LDS; per vertex
-//              blend shapes (10), pose correctives (207 coalesced row segments of posedirs),
-//              blended transform from the transposed skin-weight table, output vertex; wave
-//              butterfly partial sums of the 9 regressed extra joints.
+//   lbs_skin   (64 vertices / workgroup, 4 waves): A, pose feature and betas staged in LDS; the 207
+//              pose-corrective rows of posedirs (coalesced segments) are split over the 4 waves
+//              and folded through LDS; wave 0 adds blend shapes (10), blends the transform from
+//              the transposed skin-weight table, writes the vertex and wave-butterfly partial
+//              sums of the 9 regressed extra joints.
 //   lbs_joints (1 workgroup / sample): fold partials, gather the 49 output joints.
 // Backward mirrors it: scatter d_joints49 -> 54 sources; per-vertex sweep producing partial
-// reductions of dA (288), d pose-feature (207), d beta (10); chain backward 12 lanes wide.
+// reductions of dA (288), d pose-feature (207), d beta (10) through a 63-shuffle transpose-reduce
+// per 64 quantities; chain backward 12 lanes wide.
 #include "dyb_common.h"
 
 #define NV 6890
@@ -28,8 +30,9 @@
 #define NVJ 21
 #define NJ54 54
 #define NJ49 49
-#define LBS_VB 256
-#define LBS_NBLK ((NV + LBS_VB - 1) / LBS_VB)   // 27
+#define LBS_VB 64                               // vertices per workgroup
+#define LBS_NBLK ((NV + LBS_VB - 1) / LBS_VB)   // 108
+#define LBS_PQ 52                               // pose-corrective rows per wave (4 waves cover 207)
 #define NRED (NJ * 12 + NPF + NB)               // 505 partial reductions per workgroup
 
 struct SmplTables {
@@ -177,19 +180,48 @@ __global__ __launch_bounds__(128) void lbs_pose_kernel(SmplTables T, const float
   }
 }
 
-__global__ __launch_bounds__(LBS_VB) void lbs_skin_kernel(SmplTables T, const float* __restrict__ betas, int ldb,
-                                                          const float* __restrict__ A, const float* __restrict__ pf,
-                                                          float* __restrict__ verts, float* __restrict__ vposed,
-                                                          float* __restrict__ extra_part) {
-  __shared__ float sA[NJ * 12], sPf[NPF_PAD], sBe[NB], sRed[4][NEXTRA * 3];
+// grid (108, B), block 256 = 4 waves x 64 vertices.  The 207-row pose-corrective sum (the only
+// real traffic: posedirs, 17.1 MB) is split over the 4 waves and folded through LDS; wave 0 then
+// finishes the vertex (blend shapes, blended transform, output, extra-joint partial sums).
+__global__ __launch_bounds__(256) void lbs_skin_kernel(SmplTables T, const float* __restrict__ betas, int ldb,
+                                                       const float* __restrict__ A, const float* __restrict__ pf,
+                                                       float* __restrict__ verts, float* __restrict__ vposed,
+                                                       float* __restrict__ extra_part) {
+  __shared__ float sA[NJ * 12], sPf[NPF_PAD], sBe[NB], sPart[4][LBS_VB][3];
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < NJ * 12; i += LBS_VB) sA[i] = A[(size_t)b * NJ * 12 + i];
-  for (int i = t; i < NPF_PAD; i += LBS_VB) sPf[i] = pf[(size_t)b * NPF_PAD + i];
+  for (int i = t; i < NJ * 12; i += 256) sA[i] = A[(size_t)b * NJ * 12 + i];
+  for (int i = t; i < NPF_PAD; i += 256) sPf[i] = pf[(size_t)b * NPF_PAD + i];
   if (t < NB) sBe[t] = betas[(size_t)b * ldb + t];
   __syncthreads();
-  const int v = blockIdx.x * LBS_VB + t;
+  const int v = blockIdx.x * LBS_VB + lane;
   const bool live = v < NV;
   const int vv = live ? v : 0;
+  {
+    const float* pd = T.posedirs + (size_t)vv * 3;
+    const int p0i = wave * LBS_PQ;
+    int p1i = p0i + LBS_PQ;
+    if (p1i > NPF) p1i = NPF;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    int p = p0i;
+    for (; p + 1 < p1i; p += 2) {
+      const float* ra = pd + (size_t)p * (NV * 3);
+      const float* rb = ra + (NV * 3);
+      float fa = sPf[p], fb = sPf[p + 1];
+      float a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+      q0 += fa * a0; q1 += fa * a1; q2 += fa * a2;
+      r0 += fb * b0; r1 += fb * b1; r2 += fb * b2;
+    }
+    if (p < p1i) {
+      const float* ra = pd + (size_t)p * (NV * 3);
+      float fa = sPf[p];
+      q0 += fa * ra[0]; q1 += fa * ra[1]; q2 += fa * ra[2];
+    }
+    sPart[wave][lane][0] = q0 + r0;
+    sPart[wave][lane][1] = q1 + r1;
+    sPart[wave][lane][2] = q2 + r2;
+  }
+  __syncthreads();
+  if (wave != 0) return;
   float vp[3], out[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -197,19 +229,7 @@ __global__ __launch_bounds__(LBS_VB) void lbs_skin_kernel(SmplTables T, const fl
     const float* sd = T.shapedirs + (size_t)(vv * 3 + c) * NB;
 #pragma unroll
     for (int l = 0; l < NB; ++l) s += sd[l] * sBe[l];
-    vp[c] = s;
-  }
-  {
-    const float* pd = T.posedirs + (size_t)vv * 3;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    for (int p = 0; p < NPF; ++p) {
-      float f = sPf[p];
-      const float* row = pd + (size_t)p * (NV * 3);
-      p0 += f * row[0];
-      p1 += f * row[1];
-      p2 += f * row[2];
-    }
-    vp[0] += p0; vp[1] += p1; vp[2] += p2;
+    vp[c] = s + ((sPart[0][lane][c] + sPart[1][lane][c]) + (sPart[2][lane][c] + sPart[3][lane][c]));
   }
   float Tm[12];
 #pragma unroll
@@ -226,17 +246,15 @@ __global__ __launch_bounds__(LBS_VB) void lbs_skin_kernel(SmplTables T, const fl
     verts[o] = out[0]; verts[o + 1] = out[1]; verts[o + 2] = out[2];
     vposed[o] = vp[0]; vposed[o + 1] = vp[1]; vposed[o + 2] = vp[2];
   }
+  float* ep = extra_part + ((size_t)b * LBS_NBLK + blockIdx.x) * (NEXTRA * 3);
   for (int e = 0; e < NEXTRA; ++e) {
     float x = live ? T.j_extra[(size_t)e * NV + v] : 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float s = dyb_wave_sum(x * out[c]);
-      if (lane == 0) sRed[wave][e * 3 + c] = s;
+      if (lane == 0) ep[e * 3 + c] = s;
     }
   }
-  __syncthreads();
-  if (t < NEXTRA * 3)
-    extra_part[((size_t)b * LBS_NBLK + blockIdx.x) * (NEXTRA * 3) + t] = (sRed[0][t] + sRed[1][t]) + (sRed[2][t] + sRed[3][t]);
 }
 
 __global__ __launch_bounds__(64) void lbs_joints_kernel(SmplTables T, const float* __restrict__ extra_part,
@@ -300,7 +318,7 @@ extern "C" int dyb_lbs_fwd(const float* const* tables_f, const int* const* table
   LbsSaved s = carve_saved(saved, B);
   hipLaunchKernelGGL(lbs_pose_kernel, dim3(B), dim3(128), 0, st, T, betas, ldb, rotmat, s.A, s.Jp, s.J, s.pf);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_skin_kernel, dim3(LBS_NBLK, B), dim3(LBS_VB), 0, st, T, betas, ldb, (const float*)s.A,
+  hipLaunchKernelGGL(lbs_skin_kernel, dim3(LBS_NBLK, B), dim3(256), 0, st, T, betas, ldb, (const float*)s.A,
                      (const float*)s.pf, verts, s.vposed, s.extra_part);
   DYB_CHECK_LAUNCH();
   hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(64), 0, st, T, (const float*)s.extra_part, (const float*)s.Jp,
@@ -327,18 +345,95 @@ __global__ __launch_bounds__(64) void lbs_bwd_scatter_kernel(SmplTables T, const
   o[0] = s0; o[1] = s1; o[2] = s2;
 }
 
-__global__ __launch_bounds__(LBS_VB) void lbs_bwd_skin_kernel(SmplTables T, const float* __restrict__ A,
-                                                              const float* __restrict__ vposed,
-                                                              const float* __restrict__ dverts,
-                                                              const float* __restrict__ dj54, float* __restrict__ part) {
-  __shared__ float sA[NJ * 12], sDj[NJ54 * 3], sW[4][NRED];
+// Sum 64 per-lane quantities across the 64 lanes of a wave with 63 shuffles (a butterfly that
+// halves the live quantities at every stage) instead of 64 x 6: on return lane l holds the
+// wave-wide sum of quantity l.
+__device__ __forceinline__ float transpose_reduce64(float (&v)[64], int lane) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    bool up = (lane & 32) != 0;
+    float send = up ? v[i] : v[i + 32], keep = up ? v[i + 32] : v[i];
+    v[i] = keep + __shfl_xor(send, 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    bool up = (lane & 16) != 0;
+    float send = up ? v[i] : v[i + 16], keep = up ? v[i + 16] : v[i];
+    v[i] = keep + __shfl_xor(send, 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    bool up = (lane & 8) != 0;
+    float send = up ? v[i] : v[i + 8], keep = up ? v[i + 8] : v[i];
+    v[i] = keep + __shfl_xor(send, 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bool up = (lane & 4) != 0;
+    float send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
+    v[i] = keep + __shfl_xor(send, 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    bool up = (lane & 2) != 0;
+    float send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
+    v[i] = keep + __shfl_xor(send, 2);
+  }
+  {
+    bool up = (lane & 1) != 0;
+    float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+    v[0] = keep + __shfl_xor(send, 1);
+  }
+  return v[0];
+}
+
+// quantities [BASE, BASE+64) of the dA block: q = j*12 + r*4 + c  ->  w_j * dv[r] * (c < 3 ? vp[c] : 1)
+template <int BASE>
+__device__ __forceinline__ void fill_dA(float (&vals)[64], const float (&w)[NJ], const float (&dv)[3], const float (&vp)[3]) {
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int q = BASE + i;
+    if (q < NJ * 12) {
+      const int j = q / 12, r = (q % 12) / 4, c = q % 4;
+      vals[i] = w[j] * dv[r] * (c < 3 ? vp[c] : 1.f);
+    } else {
+      vals[i] = 0.f;
+    }
+  }
+}
+// quantities [BASE, BASE+64) of the [207 pose-feature | 10 beta] block
+template <int BASE>
+__device__ __forceinline__ void fill_dpf(float (&vals)[64], const float* __restrict__ pd, const float* __restrict__ sd,
+                                         const float (&dvp)[3], bool live) {
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int q = BASE + i;
+    float x = 0.f;
+    if (q < NPF) {
+      const float* row = pd + (size_t)q * (NV * 3);
+      if (live) x = row[0] * dvp[0] + row[1] * dvp[1] + row[2] * dvp[2];
+    } else if (q < NPF + NB) {
+      const int l = q - NPF;
+      if (live) x = sd[l] * dvp[0] + sd[NB + l] * dvp[1] + sd[2 * NB + l] * dvp[2];
+    }
+    vals[i] = x;
+  }
+}
+
+// grid (108, B), block 64 (one wave, one vertex per lane).  Per-workgroup partial sums, layout
+// [0,288) dA, [288,495) d pose-feature, [495,505) d beta.
+__global__ __launch_bounds__(64) void lbs_bwd_skin_kernel(SmplTables T, const float* __restrict__ A,
+                                                          const float* __restrict__ vposed,
+                                                          const float* __restrict__ dverts,
+                                                          const float* __restrict__ dj54, float* __restrict__ part) {
+  __shared__ float sA[NJ * 12], sDj[NJ54 * 3];
   __shared__ int sVj[NVJ];
-  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < NJ * 12; i += LBS_VB) sA[i] = A[(size_t)b * NJ * 12 + i];
-  for (int i = t; i < NJ54 * 3; i += LBS_VB) sDj[i] = dj54[(size_t)b * NJ54 * 3 + i];
-  if (t < NVJ) sVj[t] = T.vertex_joint_ids[t];
+  const int b = blockIdx.y, lane = threadIdx.x;
+  for (int i = lane; i < NJ * 12; i += 64) sA[i] = A[(size_t)b * NJ * 12 + i];
+  for (int i = lane; i < NJ54 * 3; i += 64) sDj[i] = dj54[(size_t)b * NJ54 * 3 + i];
+  if (lane < NVJ) sVj[lane] = T.vertex_joint_ids[lane];
   __syncthreads();
-  const int v = blockIdx.x * LBS_VB + t;
+  const int v = blockIdx.x * LBS_VB + lane;
   const bool live = v < NV;
   const int vv = live ? v : 0;
   float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
@@ -360,54 +455,37 @@ __global__ __launch_bounds__(LBS_VB) void lbs_bwd_skin_kernel(SmplTables T, cons
       }
     }
   }
-  // blended rotation, then d v_posed = T_R^T dv
+  float w[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) w[j] = live ? T.weights_t[(size_t)j * NV + vv] : 0.f;
   float TR[9];
 #pragma unroll
   for (int e = 0; e < 9; ++e) TR[e] = 0.f;
-  for (int j = 0; j < NJ; ++j) {
-    float w = T.weights_t[(size_t)j * NV + vv];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) TR[r * 3 + c] += w * sA[j * 12 + r * 4 + c];
-  }
+      for (int c = 0; c < 3; ++c) TR[r * 3 + c] += w[j] * sA[j * 12 + r * 4 + c];
   float dvp[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) dvp[c] = TR[0 * 3 + c] * dv[0] + TR[1 * 3 + c] * dv[1] + TR[2 * 3 + c] * dv[2];
-  float* mine = sW[wave];
-  // dA_j[r][c<3] += w dv[r] vp[c];  dA_j[r][3] += w dv[r]
-  for (int j = 0; j < NJ; ++j) {
-    float w = live ? T.weights_t[(size_t)j * NV + vv] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      float wd = w * dv[r];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float s = dyb_wave_sum(c < 3 ? wd * vp[c] : wd);
-        if (lane == 0) mine[j * 12 + r * 4 + c] = s;
-      }
-    }
-  }
-  {
-    const float* pd = T.posedirs + (size_t)vv * 3;
-    for (int p = 0; p < NPF; ++p) {
-      const float* row = pd + (size_t)p * (NV * 3);
-      float s = dyb_wave_sum(live ? (row[0] * dvp[0] + row[1] * dvp[1] + row[2] * dvp[2]) : 0.f);
-      if (lane == 0) mine[NJ * 12 + p] = s;
-    }
-  }
-  for (int l = 0; l < NB; ++l) {
-    float x = 0.f;
-    if (live) {
-      const float* sd = T.shapedirs + (size_t)vv * 3 * NB + l;
-      x = sd[0] * dvp[0] + sd[NB] * dvp[1] + sd[2 * NB] * dvp[2];
-    }
-    float s = dyb_wave_sum(x);
-    if (lane == 0) mine[NJ * 12 + NPF + l] = s;
-  }
-  __syncthreads();
+
   float* o = part + ((size_t)b * LBS_NBLK + blockIdx.x) * NRED;
-  for (int i = t; i < NRED; i += LBS_VB) o[i] = (sW[0][i] + sW[1][i]) + (sW[2][i] + sW[3][i]);
+  float vals[64];
+  float r;
+  fill_dA<0>(vals, w, dv, vp);   r = transpose_reduce64(vals, lane); o[lane] = r;
+  fill_dA<64>(vals, w, dv, vp);  r = transpose_reduce64(vals, lane); o[64 + lane] = r;
+  fill_dA<128>(vals, w, dv, vp); r = transpose_reduce64(vals, lane); o[128 + lane] = r;
+  fill_dA<192>(vals, w, dv, vp); r = transpose_reduce64(vals, lane); o[192 + lane] = r;
+  fill_dA<256>(vals, w, dv, vp); r = transpose_reduce64(vals, lane); if (lane < NJ * 12 - 256) o[256 + lane] = r;
+  const float* pd = T.posedirs + (size_t)vv * 3;
+  const float* sd = T.shapedirs + (size_t)vv * 3 * NB;
+  float* o2 = o + NJ * 12;
+  fill_dpf<0>(vals, pd, sd, dvp, live);   r = transpose_reduce64(vals, lane); o2[lane] = r;
+  fill_dpf<64>(vals, pd, sd, dvp, live);  r = transpose_reduce64(vals, lane); o2[64 + lane] = r;
+  fill_dpf<128>(vals, pd, sd, dvp, live); r = transpose_reduce64(vals, lane); o2[128 + lane] = r;
+  fill_dpf<192>(vals, pd, sd, dvp, live); r = transpose_reduce64(vals, lane); if (lane < NPF + NB - 192) o2[192 + lane] = r;
 }
 
 __global__ __launch_bounds__(64) void lbs_bwd_chain_kernel(SmplTables T, const float* __restrict__ part,
@@ -419,9 +497,13 @@ __global__ __launch_bounds__(64) void lbs_bwd_chain_kernel(SmplTables T, const f
   __shared__ int sPar[NJ];
   const int b = blockIdx.x, t = threadIdx.x;
   for (int i = t; i < NRED; i += 64) {
-    float s = 0.f;
-    for (int k = 0; k < LBS_NBLK; ++k) s += part[((size_t)b * LBS_NBLK + k) * NRED + i];
-    sTot[i] = s;
+    const float* pp = part + (size_t)b * LBS_NBLK * NRED + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = 0; k < LBS_NBLK; k += 4) {            // LBS_NBLK = 108 is a multiple of 4
+      float a0 = pp[(size_t)k * NRED], a1 = pp[(size_t)(k + 1) * NRED], a2 = pp[(size_t)(k + 2) * NRED], a3 = pp[(size_t)(k + 3) * NRED];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    sTot[i] = (s0 + s1) + (s2 + s3);
   }
   for (int i = t; i < NJ * 9; i += 64) {
     sR[i] = rot[(size_t)b * NJ * 9 + i];
@@ -501,7 +583,7 @@ extern "C" int dyb_lbs_bwd(const float* const* tables_f, const int* const* table
   float* part = dj54 + (size_t)B * NJ54 * 3;
   hipLaunchKernelGGL(lbs_bwd_scatter_kernel, dim3(B), dim3(64), 0, st, T, djoints49, dj54);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_bwd_skin_kernel, dim3(LBS_NBLK, B), dim3(LBS_VB), 0, st, T, (const float*)s.A,
+  hipLaunchKernelGGL(lbs_bwd_skin_kernel, dim3(LBS_NBLK, B), dim3(64), 0, st, T, (const float*)s.A,
                      (const float*)s.vposed, dverts, (const float*)dj54, part);
   DYB_CHECK_LAUNCH();
   hipLaunchKernelGGL(lbs_bwd_chain_kernel, dim3(B), dim3(64), 0, st, T, (const float*)part, (const float*)dj54, rotmat,

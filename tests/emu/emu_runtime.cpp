@@ -50,6 +50,7 @@ struct Wave {
   int alive, arrived;
   unsigned long long gen;
   unsigned char xbuf[2][64][16];
+  unsigned long long dep_gen[2][64];   // generation in which each lane last deposited (+1; 0 = never)
   float a[2][64], b[2][64];
 };
 
@@ -122,12 +123,14 @@ int lane_id() { return g_f[g_cur].lane; }
 void wave_exchange(const void* mine, void* theirs, int src_lane, int bytes) {
   Fiber& f = g_f[g_cur];
   Wave& w = g_w[f.wave];
-  int par = (int)(w.gen & 1);
+  const unsigned long long op = w.gen;
+  int par = (int)(op & 1);
   memcpy(w.xbuf[par][f.lane], mine, bytes);
+  w.dep_gen[par][f.lane] = op + 1;
   wave_sync(w);
-  int nl = g_n - f.wave * 64;
-  if (nl > 64) nl = 64;
-  int src = (src_lane >= 0 && src_lane < nl && g_f[f.wave * 64 + src_lane].state != DONE) ? src_lane : f.lane;
+  // a partner is valid iff it took part in THIS exchange (it may have finished the kernel since);
+  // lanes that never reached it (exited earlier / beyond the block) read as the caller's own value
+  int src = (src_lane >= 0 && src_lane < 64 && w.dep_gen[par][src_lane] == op + 1) ? src_lane : f.lane;
   memcpy(theirs, w.xbuf[par][src], bytes);
 }
 
@@ -187,6 +190,7 @@ void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
           g_w[w].alive = cnt > 64 ? 64 : cnt;
           g_w[w].arrived = 0;
           g_w[w].gen = 0;
+          memset(g_w[w].dep_gen, 0, sizeof(g_w[w].dep_gen));
         }
         for (int i = 0; i < n; ++i) {
           init_fiber(i);
