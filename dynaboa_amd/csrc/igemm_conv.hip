@@ -14,19 +14,20 @@
 //   dgrad : dX[m=(n,h,w)][c]         = sum_{(r,s,k)}  dY(m;(r,s,k)) * W[(r,s,c)][k]
 //   wgrad : dW[i=(r,s,c)][k]         = sum_{p=(n,ho,wo)} X(p;i) * dY[p][k]
 //
-// Tiling: 256 threads = 4 waves per workgroup, block tile 64x64, K-step 16, each wave owns one
-// 32x32 accumulator (16 VGPRs).  Operands are staged through LDS k-major ([16][64+4]) so the
+// Tiling: 256 threads = 4 waves per workgroup, block tile 64x64, K-step 32, each wave owns one
+// 32x32 accumulator (16 VGPRs).  Operands are staged through LDS k-major ([32][64+4]) so the
 // MFMA fragment read (lane -> row lane&31, k = lane>>5) is a conflict-free ds_read_b32 and the
 // "contiguous along the tile row" sources are written with one ds_write_b128.  Global loads are
-// 16 B per lane and register-prefetched one K-step ahead of the MFMAs (two LDS buffers, one
-// barrier per step).  At batch 1 most layers have only 1..50 output tiles, so the K loop is
+// 16 B per lane, four per thread per K-step (two per operand), register-prefetched one K-step
+// ahead of the 16 MFMAs of the current step (two LDS buffers, one barrier per step): at batch 1
+// the loop is load-latency-bound, so fewer, fatter steps matter more than LDS footprint.  At batch 1 most layers have only 1..50 output tiles, so the K loop is
 // split over blockIdx.z into fp32 slabs that a second kernel (or the GroupNorm statistics
 // kernel) folds - deterministic, no atomics.
 #include "dyb_common.h"
 
 #define BM 64
 #define BN 64
-#define BK 16
+#define BK 32
 #define LDS_LD (64 + 4)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
   int kt_end = kt_begin + g.tiles_per_split;
   if (kt_end > g.ktiles) kt_end = g.ktiles;
 
-  // "transposing" mapping: one tile row, 4 consecutive k          (t_row, t_kq)
-  // "direct" mapping     : one k, 4 consecutive tile columns       (d_k, d_q)
+  // Each thread moves TWO 16-byte pieces per operand per K-step (h = 0, 1):
+  // "transposing" mapping: one tile row, 4 consecutive k at k-offset t_kq + 16h      (t_row, t_kq)
+  // "direct" mapping     : k-offset d_k + 16h, 4 consecutive tile columns            (d_k, d_q)
   const int t_row = tid >> 2, t_kq = (tid & 3) * 4;
   const int d_k = tid >> 4, d_q = (tid & 15) * 4;
 
@@ -183,34 +185,34 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
   if constexpr (MODE == MODE_DGRAD) da = dg_a_row(g, m0 + t_row);
   if constexpr (MODE == MODE_WGRAD) wa = wg_a_row(g, m0 + d_q);
 
-  auto load_a = [&](int kt) -> float4 {
-    if constexpr (MODE == MODE_FWD) return fwd_a_load(g, fa, kt * BK + t_kq);
-    else if constexpr (MODE == MODE_DGRAD) return dg_a_load(g, da, kt * BK + t_kq);
-    else return wg_a_load(g, wa, kt * BK + d_k);
+  auto load_a = [&](int kt, int h) -> float4 {
+    if constexpr (MODE == MODE_FWD) return fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
+    else if constexpr (MODE == MODE_DGRAD) return dg_a_load(g, da, kt * BK + 16 * h + t_kq);
+    else return wg_a_load(g, wa, kt * BK + 16 * h + d_k);
   };
-  auto load_b = [&](int kt) -> float4 {
-    if constexpr (MODE == MODE_FWD) return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + d_k, n0 + d_q);
-    else if constexpr (MODE == MODE_DGRAD) return dg_b_load(g, n0 + t_row, kt * BK + t_kq);
-    else return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + d_k, n0 + d_q);
+  auto load_b = [&](int kt, int h) -> float4 {
+    if constexpr (MODE == MODE_FWD) return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+    else if constexpr (MODE == MODE_DGRAD) return dg_b_load(g, n0 + t_row, kt * BK + 16 * h + t_kq);
+    else return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
   };
-  auto store_a = [&](int buf, float4 v) {
+  auto store_a = [&](int buf, int h, float4 v) {
     if constexpr (MODE == MODE_WGRAD) {
-      *reinterpret_cast<float4*>(&As[buf][d_k][d_q]) = v;
+      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = v;
     } else {
-      As[buf][t_kq + 0][t_row] = v.x;
-      As[buf][t_kq + 1][t_row] = v.y;
-      As[buf][t_kq + 2][t_row] = v.z;
-      As[buf][t_kq + 3][t_row] = v.w;
+      As[buf][16 * h + t_kq + 0][t_row] = v.x;
+      As[buf][16 * h + t_kq + 1][t_row] = v.y;
+      As[buf][16 * h + t_kq + 2][t_row] = v.z;
+      As[buf][16 * h + t_kq + 3][t_row] = v.w;
     }
   };
-  auto store_b = [&](int buf, float4 v) {
+  auto store_b = [&](int buf, int h, float4 v) {
     if constexpr (MODE == MODE_DGRAD) {
-      Bs[buf][t_kq + 0][t_row] = v.x;
-      Bs[buf][t_kq + 1][t_row] = v.y;
-      Bs[buf][t_kq + 2][t_row] = v.z;
-      Bs[buf][t_kq + 3][t_row] = v.w;
+      Bs[buf][16 * h + t_kq + 0][t_row] = v.x;
+      Bs[buf][16 * h + t_kq + 1][t_row] = v.y;
+      Bs[buf][16 * h + t_kq + 2][t_row] = v.z;
+      Bs[buf][16 * h + t_kq + 3][t_row] = v.w;
     } else {
-      *reinterpret_cast<float4*>(&Bs[buf][d_k][d_q]) = v;
+      *reinterpret_cast<float4*>(&Bs[buf][16 * h + d_k][d_q]) = v;
     }
   };
 
@@ -219,17 +221,17 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   if (kt_begin < kt_end) {
-    float4 ra = load_a(kt_begin), rb = load_b(kt_begin);
-    store_a(0, ra);
-    store_b(0, rb);
+    float4 ra0 = load_a(kt_begin, 0), ra1 = load_a(kt_begin, 1), rb0 = load_b(kt_begin, 0), rb1 = load_b(kt_begin, 1);
+    store_a(0, 0, ra0); store_a(0, 1, ra1);
+    store_b(0, 0, rb0); store_b(0, 1, rb1);
     __syncthreads();
     const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const bool more = (kt + 1) < kt_end;
       if (more) {
-        ra = load_a(kt + 1);
-        rb = load_b(kt + 1);
+        ra0 = load_a(kt + 1, 0); ra1 = load_a(kt + 1, 1);
+        rb0 = load_b(kt + 1, 0); rb1 = load_b(kt + 1, 1);
       }
 #pragma unroll
       for (int k2 = 0; k2 < BK; k2 += 2) {
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
       if (more) {
-        store_a(buf ^ 1, ra);
-        store_b(buf ^ 1, rb);
+        store_a(buf ^ 1, 0, ra0); store_a(buf ^ 1, 1, ra1);
+        store_b(buf ^ 1, 0, rb0); store_b(buf ^ 1, 1, rb1);
       }
       __syncthreads();
       buf ^= 1;
@@ -313,11 +315,11 @@ static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
   return DYB_OK;
 }
 
-// Split-K policy: aim for >= ~3 workgroups per CU (768) while keeping >= 4 K-steps per split.
+// Split-K policy: aim for >= ~3 workgroups per CU (768) while keeping >= 2 K-steps (64 k) per split.
 static int choose_split(const IgemmArgs& g, size_t ws_floats) {
   int tiles = dyb_cdiv(g.M, BM) * dyb_cdiv(g.Ncols, BN);
   int want = dyb_cdiv(768, tiles);
-  int cap = g.ktiles / 4;
+  int cap = g.ktiles / 2;
   if (cap < 1) cap = 1;
   int s = want < cap ? want : cap;
   if (s < 1) s = 1;

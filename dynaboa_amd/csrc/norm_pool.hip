@@ -80,6 +80,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   __shared__ float s_mean[G], s_rstd[G];
   const int n = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int CQ = C >> 2, cqg = C >> 4;
+  const size_t total = (size_t)HW * CQ;
+  const size_t base = (size_t)n * HW * C;
+  // issue this thread's first element loads BEFORE the statistics prologue: the two memory round
+  // trips (partials, data) then overlap instead of adding up (these kernels are latency-bound)
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), ga0 = v0, be0 = v0, r0 = v0;
+  if (i0 < total) {
+    int cq = (int)(i0 % CQ);
+    v0 = *reinterpret_cast<const float4*>(y + base + i0 * 4);
+    ga0 = *reinterpret_cast<const float4*>(gamma + cq * 4);
+    be0 = *reinterpret_cast<const float4*>(beta + cq * 4);
+    if (res) r0 = *reinterpret_cast<const float4*>(res + base + i0 * 4);
+  }
   {
     double a = 0.0, b = 0.0;
     for (int ch = lane; ch < nchunks; ch += 64) {
@@ -104,25 +118,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  const int CQ = C >> 2, cqg = C >> 4;
-  const size_t total = (size_t)HW * CQ;
-  const size_t base = (size_t)n * HW * C;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     int cq = (int)(i % CQ);
     int g = cq / cqg;
     float mean = s_mean[g], rstd = s_rstd[g];
-    float4 v = *reinterpret_cast<const float4*>(y + base + i * 4);
-    float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
-    float4 be = *reinterpret_cast<const float4*>(beta + cq * 4);
+    float4 v, ga, be, r;
+    if (i == i0) {
+      v = v0; ga = ga0; be = be0; r = r0;
+    } else {
+      v = *reinterpret_cast<const float4*>(y + base + i * 4);
+      ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+      be = *reinterpret_cast<const float4*>(beta + cq * 4);
+      r = res ? *reinterpret_cast<const float4*>(res + base + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float4 o;
     o.x = (v.x - mean) * rstd * ga.x + be.x;
     o.y = (v.y - mean) * rstd * ga.y + be.y;
     o.z = (v.z - mean) * rstd * ga.z + be.z;
     o.w = (v.w - mean) * rstd * ga.w + be.w;
-    if (res) {
-      float4 r = *reinterpret_cast<const float4*>(res + base + i * 4);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-    }
+    if (res) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
@@ -288,30 +302,54 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       dgamma[c] = B;
     }
   }
+  __shared__ float s_red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t per = (size_t)HW * CQ, total = (size_t)N * per;
   for (int n0 = 0; n0 < N; n0 += 16) {
     const int nn = (N - n0) < 16 ? (N - n0) : 16;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nn * G * 2; e += 256) {
-      int n = n0 + e / (G * 2), q = (e / 2) % G, which = e & 1;
-      const float* gp = gpart + (size_t)n * nchunks * ncolb * G * 2 + q * 2 + which;
-      float s = 0.f;
-      for (int k = 0; k < nchunks * ncolb; ++k) s += gp[(size_t)k * G * 2];
-      s_coef[e] = s * inv_m;
+    const size_t lo = (size_t)n0 * per, hi = (size_t)(n0 + nn) * per;
+    // first element of this slice: loads go out before the coefficient prologue (latency overlap)
+    const size_t i0 = lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), v0 = d0, ga0 = d0, o0 = d0;
+    if (i0 < hi) {
+      d0 = *reinterpret_cast<const float4*>(dout + i0 * 4);
+      v0 = *reinterpret_cast<const float4*>(y + i0 * 4);
+      ga0 = *reinterpret_cast<const float4*>(gamma + (int)(i0 % CQ) * 4);
+      if (relu) o0 = *reinterpret_cast<const float4*>(out + i0 * 4);
+    }
+    // coefficients: all 256 threads fold the (chunk, column-block) partials, 8 values per sample
+    const int K = nchunks * ncolb;
+    for (int n = n0; n < n0 + nn; ++n) {
+      const float* gp = gpart + (size_t)n * K * G * 2 + (threadIdx.x & 7);
+      float sacc = 0.f;
+      for (int k = threadIdx.x >> 3; k < K; k += 32) sacc += gp[(size_t)k * G * 2];
+      sacc += __shfl_xor(sacc, 8);
+      sacc += __shfl_xor(sacc, 16);
+      sacc += __shfl_xor(sacc, 32);
+      __syncthreads();
+      if (lane < 8) s_red[wave][lane] = sacc;
+      __syncthreads();
+      if (threadIdx.x < 8)
+        s_coef[(n - n0) * G * 2 + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x])) * inv_m;
     }
     __syncthreads();
-    const size_t lo = (size_t)n0 * per, hi = (size_t)(n0 + nn) * per;
-    for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi && i < total; i += (size_t)gridDim.x * 256) {
+    for (size_t i = i0; i < hi; i += (size_t)gridDim.x * 256) {
       int n = (int)(i / per);
       int cq = (int)(i % CQ);
       int g = cq / cqg;
       float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
       float c1 = s_coef[((n - n0) * G + g) * 2], c2 = s_coef[((n - n0) * G + g) * 2 + 1];
-      float4 d = *reinterpret_cast<const float4*>(dout + i * 4);
-      float4 v = *reinterpret_cast<const float4*>(y + i * 4);
-      float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+      float4 d, v, ga, o;
+      if (i == i0) {
+        d = d0; v = v0; ga = ga0; o = o0;
+      } else {
+        d = *reinterpret_cast<const float4*>(dout + i * 4);
+        v = *reinterpret_cast<const float4*>(y + i * 4);
+        ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+        o = relu ? *reinterpret_cast<const float4*>(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (relu) {
-        float4 o = *reinterpret_cast<const float4*>(out + i * 4);
         d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
         d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
       }

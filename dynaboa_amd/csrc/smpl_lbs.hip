@@ -202,19 +202,21 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(SmplTables T, const float
     int p1i = p0i + LBS_PQ;
     if (p1i > NPF) p1i = NPF;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    int p = p0i;
-    for (; p + 1 < p1i; p += 2) {
-      const float* ra = pd + (size_t)p * (NV * 3);
-      const float* rb = ra + (NV * 3);
-      float fa = sPf[p], fb = sPf[p + 1];
-      float a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
-      q0 += fa * a0; q1 += fa * a1; q2 += fa * a2;
-      r0 += fb * b0; r1 += fb * b1; r2 += fb * b2;
-    }
-    if (p < p1i) {
-      const float* ra = pd + (size_t)p * (NV * 3);
-      float fa = sPf[p];
-      q0 += fa * ra[0]; q1 += fa * ra[1]; q2 += fa * ra[2];
+    // 13 rows = 39 independent loads issued before the first use: the sweep is latency-bound
+    for (int p = p0i; p < p1i; p += 13) {
+      float x[13][3];
+#pragma unroll
+      for (int u = 0; u < 13; ++u) {
+        const int pp = (p + u < p1i) ? (p + u) : p;       // clamp; weight below is 0 for the clamped rows
+        const float* ra = pd + (size_t)pp * (NV * 3);
+        x[u][0] = ra[0]; x[u][1] = ra[1]; x[u][2] = ra[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 13; ++u) {
+        const float f = (p + u < p1i) ? sPf[p + u] : 0.f;
+        if (u & 1) { r0 += f * x[u][0]; r1 += f * x[u][1]; r2 += f * x[u][2]; }
+        else { q0 += f * x[u][0]; q1 += f * x[u][1]; q2 += f * x[u][2]; }
+      }
     }
     sPart[wave][lane][0] = q0 + r0;
     sPart[wave][lane][1] = q1 + r1;
