@@ -24,8 +24,8 @@ int dyb_conv2d_nhwc_wgrad(const float*, const float*, float*, int, int, int, int
 size_t dyb_groupnorm_workspace_bytes(int, int, int);
 int dyb_groupnorm_fwd(const float*, int, float*, const float*, const float*, const float*, float*, float*, int, int, int,
                       int, void*, size_t, hipStream_t);
-int dyb_groupnorm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                      float*, int, int, int, int, void*, size_t, hipStream_t);
+int dyb_groupnorm_bwd_fold(const float*, int, size_t, const float*, float*, const float*, const float*, const float*,
+                           const float*, float*, float*, float*, float*, int, int, int, int, void*, size_t, hipStream_t);
 int dyb_nchw3_to_nhwc4(const float*, float*, int, int, int, hipStream_t);
 int dyb_maxpool3x3s2_fwd(const float*, float*, uint32_t*, int, int, int, int, hipStream_t);
 int dyb_maxpool3x3s2_bwd(const float*, const uint32_t*, float*, int, int, int, int, hipStream_t);
@@ -197,7 +197,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_lin + 4 * P.ws_grad_each + P.ws_dy + P.ws_reg;
   return pp;
 }
 
@@ -272,7 +272,7 @@ extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long l
 
 struct WsCarve {
   char *conv, *conv_aux, *gn, *lin;
-  float* g[3];
+  float* g[4];
   float* dy;
   float* reg;
 };
@@ -283,7 +283,7 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   c.conv_aux = b; b += P.ws_conv_aux;
   c.gn = b; b += P.ws_gn;
   c.lin = b; b += P.ws_lin;
-  for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
+  for (int i = 0; i < 4; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
   c.dy = reinterpret_cast<float*>(b); b += P.ws_dy;
   c.reg = reinterpret_cast<float*>(b);
   return c;
@@ -351,17 +351,28 @@ extern "C" int dyb_hmr_forward(const void* plan, const float* params, const floa
   return DYB_OK;
 }
 
-// GroupNorm backward -> d(conv output) into this layer's own dy buffer, then the two convolution
-// gradients.  The weight gradient is off the critical path (nothing downstream reads it before the
-// optimiser), so when an auxiliary stream is given it runs there, ordered by one event per layer,
-// with its own split-K slab region; the data gradient continues on the main stream.
-static int gn_conv_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
-                       const float* dout, int relu, float* dres, float* dx, const float* dx_addend, const WsCarve& w,
-                       hipStream_t st, hipStream_t aux) {
+// A gradient tensor that may still be spread over the split-K slabs of the data-gradient convolution
+// that produced it (plus an addend, the residual-edge gradient).  The next GroupNorm backward folds
+// it inside its reduce kernel, which removes one dependent launch per layer from the critical path.
+struct Pending {
+  const float* base;
+  int nslabs;
+  size_t stride;
+  const float* addend;
+};
+static Pending plain(const float* p) { return Pending{p, 1, 0, nullptr}; }
+
+// GroupNorm backward of layer ci (folding `din` into `fold_buf` when needed) -> this layer's own dy
+// buffer; then the weight gradient - off the critical path, so on the auxiliary stream when given,
+// ordered by one event per layer, with its own split-K slab region.
+static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
+                        const Pending& din, float* fold_buf, int relu, float* dres, const WsCarve& w, hipStream_t st,
+                        hipStream_t aux) {
   const ConvL& c = P.convs[ci];
   float* dy_buf = w.dy + c.dy;
-  RUN(dyb_groupnorm_bwd(dout, acts + c.out, acts + c.y, acts + c.stats, params + c.gam, dy_buf, dres, grads + c.gam,
-                        grads + c.bet, P.B, c.Ho * c.Wo, c.K, relu, w.gn, P.ws_gn, st));
+  RUN(dyb_groupnorm_bwd_fold(din.base, din.nslabs, din.stride, din.addend, fold_buf, acts + c.out, acts + c.y,
+                             acts + c.stats, params + c.gam, dy_buf, dres, grads + c.gam, grads + c.bet, P.B, c.Ho * c.Wo,
+                             c.K, relu, w.gn, P.ws_gn, st));
   if (aux) {
     if (hipEventRecord(P.ev_dy[ci], st) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(aux, P.ev_dy[ci], 0) != hipSuccess) return DYB_ERR_LAUNCH;
@@ -371,9 +382,19 @@ static int gn_conv_bwd(HmrPlan& P, int ci, const float* params, const float* act
     RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv,
                               P.ws_conv, st));
   }
-  if (dx)
-    RUN(dyb_conv2d_nhwc_dgrad(dy_buf, params + c.w, dx, dx_addend, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad,
-                              w.conv, P.ws_conv, st));
+  return DYB_OK;
+}
+// data gradient of layer ci; result either materialised in dx_buf (acc + addend) or left pending
+static int layer_dgrad(HmrPlan& P, int ci, const float* params, float* dx_buf, const float* addend, Pending* out,
+                       const WsCarve& w, hipStream_t st) {
+  const ConvL& c = P.convs[ci];
+  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
+  int ns = 1;
+  RUN(dyb_conv_dgrad_raw(d, w.dy + c.dy, params + c.w, dx_buf, addend, w.conv, P.ws_conv, out ? &ns : nullptr, st));
+  if (out) {
+    if (ns > 1) *out = Pending{reinterpret_cast<const float*>(w.conv), ns, (size_t)P.B * c.H * c.W * c.C, addend};
+    else *out = plain(dx_buf);
+  }
   return DYB_OK;
 }
 
@@ -425,32 +446,46 @@ extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* ac
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, FC1_IN_PAD, HID, grads + P.fc1_w, FC1_IN_PAD, grads + P.fc1_b, st));
   }
 
-  // ---- backbone, last block first.  Three ping-pong buffers (cur = d(block output), T2, T3) plus one
-  // dedicated d(conv output) buffer per layer (w.dy), which is what lets wgrad run asynchronously.
-  float *cur = w.g[0], *T2 = w.g[1], *T3 = w.g[2];
-  RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, cur, B, P.featHW, FEAT, st));
+  // ---- backbone, last block first.  Buffers: Ra/Rb ping-pong for the residual-edge gradient that
+  // travels between blocks as the pending gradient's addend, F = fold target, D = materialised dgrad.
+  float *Rin = nullptr, *Rfree0 = w.g[0], *Rfree1 = w.g[1], *F = w.g[2], *D = w.g[3];
+  RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, F, B, P.featHW, FEAT, st));
+  Pending cur = plain(F);     // a plain gradient needs no fold; a pending one is always folded into F
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
     const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
-    // out = relu(gn3(conv3(a2)) + res):  T2 <- d(residual edge), T3 <- d(a2)
-    RUN(gn_conv_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, 1, T2, T3, nullptr, w, st, aux));
-    // cur <- d(a1)
-    RUN(gn_conv_bwd(P, b.c2, params, acts, grads, acts + c1.out, T3, 1, nullptr, cur, nullptr, w, st, aux));
+    float* Rnew = (Rin == Rfree0) ? Rfree1 : Rfree0;          // residual-edge gradient of THIS block
+    // out = relu(gn3(conv3(a2)) + res)
+    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, F, 1, Rnew, w, st, aux));
+    Pending p3, p2, pout;
+    RUN(layer_dgrad(P, b.c3, params, D, nullptr, &p3, w, st));
+    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, p3, F, 1, nullptr, w, st, aux));
+    RUN(layer_dgrad(P, b.c2, params, D, nullptr, &p2, w, st));
+    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, p2, F, 1, nullptr, w, st, aux));
+    float* Rother = (Rnew == Rfree0) ? Rfree1 : Rfree0;       // == Rin's buffer (dead after the c3 fold) or the spare
     if (b.cd >= 0) {
-      // shortcut branch first: T3 <- dgrad_d(T2); then the main branch adds it: T2 <- dgrad_1(cur) + T3
-      RUN(gn_conv_bwd(P, b.cd, params, acts, grads, xin, T2, 0, nullptr, T3, nullptr, w, st, aux));
-      RUN(gn_conv_bwd(P, b.c1, params, acts, grads, xin, cur, 1, nullptr, T2, T3, w, st, aux));
+      // shortcut branch: GN (no ReLU) on the residual-edge gradient, data gradient materialised in Rother
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, plain(Rnew), nullptr, 0, nullptr, w, st, aux));
+      RUN(layer_dgrad(P, b.cd, params, Rother, nullptr, nullptr, w, st));
+      RUN(layer_dgrad(P, b.c1, params, D, Rother, &pout, w, st));
+      Rin = Rother;
     } else {
-      RUN(gn_conv_bwd(P, b.c1, params, acts, grads, xin, cur, 1, nullptr, T3, T2, w, st, aux));
-      float* tmp = T2; T2 = T3; T3 = tmp;
+      RUN(layer_dgrad(P, b.c1, params, D, Rnew, &pout, w, st));
+      Rin = Rnew;
     }
-    float* tmp = cur; cur = T2; T2 = tmp;          // result was in T2 -> becomes cur
+    cur = pout;
   }
-  // ---- stem: maxpool -> GN/ReLU -> conv1 (no data gradient needed for the image)
+  // ---- stem: maxpool needs the gradient materialised -> GN/ReLU -> conv1 (no data gradient for the image)
   const ConvL& stem = P.convs[0];
-  RUN(dyb_maxpool3x3s2_bwd(cur, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), T3, B, stem.Ho, stem.Wo, stem.K, st));
-  RUN(gn_conv_bwd(P, 0, params, acts, grads, acts + P.a_x4, T3, 1, nullptr, nullptr, nullptr, w, st, aux));
+  const float* gpool = cur.base;
+  if (cur.nslabs > 1 || cur.addend) {
+    RUN(dyb_splitk_fold(cur.base, cur.nslabs, (size_t)B * P.poolH * P.poolW * stem.K, cur.addend, F, st));
+    gpool = F;
+  }
+  float* gstem = (gpool == D) ? F : D;
+  RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), gstem, B, stem.Ho, stem.Wo, stem.K, st));
+  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, plain(gstem), nullptr, 1, nullptr, w, st, aux));
   if (aux) {
     if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;

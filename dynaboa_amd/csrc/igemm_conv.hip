@@ -381,6 +381,25 @@ int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y
   return run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, nslabs, st);
 }
 
+// out = sum_z slabs[z] (+ addend) over n floats (n % 4 == 0)
+int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st) {
+  size_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
+                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// data gradient that may leave `*nslabs` (>1) un-reduced split-K slabs in `ws` for the consumer (the
+// next GroupNorm backward) to fold together with `addend`; with *nslabs == 1 dx already holds
+// acc + addend.
+int dyb_conv_dgrad_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
+                       size_t ws_bytes, int* nslabs, hipStream_t st) {
+  return run_igemm(MODE_DGRAD, d, dy, w, dx, addend, ws, ws_bytes, nslabs, st);
+}
+
 extern "C" int dyb_conv2d_nhwc_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R,
                                    int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
   ConvDesc d{N, H, W, C, K, R, S, stride, pad};

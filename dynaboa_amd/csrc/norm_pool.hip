@@ -210,7 +210,12 @@ extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const
 //                   ceil(C/256) workgroups also fold the per-channel partials into dgamma / dbeta.
 // ------------------------------------------------------------------------------------------
 // grid (CQ/TX, nchunks, N), block 256 = TX x TY
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+// If nslabs > 1 or addend != NULL the incoming gradient is  sum_z dout[z*slab_stride + .] + addend[.]
+// (the un-folded split-K slabs of the data-gradient convolution that produced it, plus the
+// residual-edge gradient); it is folded here, once, and written to `folded` for the apply kernel.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, int nslabs, size_t slab_stride,
+                                                            const float* __restrict__ addend, float* __restrict__ folded,
+                                                            const float* __restrict__ out,
                                                             const float* __restrict__ y, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, float* __restrict__ partials,
                                                             float* __restrict__ gpart, int HW, int C, int rows_per_chunk,
@@ -232,6 +237,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 d = *reinterpret_cast<const float4*>(dout + off);
     float4 v = *reinterpret_cast<const float4*>(y + off);
+    if (folded) {
+      float4 d1 = make_float4(0.f, 0.f, 0.f, 0.f), d2 = d1;
+      int z = 1;
+      for (; z + 1 < nslabs; z += 2) {
+        float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
+        float4 q = *reinterpret_cast<const float4*>(dout + (size_t)(z + 1) * slab_stride + off);
+        d1.x += p.x; d1.y += p.y; d1.z += p.z; d1.w += p.w;
+        d2.x += q.x; d2.y += q.y; d2.z += q.z; d2.w += q.w;
+      }
+      if (z < nslabs) {
+        float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
+        d1.x += p.x; d1.y += p.y; d1.z += p.z; d1.w += p.w;
+      }
+      if (addend) {
+        float4 p = *reinterpret_cast<const float4*>(addend + off);
+        d2.x += p.x; d2.y += p.y; d2.z += p.z; d2.w += p.w;
+      }
+      d.x += d1.x + d2.x; d.y += d1.y + d2.y; d.z += d1.z + d2.z; d.w += d1.w + d2.w;
+      *reinterpret_cast<float4*>(folded + off) = d;
+    }
     if (relu) {
       float4 o = *reinterpret_cast<const float4*>(out + off);
       d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
@@ -367,11 +392,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // dout: gradient w.r.t. the kernel's forward output (after residual add / ReLU); out: that forward
 // output (ReLU mask); y/stats: saved conv output and (mean,rstd).  Writes dy (grad w.r.t. y),
 // dgamma, dbeta and, if dres != NULL, the gradient flowing into the residual operand.
-extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const float* y, const float* stats,
-                                 const float* gamma, float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW,
-                                 int C, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
-  DYB_REQUIRE(dout && y && stats && gamma && dy && dgamma && dbeta && ws, DYB_ERR_ARG);
+// Fold variant: the incoming gradient is sum_z dout_slabs[z] (+ addend); `folded` (required when
+// nslabs > 1 or addend) receives the sum.  `folded` may alias neither input.
+extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_t slab_stride, const float* addend,
+                                      float* folded, const float* out, const float* y, const float* stats,
+                                      const float* gamma, float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW,
+                                      int C, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(dout_slabs && y && stats && gamma && dy && dgamma && dbeta && ws, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
+  DYB_REQUIRE(nslabs >= 1, DYB_ERR_ARG);
+  const bool fold = nslabs > 1 || addend != nullptr;
+  DYB_REQUIRE(!fold || folded, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   int nch = gn_chunks_bwd(HW, N, C);
   int CQ = C / 4;
@@ -382,18 +413,25 @@ extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const floa
   int rows = dyb_cdiv(HW, nch);
   float* partials = reinterpret_cast<float*>(ws);
   float* gpart = partials + (size_t)N * nch * 2 * C;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, out, y, stats, gamma, partials,
-                     gpart, HW, C, rows, relu, TX);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout_slabs, nslabs, slab_stride, addend,
+                     fold ? folded : (float*)nullptr, out, y, stats, gamma, partials, gpart, HW, C, rows, relu, TX);
   DYB_CHECK_LAUNCH();
+  const float* dsrc = fold ? folded : dout_slabs;
   size_t total4 = (size_t)N * HW * CQ;
   int blocks = (int)((total4 + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
   int minb = dyb_cdiv(C, 256);
   if (blocks < minb) blocks = minb;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, stats, (const float*)partials,
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dsrc, out, y, stats, (const float*)partials,
                      (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const float* y, const float* stats,
+                                 const float* gamma, float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW,
+                                 int C, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+  return dyb_groupnorm_bwd_fold(dout, 1, 0, nullptr, nullptr, out, y, stats, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu,
+                                ws, ws_bytes, st);
 }
 
 // ------------------------------------------------------------------------------------------

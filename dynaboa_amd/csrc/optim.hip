@@ -127,3 +127,15 @@ extern "C" int dyb_cosine_sim(const float* a, const float* b, size_t n, float ep
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+
+// Diagnostic: n dependent launches of a one-workgroup no-op kernel issued from C++ on `stream`
+// (measures the per-launch floor of a dependent kernel chain on the system; not used by the path).
+__global__ void chain_probe_kernel(float* p) {
+  if (threadIdx.x == 0) p[0] += 1.0f;
+}
+extern "C" int dyb_debug_launch_chain(float* scratch, int n, int blocks, hipStream_t st) {
+  DYB_REQUIRE(scratch && n > 0 && blocks > 0, DYB_ERR_ARG);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(chain_probe_kernel, dim3(blocks), dim3(256), 0, st, scratch);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

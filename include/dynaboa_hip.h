@@ -52,6 +52,14 @@ int dyb_groupnorm_bwd(const float* dout, const float* out, const float* y, const
                       float* dy, float* dres, float* dgamma, float* dbeta, int N, int HW, int C, int relu, void* ws,
                       size_t ws_bytes, dyb_stream_t stream);
 
+/* as dyb_groupnorm_bwd, but the incoming gradient is sum_z dout_slabs[z*slab_stride + .] (+ addend),
+ * i.e. the un-folded split-K slabs of the data-gradient convolution that produced it plus the
+ * residual-edge gradient; the sum is formed once inside the reduce kernel and written to `folded`. */
+int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_t slab_stride, const float* addend, float* folded,
+                           const float* out, const float* y, const float* stats, const float* gamma, float* dy,
+                           float* dres, float* dgamma, float* dbeta, int N, int HW, int C, int relu, void* ws,
+                           size_t ws_bytes, dyb_stream_t stream);
+
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
 int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);
@@ -115,6 +123,9 @@ int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, flo
 int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, dyb_stream_t stream);
 int dyb_axpby(const float* x, float* y, float a, float b, size_t n, dyb_stream_t stream);
 int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* out, dyb_stream_t stream);
+
+/* diagnostic: n dependent launches of a trivial kernel (per-launch floor of a kernel chain) */
+int dyb_debug_launch_chain(float* scratch, int n, int blocks, dyb_stream_t stream);
 
 /* ---- native HMR engine: HMR.forward (reference model/hmr.py:127-181) and its backward over a
  * static plan.  Parameter / activation arena layouts are queried from the plan. */

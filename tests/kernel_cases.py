@@ -422,3 +422,38 @@ def case_hmr_engine(be, golden, ckpt, check_grads=True):
             assert cosine(G[n].flatten()[:256], g[k]) > 0.9999, n
     e["grad_norm_maxrel"] = float(np.abs(norms / g["grad_norms"] - 1).max())
     return e
+
+
+def case_groupnorm_fold(be, N, HW, C, nslabs, with_addend, seed=11):
+    """dyb_groupnorm_bwd_fold == dyb_groupnorm_bwd on the pre-folded gradient."""
+    rng = _rng(seed)
+    y = (rng.standard_normal((N, HW, C)) * 1.3).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    slabs = rng.standard_normal((nslabs, N, HW, C)).astype(np.float32)
+    addend = rng.standard_normal((N, HW, C)).astype(np.float32) if with_addend else None
+    dout = slabs.sum(0) + (addend if with_addend else 0)
+    wsb = be.lib.dyb_groupnorm_workspace_bytes(N, HW, C)
+    ws = be.empty((wsb // 4,))
+    Y, OUT, ST = be.dev(y), be.empty((N, HW, C)), be.empty((N, 4, 2))
+    G_, B_ = be.dev(gamma), be.dev(beta)
+    check(be.lib.dyb_groupnorm_fwd(None, 1, be.ptr(Y), be.ptr(G_), be.ptr(B_), None, be.ptr(OUT), be.ptr(ST), N, HW, C, 1,
+                                   be.ptr(ws), wsb, be.stream), "gn fwd")
+    res = {}
+    for tag in ("ref", "fold"):
+        DY, DRES, DG, DB = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((C,)), be.empty((C,))
+        if tag == "ref":
+            check(be.lib.dyb_groupnorm_bwd(be.ptr(be.dev(dout)), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(G_), be.ptr(DY),
+                                           be.ptr(DRES), be.ptr(DG), be.ptr(DB), N, HW, C, 1, be.ptr(ws), wsb, be.stream), "bwd")
+        else:
+            FOLD = be.empty((N, HW, C))
+            check(be.lib.dyb_groupnorm_bwd_fold(be.ptr(be.dev(slabs)), nslabs, N * HW * C, be.ptr(be.dev(addend)) if with_addend else None,
+                                                be.ptr(FOLD), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(G_), be.ptr(DY), be.ptr(DRES),
+                                                be.ptr(DG), be.ptr(DB), N, HW, C, 1, be.ptr(ws), wsb, be.stream), "bwd fold")
+            res["folded"] = rel_err(be.host(FOLD), dout)
+        res[tag] = [be.host(a) for a in (DY, DRES, DG, DB)]
+    e = dict(folded=res["folded"])
+    for name, a, b in zip(("dy", "dres", "dgamma", "dbeta"), res["fold"], res["ref"]):
+        e[name] = rel_err(a, b)
+    assert max(e.values()) < 1e-5, e
+    return e

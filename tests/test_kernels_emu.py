@@ -33,6 +33,12 @@ def test_groupnorm(be, cfg):
     K.case_groupnorm(be, *cfg)
 
 
+def test_groupnorm_fold(be):
+    K.case_groupnorm_fold(be, 1, 49, 64, 5, True)
+    K.case_groupnorm_fold(be, 2, 20, 512, 2, False)
+    K.case_groupnorm_fold(be, 1, 30, 128, 1, True)
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)

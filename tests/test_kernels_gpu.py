@@ -45,6 +45,12 @@ def test_groupnorm(be, cfg):
     K.case_groupnorm(be, *cfg)
 
 
+def test_groupnorm_fold(be):
+    K.case_groupnorm_fold(be, 1, 784, 512, 4, True)
+    K.case_groupnorm_fold(be, 1, 49, 2048, 36, False)
+    K.case_groupnorm_fold(be, 2, 3136, 64, 2, True)
+
+
 def test_pools(be):
     K.case_pools(be, 2, 112, 112, 64)
     K.case_avgpool(be, 3, 49, 2048)

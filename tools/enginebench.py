@@ -50,6 +50,18 @@ def main(B=1, reps=20):
         host = (time.perf_counter() - t0) / reps * 1e3
         e1.synchronize()
         out[name] = dict(host_issue_ms=host, gpu_ms=e0.elapsed_time(e1) / reps)
+    scratch = torch.zeros(64, device=dev)
+    for blocks in (1, 256):
+        lib.dyb_debug_launch_chain(scratch.data_ptr(), 50, blocks, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        lib.dyb_debug_launch_chain(scratch.data_ptr(), 2000, blocks, st)
+        e1.record()
+        host = (time.perf_counter() - t0) * 1e3
+        e1.synchronize()
+        out[f"chain_{blocks}wg"] = dict(host_us_per_launch=host, gpu_us_per_launch=e0.elapsed_time(e1) / 2.0)
     # graph replay of the same forward / backward (what a captured frame would cost)
     try:
         s = torch.cuda.Stream()
