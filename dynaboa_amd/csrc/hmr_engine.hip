@@ -47,6 +47,10 @@ int dyb_rot6d_bwd(const float*, int, const float*, float*, int, int, hipStream_t
 #define STATE_LD 160     // pose 144 | shape 10 | cam 3 | pad 3
 #define HID 1024
 #define MAX_ITER 3
+// Folding dgrad slabs inside the next GroupNorm backward was measured SLOWER than the wide stand-alone
+// fold (2.19-2.31 ms vs 2.11 ms per backward on MI355X): the GN reduce kernel has few workgroups,
+// so extra serial loads there cost more than a launch.  1 = always materialise; the path is kept.
+#define DYB_MAX_PENDING_SLABS 1
 
 enum TensorKind { K_CONV_W = 0, K_NORM_W = 1, K_NORM_B = 2, K_FC_W = 3, K_FC_B = 4, K_DEC_W = 5, K_DEC_B = 6 };
 
@@ -211,8 +215,8 @@ extern "C" void dyb_hmr_plan_destroy(void* plan) {
   HmrPlan* P = reinterpret_cast<HmrPlan*>(plan);
   if (!P) return;
   if (P->events_ready) {
-    for (hipEvent_t e : P->ev_dy) hipEventDestroy(e);
-    hipEventDestroy(P->ev_join);
+    for (hipEvent_t e : P->ev_dy) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(P->ev_join);
   }
   delete P;
 }
@@ -392,8 +396,15 @@ static int layer_dgrad(HmrPlan& P, int ci, const float* params, float* dx_buf, c
   int ns = 1;
   RUN(dyb_conv_dgrad_raw(d, w.dy + c.dy, params + c.w, dx_buf, addend, w.conv, P.ws_conv, out ? &ns : nullptr, st));
   if (out) {
-    if (ns > 1) *out = Pending{reinterpret_cast<const float*>(w.conv), ns, (size_t)P.B * c.H * c.W * c.C, addend};
-    else *out = plain(dx_buf);
+    const size_t n = (size_t)P.B * c.H * c.W * c.C;
+    if (ns > 1 && ns <= DYB_MAX_PENDING_SLABS) {
+      *out = Pending{reinterpret_cast<const float*>(w.conv), ns, n, addend};
+    } else {
+      // many slabs: the wide stand-alone fold is cheaper than a long serial loop inside the
+      // (few-workgroup) GroupNorm reduce kernel
+      if (ns > 1) RUN(dyb_splitk_fold(reinterpret_cast<const float*>(w.conv), ns, n, addend, dx_buf, st));
+      *out = plain(dx_buf);
+    }
   }
   return DYB_OK;
 }

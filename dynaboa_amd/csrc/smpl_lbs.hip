@@ -120,6 +120,31 @@ extern "C" int dyb_rot6d_bwd(const float* x6, int ldx, const float* drotmat, flo
   return DYB_OK;
 }
 
+// axis-angle -> rotation matrix as smplx.lbs.batch_rodrigues does it (angle = ||r + 1e-8||,
+// R = I + sin K + (1-cos) K^2): the pose2rot=True path of SMPL.forward, used for the ground-truth
+// meshes of the metric path (reference dynaboa_benchmark.py:221-227,242).  No gradient needed.
+__global__ __launch_bounds__(64) void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, int n) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float x = aa[i * 3], y = aa[i * 3 + 1], z = aa[i * 3 + 2];
+  float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
+  float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+  float kx = x / ang, ky = y / ang, kz = z / ang;
+  float s = sinf(ang), c1 = 1.f - cosf(ang);
+  float* o = R + (size_t)i * 9;
+  // K = [[0,-kz,ky],[kz,0,-kx],[-ky,kx,0]];  K^2 = k k^T - |k|^2 I
+  float k2 = kx * kx + ky * ky + kz * kz;
+  o[0] = 1.f + c1 * (kx * kx - k2); o[1] = -s * kz + c1 * kx * ky;   o[2] = s * ky + c1 * kx * kz;
+  o[3] = s * kz + c1 * kx * ky;     o[4] = 1.f + c1 * (ky * ky - k2); o[5] = -s * kx + c1 * ky * kz;
+  o[6] = -s * ky + c1 * kx * kz;    o[7] = s * kx + c1 * ky * kz;     o[8] = 1.f + c1 * (kz * kz - k2);
+}
+extern "C" int dyb_rodrigues_fwd(const float* aa, float* rotmat, int n, hipStream_t st) {
+  DYB_REQUIRE(aa && rotmat && n > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(rodrigues_kernel, dim3(dyb_cdiv(n, 64)), dim3(64), 0, st, aa, rotmat, n);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // LBS forward
 // ------------------------------------------------------------------------------------------

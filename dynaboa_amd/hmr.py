@@ -92,9 +92,10 @@ class _HMRFunction(torch.autograd.Function):
                                   acts.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
         ctx.L, ctx.n_iter = L, n_iter
         ctx.save_for_backward(theta, acts)
-        rot = acts[L.off_rotmat:L.off_rotmat + B * 216].view(B, 24, 3, 3).clone()
+        # outputs are views of the activation arena (kept alive by them; nobody writes it afterwards)
+        rot = acts[L.off_rotmat:L.off_rotmat + B * 216].view(B, 24, 3, 3)
         st = acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD)
-        shape, cam = st[:, 144:154].clone(), st[:, 154:157].clone()
+        shape, cam = st[:, 144:154], st[:, 154:157]
         feats = tuple(_feature_views(L, acts, n_iter)) if need_feature else ()
         ctx.mark_non_differentiable(*feats)
         return (rot, shape, cam) + feats
@@ -180,6 +181,13 @@ class HMR(nn.Module):
     # ---- forward ---------------------------------------------------------------------------------
     def make_init_state(self, batch_size, init_pose=None, init_shape=None, init_cam=None):
         dev = self.theta.device
+        if init_pose is None and init_shape is None and init_cam is None:
+            key = (batch_size, str(dev), self.init_pose._version, self.init_shape._version, self.init_cam._version)
+            cache = self.__dict__.setdefault("_init_cache", {})
+            if key not in cache:
+                cache.clear()
+                cache[key] = self.make_init_state(batch_size, self.init_pose.expand(batch_size, -1))
+            return cache[key]
         st = torch.zeros(batch_size, STATE_LD, dtype=torch.float32, device=dev)
         st[:, :144] = self.init_pose.expand(batch_size, -1) if init_pose is None else init_pose
         st[:, 144:154] = self.init_shape.expand(batch_size, -1) if init_shape is None else init_shape

@@ -48,7 +48,8 @@ class _FrameLoss(torch.autograd.Function):
         lib = _lib.load()
         B = rotmat.shape[0]
         dev = rotmat.device
-        rotmat, shape, cam = rotmat.contiguous().float(), shape.contiguous().float(), cam.contiguous().float()
+        rows = lambda t: t.float() if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous().float()   # row stride is passed
+        rotmat, shape, cam = rotmat.contiguous().float(), rows(shape), rows(cam)
         joints, kp2d = joints.contiguous().float(), kp2d.contiguous().float()
         losses = torch.empty(4, device=dev)
         drot = torch.empty(B, 24, 3, 3, device=dev)

@@ -32,7 +32,7 @@ class _LBSFunction(torch.autograd.Function):
     def forward(ctx, betas, rot, smpl):
         lib = _lib.load()
         B = betas.shape[0]
-        betas = betas.contiguous().float()
+        betas = betas.float() if (betas.dim() == 2 and betas.stride(1) == 1) else betas.contiguous().float()
         rot = rot.contiguous().float()
         dev = betas.device
         verts = torch.empty(B, C.NUM_VERTS, 3, device=dev)
@@ -68,14 +68,13 @@ class _LBSFunction(torch.autograd.Function):
 
 
 def _rodrigues(rv: torch.Tensor) -> torch.Tensor:
-    """smplx.lbs.batch_rodrigues (angle = ||r + 1e-8||).  Only the metric path converts the ground
-    truth axis-angle pose (reference dynaboa_benchmark.py:221-227); a handful of tiny torch ops."""
-    ang = (rv + 1e-8).norm(dim=1, keepdim=True)
-    k = rv / ang
-    z = torch.zeros_like(k[:, 0])
-    K = torch.stack([z, -k[:, 2], k[:, 1], k[:, 2], z, -k[:, 0], -k[:, 1], k[:, 0], z], 1).view(-1, 3, 3)
-    s, c = ang.sin()[:, :, None], ang.cos()[:, :, None]
-    return torch.eye(3, device=rv.device, dtype=rv.dtype) + s * K + (1 - c) * (K @ K)
+    """smplx.lbs.batch_rodrigues (angle = ||r + 1e-8||) in one launch.  Only the metric path converts
+    the ground-truth axis-angle pose (reference dynaboa_benchmark.py:221-227); no gradient."""
+    rv = rv.detach().contiguous().float()
+    n = rv.shape[0]
+    R = torch.empty(n, 3, 3, device=rv.device)
+    check(_lib.load().dyb_rodrigues_fwd(rv.data_ptr(), R.data_ptr(), n, stream_of(rv)), "dyb_rodrigues_fwd")
+    return R
 
 
 class SMPL(nn.Module):

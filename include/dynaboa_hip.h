@@ -84,6 +84,8 @@ int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, const float* co
  * (rotation_matrix_to_angle_axis), forward and backward. */
 int dyb_rot6d_fwd(const float* x6, int ldx, float* rotmat, int B, dyb_stream_t stream);
 int dyb_rot6d_bwd(const float* x6, int ldx, const float* drotmat, float* dx6, int lddx, int B, dyb_stream_t stream);
+/* smplx.lbs.batch_rodrigues (pose2rot=True path of SMPL.forward; metric ground truth only) */
+int dyb_rodrigues_fwd(const float* axis_angle, float* rotmat, int n, dyb_stream_t stream);
 int dyb_rotmat_to_aa_fwd(const float* R, float* aa, int n, dyb_stream_t stream);
 int dyb_rotmat_to_aa_bwd(const float* R, const float* daa, float* dR, int n, dyb_stream_t stream);
 

@@ -211,6 +211,19 @@ def case_rot6d(be, golden):
     return e
 
 
+def case_rodrigues(be, n=200, seed=12):
+    rng = _rng(seed)
+    aa = (rng.standard_normal((n, 3)) * 0.8).astype(np.float32)
+    aa[0] = 0
+    aa[1] = [1e-5, -2e-5, 3e-6]
+    R = be.empty((n, 3, 3))
+    check(be.lib.dyb_rodrigues_fwd(be.ptr(be.dev(aa)), be.ptr(R), n, be.stream), "rodrigues")
+    ref = O.smplx_rodrigues(torch.from_numpy(aa)).numpy()
+    e = float(np.abs(be.host(R) - ref).max())
+    assert e < 2e-6, e
+    return dict(err=e)
+
+
 def case_rotmat_to_aa(be, golden):
     g = golden("g1_geometry.npz")
     R = g["rodrigues_R"]

@@ -52,6 +52,7 @@ def test_linear(be):
 def test_rotations(be):
     K.case_rot6d(be, golden)
     K.case_rotmat_to_aa(be, golden)
+    K.case_rodrigues(be)
     K.case_projection(be)
 
 
