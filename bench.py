@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--inner_step", type=int, default=3)
     ap.add_argument("--schedule", choices=["faithful", "minimal"], default="faithful")
     ap.add_argument("--full_losses", type=int, default=0, help="1: the reference's default term set (teacher+motion+exemplars+dynamic loop)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: metric / feature forwards on a side HIP stream (same results)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_baseline_only", action="store_true")
@@ -162,6 +163,7 @@ def main():
         o = DB.frame_only_options(inner_step=args.inner_step)
     o.batch_size = args.batch
     o.deferred_metrics = 1
+    o.overlap_metrics = args.overlap
     o.eval_lower = 1 if args.schedule == "faithful" else 0
     ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
     total = args.warmup + args.steps
@@ -213,9 +215,10 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
                                       "inner_step=%d + 1 outer, first-order (reference parity mode), %s; schedule=%s "
-                                      "(%d HMR forwards + %d backwards per frame)" %
+                                      "(%d HMR forwards + %d backwards per frame); metric/feature forwards %s" %
                                       (args.batch, args.inner_step, "reference default loss set" if args.full_losses else "frame losses only",
-                                       args.schedule, fwd_pf, args.inner_step + 1),
+                                       args.schedule, fwd_pf, args.inner_step + 1,
+                                       "overlapped on a side HIP stream" if args.overlap else "in line"),
                           "global_batch": args.batch * world, "parallelism": f"replicas{world} (stream sharded by sequence)",
                           "per_gpu_frames_per_s": value / world,
                           "pa_mpjpe_mm_synthetic_mean": float(np.mean(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]))) if metrics["pampjpe"] else None,

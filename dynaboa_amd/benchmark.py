@@ -63,6 +63,9 @@ parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
 parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
+parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1],
+                    help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
+                         'concurrently with the next adaptation step (same arithmetic, same results)')
 parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
                     help='run inference() after every inner step like the reference (:142)')
 
@@ -86,6 +89,41 @@ class Adaptor(BaseAdaptor):
         self.pampjpe_all_lower = [[] for _ in range(self.options.inner_step)]
         self.history, self.kp2dlosses_lower, self.kp2dlosses_upper = {}, [], {}
         self._pending = []            # deferred metric records
+        self._side, self._side_done = None, None
+        if getattr(self.options, "overlap_metrics", 0) and self.options.deferred_metrics and self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.device)
+
+    # ------------------------------------------------------------------ side-stream plumbing
+    def _on_side(self, fn, *reads):
+        """Run fn() on the side stream after everything issued so far on the current stream.
+        `reads`: tensors produced on the main stream that fn reads (kept alive for the side stream)."""
+        if self._side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        for t in reads:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            out = fn()
+            self._side_done = torch.cuda.Event()
+            self._side_done.record(self._side)
+        return out
+
+    def _join_side(self):
+        """Main stream waits for the side stream (before theta / teacher are modified in place, or
+        before side results are consumed on the main stream)."""
+        if self._side is not None and self._side_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._side_done)
+
+    @staticmethod
+    def _theta_of(model):
+        t = getattr(model, "_theta", None)
+        if t is None:
+            m = getattr(model, "module", model)
+            t = getattr(m, "theta", None)
+        return t
 
     def excute(self, frames: Optional[Iterable[Dict[str, torch.Tensor]]] = None, nframes: Optional[int] = None):
         frames = self.dataloader if frames is None else frames
@@ -115,8 +153,10 @@ class Adaptor(BaseAdaptor):
             loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, None, self.model)
             self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
             return self.inference(batch, self.model)
-        with torch.no_grad():
-            init_features = self.model(image, need_feature=True)[3]
+        def _feats():
+            with torch.no_grad():
+                return self.model(image, need_feature=True)[3]
+        init_features = self._on_side(_feats, image)
         h36m_batch = None
         learner = self.model.clone()
         for i in range(o.inner_step):
@@ -128,6 +168,7 @@ class Adaptor(BaseAdaptor):
         upper_loss, _ = self.upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
         self.optimizer.zero_grad()
         upper_loss.backward()
+        self._join_side()                       # side-stream readers of theta must be done before the in-place step
         self.optimizer.step()
         if o.use_meanteacher:
             self.update_teacher(self.teacher, self.model)
@@ -136,6 +177,7 @@ class Adaptor(BaseAdaptor):
             self.mpjpe_statistics[self.global_step] = [mpjpe]
             self.pampjpe_statistics[self.global_step] = [pampjpe]
         if o.dynamic_boa:
+            self._join_side()                   # init_features were produced on the side stream
             with torch.no_grad():
                 adapted = self.model(image, need_feature=True)[3]
                 sims = self.cal_feature_diff(init_features, adapted)
@@ -149,6 +191,7 @@ class Adaptor(BaseAdaptor):
                 upper_loss, adapted = self.upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, self.model)
                 self.optimizer.zero_grad()
                 upper_loss.backward()
+                self._join_side()
                 self.optimizer.step()
                 if o.use_meanteacher:
                     self.update_teacher(self.teacher, self.model)
@@ -175,6 +218,10 @@ class Adaptor(BaseAdaptor):
         return out[:, self.joint_mapper_h36m, :] - out[:, [0], :]
 
     def inference(self, batch, model, need_feature=False, tag=None):
+        if self._side is not None and self.options.deferred_metrics and not need_feature \
+                and torch.cuda.current_stream(self.device) != self._side:
+            reads = [self._theta_of(model)] + [v for v in batch.values() if torch.is_tensor(v)]
+            return self._on_side(lambda: self.inference(batch, model, need_feature, tag), *reads)
         image, gt_pose, gt_betas, gender = batch['image'], batch['pose'], batch['betas'], batch['gender']
         model.eval()
         with torch.no_grad():
@@ -209,6 +256,8 @@ class Adaptor(BaseAdaptor):
 
     def flush_metrics(self):
         """Resolve deferred records with one device->host transfer (and one batched SVD)."""
+        if self._side is not None:
+            self._side.synchronize()
         rec = self._pending
         self._pending = []
         if not rec:

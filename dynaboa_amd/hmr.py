@@ -53,7 +53,9 @@ def get_layout(batch: int, height: int = 224, width: int = 224) -> HmrLayout:
 
 
 def get_workspace(L: HmrLayout, device: torch.device) -> torch.Tensor:
-    key = (L.B, L.H, L.W, str(device))
+    """One engine workspace per (plan, device, stream): calls on different streams may overlap."""
+    sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (L.B, L.H, L.W, str(device), sid)
     ws = _WORKSPACES.get(key)
     if ws is None:
         ws = torch.empty(L.ws_bytes, dtype=torch.uint8, device=device)

@@ -97,6 +97,29 @@ def test_deferred_metrics_equal_immediate():
     np.testing.assert_allclose(np.concatenate(r1["mpjpe"]), np.concatenate([np.atleast_1d(x) for x in r2["mpjpe"]]), rtol=1e-5)
 
 
+def test_side_stream_overlap_changes_nothing():
+    """Metric / feature forwards on a side HIP stream: same kernels, same inputs -> identical state
+    and metrics (guards the event / allocator plumbing)."""
+    from dynaboa_amd import assets
+    frames = [assets.make_frame(s, 1, seed=22) for s in range(3)]
+    outs = []
+    for overlap in (0, 1):
+        opts, ident = STREAMS["fo_inner3_frameonly"]
+        ad, _ = make_adaptor(dict(opts, overlap_metrics=overlap), ident, deferred=1)
+        r = ad.excute(frames, nframes=3)
+        outs.append((ad.model.module.theta.detach().clone(), r))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in ("mpjpe", "pampjpe", "pve"):
+        np.testing.assert_array_equal(np.array(outs[0][1][k], dtype=np.float64).ravel(), np.array(outs[1][1][k], dtype=np.float64).ravel())
+    full, ident = STREAMS["fo_inner1_full_forced"]
+    outs = []
+    for overlap in (0, 1):
+        ad, _ = make_adaptor(dict(full, overlap_metrics=overlap), ident, deferred=1)
+        ad.excute(frames, nframes=3)
+        outs.append(ad.model.module.theta.detach().clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_state_dict_roundtrip_and_missing_extension_is_loud(tmp_path):
     from dynaboa_amd import _lib, assets
     from dynaboa_amd.hmr import hmr
