@@ -211,11 +211,14 @@ class Adaptor(BaseAdaptor):
         B = verts.shape[0]
         if not hasattr(self, "_Jh36m_dev"):
             self._Jh36m_dev = self.J_regressor.to(self.device).contiguous()
+            # device-resident index: indexing with a Python list would build the index on the host and
+            # do a synchronous H2D copy on every call (a full pipeline drain, 8x per frame)
+            self._j14_idx = torch.tensor(self.joint_mapper_h36m, dtype=torch.long, device=self.device)
         out = torch.empty(B, 17, 3, device=self.device)
         v = verts.contiguous()
         check(lib.dyb_regress_joints(self._Jh36m_dev.data_ptr(), v.data_ptr(), out.data_ptr(), 17, B, stream_of(v)),
               "dyb_regress_joints")
-        return out[:, self.joint_mapper_h36m, :] - out[:, [0], :]
+        return out.index_select(1, self._j14_idx) - out[:, 0:1, :]
 
     def inference(self, batch, model, need_feature=False, tag=None):
         if self._side is not None and self.options.deferred_metrics and not need_feature \
