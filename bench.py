@@ -224,7 +224,8 @@ def main():
                           "global_batch": args.batch * world, "parallelism": f"replicas{world} (stream sharded by sequence)",
                           "per_gpu_frames_per_s": value / world,
                           "pa_mpjpe_mm_synthetic_mean": float(np.mean(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]))) if metrics["pampjpe"] else None,
-                          "gathered_frames": int(gathered.numel()) if gathered is not None else None}}
+                          "gathered_frames": int(gathered.numel()) if gathered is not None else None,
+                          "engine_graphs": __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(args.batch).graph_stats()}}
         if not args.no_roofline:
             r = conv_roofline(device, args.batch, fwd_pf, args.inner_step + 1)
             out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

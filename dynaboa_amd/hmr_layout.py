@@ -46,6 +46,10 @@ class HmrLayout:
             lib.dyb_hmr_feature_info(plan, w, ctypes.cast(ctypes.pointer(off), ctypes.c_void_p),
                                      ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(ctypes.pointer(rs), ctypes.c_void_p))
             self.features.append(dict(offset=off.value, dims=list(dims), row_stride=rs.value))
+        # whole-call hipGraph caching inside the engine (the eager loop is host-issue-bound); DYB_GRAPHS=0 disables
+        import os
+        self.graphs = os.environ.get("DYB_GRAPHS", "1") != "0"
+        lib.dyb_hmr_set_graph_mode(plan, 1 if self.graphs else 0)
         self.off_rotmat = int(lib.dyb_hmr_act_offset_rotmat(plan))
         self.off_state = int(lib.dyb_hmr_act_offset_state(plan))
 
@@ -54,6 +58,11 @@ class HmrLayout:
             self.lib.dyb_hmr_plan_destroy(self.plan)
         except Exception:
             pass
+
+    def graph_stats(self):
+        st = (ctypes.c_longlong * 3)()
+        self.lib.dyb_hmr_graph_stats(self.plan, ctypes.cast(st, ctypes.c_void_p))
+        return dict(replays=int(st[0]), eager=int(st[1]), captures=int(st[2]))
 
     # ---- sizes -------------------------------------------------------------------------------
     def numel(self, t: dict) -> int:

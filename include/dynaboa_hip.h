@@ -144,7 +144,11 @@ int dyb_hmr_tensor_info(const void* plan, int i, char* name, int name_cap, int* 
 int dyb_hmr_feature_info(const void* plan, int which, long long* offset, int* dims4, int* row_stride);
 long long dyb_hmr_act_offset_rotmat(const void* plan); /* [B][24][9] */
 long long dyb_hmr_act_offset_state(const void* plan);  /* [B][160] pose|shape|cam|pad */
-int dyb_hmr_forward(const void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
+/* graph mode: whole forward / backward calls are captured into hipGraphs keyed by their pointer
+ * arguments (second sighting of a key) and replayed; results are those of the eager path. */
+int dyb_hmr_set_graph_mode(void* plan, int on);
+int dyb_hmr_graph_stats(const void* plan, long long* stats3); /* replays, eager calls, captures */
+int dyb_hmr_forward(void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
                     float* acts, void* ws, size_t ws_bytes, dyb_stream_t stream);
 /* aux_stream (may be NULL): second stream for the weight-gradient convolutions, which are off the
  * critical path; `stream` waits for them before the call returns control of ordering. */
