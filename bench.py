@@ -179,14 +179,20 @@ def main():
             ad.model.eval()
             ad.adaptation(frames[s])
 
-    run(0, args.warmup)
-    ad.flush_metrics()
+    # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
+    # capture on the legacy null stream
+    main_stream = torch.cuda.Stream(device=device)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main_stream):
+        run(0, args.warmup)
+        ad.flush_metrics()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, total)
+    with torch.cuda.stream(main_stream):
+        run(args.warmup, total)
     t_issue = time.perf_counter() - t0          # host finished issuing; GPU may still be draining
     torch.cuda.synchronize()
     if dist is not None:

@@ -110,7 +110,7 @@ struct HmrPlan {
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
   int graph_mode;
-  long g_hits, g_eager, g_captures;
+  long g_hits, g_eager, g_captures, g_fail_begin, g_fail_body, g_fail_end, g_fail_inst, g_fail_launch;
   // cross-stream ordering for the weight-gradient convolutions (created on first use)
   std::vector<hipEvent_t> ev_dy;
   hipEvent_t ev_join;
@@ -205,6 +205,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.events_ready = false;
   P.graph_mode = 0;
   P.g_hits = P.g_eager = P.g_captures = 0;
+  P.g_fail_begin = P.g_fail_body = P.g_fail_end = P.g_fail_inst = P.g_fail_launch = 0;
   for (auto& c : P.convs) {
     c.dy = dyoff;
     dyoff = align64(dyoff + (size_t)B * c.Ho * c.Wo * c.K);
@@ -338,11 +339,15 @@ extern "C" int dyb_hmr_set_graph_mode(void* plan, int on) {
   P->graph_mode = on ? 1 : 0;
   return DYB_OK;
 }
-// stats[0..2] = graph replays, eager calls, captures
-extern "C" int dyb_hmr_graph_stats(const void* plan, long long* stats3) {
+// stats[0..9] = graph replays, eager calls, captures, distinct forward keys, distinct backward keys,
+// capture failures at: begin, body, end, instantiate, first launch
+extern "C" int dyb_hmr_graph_stats(const void* plan, long long* stats10) {
   const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
-  DYB_REQUIRE(P && stats3, DYB_ERR_ARG);
-  stats3[0] = P->g_hits; stats3[1] = P->g_eager; stats3[2] = P->g_captures;
+  DYB_REQUIRE(P && stats10, DYB_ERR_ARG);
+  stats10[0] = P->g_hits; stats10[1] = P->g_eager; stats10[2] = P->g_captures;
+  stats10[3] = (long long)P->gfwd.size(); stats10[4] = (long long)P->gbwd.size();
+  stats10[5] = P->g_fail_begin; stats10[6] = P->g_fail_body; stats10[7] = P->g_fail_end; stats10[8] = P->g_fail_inst;
+  stats10[9] = P->g_fail_launch;
   return DYB_OK;
 }
 
@@ -367,6 +372,8 @@ static int run_cached(HmrPlan& P, std::unordered_map<GKey, GEntry, GKeyHash>& ca
       int rc = body();
       hipGraph_t graph = nullptr;
       hipError_t er = hipStreamEndCapture(st, &graph);
+      if (rc != DYB_OK) ++P.g_fail_body;
+      else if (er != hipSuccess || !graph) ++P.g_fail_end;
       if (rc == DYB_OK && er == hipSuccess && graph) {
         hipGraphExec_t exec = nullptr;
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec) {
@@ -374,14 +381,17 @@ static int run_cached(HmrPlan& P, std::unordered_map<GKey, GEntry, GKeyHash>& ca
           ++P.g_captures;
           e.exec = exec;
           if (hipGraphLaunch(exec, st) == hipSuccess) { ++P.g_hits; return DYB_OK; }
+          ++P.g_fail_launch;
           e.bad = true;
           return DYB_ERR_LAUNCH;
         }
+        ++P.g_fail_inst;
       }
       if (graph) (void)hipGraphDestroy(graph);
       (void)hipGetLastError();
       e.bad = true;                 // nothing ran (capture only records): fall through to eager
     } else {
+      ++P.g_fail_begin;
       (void)hipGetLastError();
       e.bad = true;
     }

@@ -63,6 +63,25 @@ def get_workspace(L: HmrLayout, device: torch.device) -> torch.Tensor:
     return ws
 
 
+_BWD_STAGE: Dict[tuple, dict] = {}
+
+
+def get_bwd_stage(L: HmrLayout, device: torch.device) -> dict:
+    """Persistent per-(plan, device, stream) buffers for the backward call: the incoming gradients
+    (tiny) are copied in and the parameter-gradient arena is written here and cloned out, so that the
+    call's pointer arguments - the engine's graph-cache key - recur from frame to frame.  The arena's
+    pad gaps are zeroed once; the engine overwrites every tensor span on each call."""
+    sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (L.B, L.H, L.W, str(device), sid)
+    st = _BWD_STAGE.get(key)
+    if st is None:
+        st = dict(d_state=torch.zeros(L.B, STATE_LD, dtype=torch.float32, device=device),
+                  d_rot=torch.zeros(L.B, 24, 3, 3, dtype=torch.float32, device=device),
+                  grads=torch.zeros(L.n_params, dtype=torch.float32, device=device))
+        _BWD_STAGE[key] = st
+    return st
+
+
 def _feature_views(L: HmrLayout, acts: torch.Tensor, n_iter: int):
     """The reference's feature list (model/hmr.py:139-168) as views of the activation arena.
     Spatial maps are exposed NCHW-shaped (channels-last strides) so shapes match the reference."""
@@ -108,19 +127,26 @@ class _HMRFunction(torch.autograd.Function):
         theta, acts = ctx.saved_tensors
         L = ctx.L
         B = L.B
-        d_state = torch.zeros(B, STATE_LD, dtype=torch.float32, device=theta.device)
+        stage = get_bwd_stage(L, theta.device)
+        d_state, d_rot_s, grads = stage["d_state"], stage["d_rot"], stage["grads"]
         if d_shape is not None:
-            d_state[:, 144:154] = d_shape
+            d_state[:, 144:154].copy_(d_shape)
+        else:
+            d_state[:, 144:154].zero_()
         if d_cam is not None:
-            d_state[:, 154:157] = d_cam
-        d_rot = torch.zeros(B, 24, 3, 3, device=theta.device) if d_rot is None else d_rot.contiguous().float()
-        grads = torch.zeros(L.n_params, dtype=torch.float32, device=theta.device)
+            d_state[:, 154:157].copy_(d_cam)
+        else:
+            d_state[:, 154:157].zero_()
+        if d_rot is not None:
+            d_rot_s.copy_(d_rot)
+        else:
+            d_rot_s.zero_()
         ws = get_workspace(L, theta.device)
-        check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot.data_ptr(), d_state.data_ptr(),
+        check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot_s.data_ptr(), d_state.data_ptr(),
                                    ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta),
                                    aux_stream_of(theta)),
               "dyb_hmr_backward")
-        return grads, None, None, None, None
+        return grads.clone(), None, None, None, None
 
 
 def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False):

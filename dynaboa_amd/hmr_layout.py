@@ -46,9 +46,11 @@ class HmrLayout:
             lib.dyb_hmr_feature_info(plan, w, ctypes.cast(ctypes.pointer(off), ctypes.c_void_p),
                                      ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(ctypes.pointer(rs), ctypes.c_void_p))
             self.features.append(dict(offset=off.value, dims=list(dims), row_stride=rs.value))
-        # whole-call hipGraph caching inside the engine (the eager loop is host-issue-bound); DYB_GRAPHS=0 disables
+        # whole-call hipGraph caching inside the engine.  OFF by default: measured on MI355X / ROCm 7.2 with a
+        # 97 % replay rate the host needs MORE time per frame (19.1 ms vs 15.2 ms eager) - hipGraphLaunch of a
+        # 180-330-node graph is slower than the engine's own C++ launch loop.  DYB_GRAPHS=1 enables it.
         import os
-        self.graphs = os.environ.get("DYB_GRAPHS", "1") != "0"
+        self.graphs = os.environ.get("DYB_GRAPHS", "0") == "1"
         lib.dyb_hmr_set_graph_mode(plan, 1 if self.graphs else 0)
         self.off_rotmat = int(lib.dyb_hmr_act_offset_rotmat(plan))
         self.off_state = int(lib.dyb_hmr_act_offset_state(plan))
@@ -60,9 +62,10 @@ class HmrLayout:
             pass
 
     def graph_stats(self):
-        st = (ctypes.c_longlong * 3)()
+        st = (ctypes.c_longlong * 10)()
         self.lib.dyb_hmr_graph_stats(self.plan, ctypes.cast(st, ctypes.c_void_p))
-        return dict(replays=int(st[0]), eager=int(st[1]), captures=int(st[2]))
+        return dict(replays=int(st[0]), eager=int(st[1]), captures=int(st[2]), fwd_keys=int(st[3]), bwd_keys=int(st[4]),
+                    fail=dict(begin=int(st[5]), body=int(st[6]), end=int(st[7]), instantiate=int(st[8]), launch=int(st[9])))
 
     # ---- sizes -------------------------------------------------------------------------------
     def numel(self, t: dict) -> int:

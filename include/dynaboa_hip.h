@@ -147,7 +147,7 @@ long long dyb_hmr_act_offset_state(const void* plan);  /* [B][160] pose|shape|ca
 /* graph mode: whole forward / backward calls are captured into hipGraphs keyed by their pointer
  * arguments (second sighting of a key) and replayed; results are those of the eager path. */
 int dyb_hmr_set_graph_mode(void* plan, int on);
-int dyb_hmr_graph_stats(const void* plan, long long* stats3); /* replays, eager calls, captures */
+int dyb_hmr_graph_stats(const void* plan, long long* stats10); /* replays, eager, captures, fwd keys, bwd keys, 5 failure counters */
 int dyb_hmr_forward(void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
                     float* acts, void* ws, size_t ws_bytes, dyb_stream_t stream);
 /* aux_stream (may be NULL): second stream for the weight-gradient convolutions, which are off the
