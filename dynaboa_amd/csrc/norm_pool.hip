@@ -152,14 +152,14 @@ static int gn_chunks(int HW, int N) {
   return dyb_cdiv(HW, rows);
 }
 
-// backward: the finalize kernel walks the chunks serially, so cap them at 32 while keeping
-// >= ~128 workgroups in the reduce kernel
+// backward: ~256 workgroups in the reduce kernel (its per-thread row loop is the latency chain),
+// at most 128 chunks (the apply kernel folds them 4 lanes wide per channel)
 static int gn_chunks_bwd(int HW, int N, int C) {
   int CQ = C / 4;
   int colblocks = CQ > 256 ? CQ / 256 : 1;
-  int want = 128 / (N * colblocks);
+  int want = 256 / (N * colblocks);
   if (want < 1) want = 1;
-  if (want > 32) want = 32;
+  if (want > 128) want = 128;
   int nch = HW < want ? HW : want;
   int rows = dyb_cdiv(HW, nch);
   return dyb_cdiv(HW, rows);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// grid-stride elementwise over [N][HW][C]; workgroups [0, ceil(C/256)) also write dgamma/dbeta
+// grid-stride elementwise over [N][HW][C]; workgroups [0, ceil(C/64)) also write dgamma/dbeta
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ y, const float* __restrict__ stats,
                                                            const float* __restrict__ partials, const float* __restrict__ gpart,
@@ -307,24 +307,35 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   __shared__ float s_coef[16 * G * 2];          // N <= 16 per call path; larger N handled in slices below
   const int CQ = C >> 2, cqg = C >> 4;
   const float inv_m = 1.0f / ((float)(C / G) * (float)HW);
-  // dgamma / dbeta: channel c = blockIdx.x*256 + tid
-  {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 < C && c < C) {
-      float A = 0.f, B = 0.f;
-      for (int n = 0; n < N; ++n) {
-        const float* p = partials + (size_t)n * nchunks * 2 * C + c;
-        int ch = 0;
-        for (; ch + 3 < nchunks; ch += 4) {
-          float a0 = p[(size_t)ch * 2 * C], a1 = p[(size_t)(ch + 1) * 2 * C], a2 = p[(size_t)(ch + 2) * 2 * C], a3 = p[(size_t)(ch + 3) * 2 * C];
-          float b0 = p[(size_t)ch * 2 * C + C], b1 = p[(size_t)(ch + 1) * 2 * C + C], b2 = p[(size_t)(ch + 2) * 2 * C + C], b3 = p[(size_t)(ch + 3) * 2 * C + C];
-          A += (a0 + a1) + (a2 + a3);
-          B += (b0 + b1) + (b2 + b3);
-        }
-        for (; ch < nchunks; ++ch) { A += p[(size_t)ch * 2 * C]; B += p[(size_t)ch * 2 * C + C]; }
+  // dgamma / dbeta: workgroup b < ceil(C/64) owns channels [64b, 64b+64); 4 lanes per channel split the
+  // (n, chunk) range and meet in LDS
+  __shared__ float s_gb[4][64][2];
+  if (blockIdx.x * 64 < C) {
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float A = 0.f, B = 0.f;
+    if (c < C) {
+      const int total = N * nchunks;
+      float A1 = 0.f, B1 = 0.f;
+      int k = part;
+      for (; k + 4 < total; k += 8) {
+        const float* p0 = partials + (size_t)k * 2 * C + c;
+        const float* p1 = partials + (size_t)(k + 4) * 2 * C + c;
+        float a0 = p0[0], b0 = p0[C], a1 = p1[0], b1 = p1[C];
+        A += a0; B += b0; A1 += a1; B1 += b1;
       }
-      dbeta[c] = A;
-      dgamma[c] = B;
+      if (k < total) {
+        const float* p0 = partials + (size_t)k * 2 * C + c;
+        A += p0[0]; B += p0[C];
+      }
+      A += A1; B += B1;
+    }
+    s_gb[part][cl][0] = A;
+    s_gb[part][cl][1] = B;
+    __syncthreads();
+    if (part == 0 && c < C) {
+      dbeta[c] = (s_gb[0][cl][0] + s_gb[1][cl][0]) + (s_gb[2][cl][0] + s_gb[3][cl][0]);
+      dgamma[c] = (s_gb[0][cl][1] + s_gb[1][cl][1]) + (s_gb[2][cl][1] + s_gb[3][cl][1]);
     }
   }
   __shared__ float s_red[4][8];
@@ -420,7 +431,7 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   size_t total4 = (size_t)N * HW * CQ;
   int blocks = (int)((total4 + 1023) / 1024);
   if (blocks > 2048) blocks = 2048;
-  int minb = dyb_cdiv(C, 256);
+  int minb = dyb_cdiv(C, 64);
   if (blocks < minb) blocks = minb;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dsrc, out, y, stats, (const float*)partials,
                      (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu);
