@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--inner_step", type=int, default=3)
     ap.add_argument("--schedule", choices=["faithful", "minimal"], default="faithful")
     ap.add_argument("--full_losses", type=int, default=0, help="1: the reference's default term set (teacher+motion+exemplars+dynamic loop)")
-    ap.add_argument("--overlap", type=int, default=1, help="1: metric / feature forwards on a side HIP stream (same results)")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="1: metric / feature forwards on a side HIP stream (same results); 2: also issued from a second host thread")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_baseline_only", action="store_true")
@@ -226,7 +227,8 @@ def main():
                                       "(%d HMR forwards + %d backwards per frame); metric/feature forwards %s" %
                                       (args.batch, args.inner_step, "reference default loss set" if args.full_losses else "frame losses only",
                                        args.schedule, fwd_pf, args.inner_step + 1,
-                                       "overlapped on a side HIP stream" if args.overlap else "in line"),
+                                       {0: "in line", 1: "overlapped on a side HIP stream",
+                                        2: "overlapped on a side HIP stream issued by a second host thread"}[args.overlap]),
                           "global_batch": args.batch * world, "parallelism": f"replicas{world} (stream sharded by sequence)",
                           "per_gpu_frames_per_s": value / world,
                           "pa_mpjpe_mm_synthetic_mean": float(np.mean(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]))) if metrics["pampjpe"] else None,

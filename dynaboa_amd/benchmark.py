@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import argparse
 import os
+import queue
+import threading
 from typing import Dict, Iterable, Optional
 
 import numpy as np
@@ -63,9 +65,10 @@ parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
 parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
-parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1],
+parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
-                         'concurrently with the next adaptation step (same arithmetic, same results)')
+                         'concurrently with the next adaptation step (same arithmetic, same results); 2 = also issue '
+                         'them from a second host thread')
 parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
                     help='run inference() after every inner step like the reference (:142)')
 
@@ -81,6 +84,42 @@ def frame_only_options(**over):
     return o
 
 
+class _SideWorker(threading.Thread):
+    """Issues work for the side HIP stream from its own host thread, so that the ~0.5 ms of launch
+    issue per no-grad forward does not serialise with the main thread's (ctypes and torch release the
+    GIL while launching).  Tasks run strictly in submission order under the side stream."""
+
+    def __init__(self, device, stream):
+        super().__init__(daemon=True)
+        self.device, self.stream = device, stream
+        self.q: "queue.Queue" = queue.Queue()
+        self.error = None
+        self.start()
+
+    def run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            fn, fut = item
+            try:
+                with torch.cuda.stream(self.stream):
+                    fut["out"] = fn()
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    fut["event"] = ev
+            except BaseException as e:      # noqa: BLE001  (re-raised on the main thread at the next join)
+                self.error = e
+            finally:
+                fut["done"].set()
+
+    def submit(self, fn):
+        fut = dict(done=threading.Event(), out=None, event=None)
+        self.q.put((fn, fut))
+        return fut
+
+
 class Adaptor(BaseAdaptor):
     def reset_records(self, nframes: int):
         self.sims, self.feat_sims, self.optim_step_record = [], {}, []
@@ -89,22 +128,33 @@ class Adaptor(BaseAdaptor):
         self.pampjpe_all_lower = [[] for _ in range(self.options.inner_step)]
         self.history, self.kp2dlosses_lower, self.kp2dlosses_upper = {}, [], {}
         self._pending = []            # deferred metric records
-        self._side, self._side_done = None, None
+        self._side, self._side_done, self._worker, self._last_fut = None, None, None, None
         if getattr(self.options, "overlap_metrics", 0) and self.options.deferred_metrics and self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)
+            if getattr(self.options, "overlap_metrics", 0) >= 2:
+                self._worker = _SideWorker(self.device, self._side)
 
     # ------------------------------------------------------------------ side-stream plumbing
     def _on_side(self, fn, *reads):
         """Run fn() on the side stream after everything issued so far on the current stream.
-        `reads`: tensors produced on the main stream that fn reads (kept alive for the side stream)."""
+        `reads`: tensors produced on the main stream that fn reads (kept alive for the side stream).
+        With a worker thread the call returns a future-like dict ({'done','out','event'})."""
         if self._side is None:
             return fn()
         ev = torch.cuda.Event()
         ev.record()
-        self._side.wait_event(ev)
         for t in reads:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(self._side)
+        if self._worker is not None:
+            side = self._side
+
+            def task():
+                side.wait_event(ev)
+                return fn()
+            self._last_fut = self._worker.submit(task)
+            return self._last_fut
+        self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
             out = fn()
             self._side_done = torch.cuda.Event()
@@ -114,8 +164,25 @@ class Adaptor(BaseAdaptor):
     def _join_side(self):
         """Main stream waits for the side stream (before theta / teacher are modified in place, or
         before side results are consumed on the main stream)."""
-        if self._side is not None and self._side_done is not None:
+        if self._side is None:
+            return
+        if self._worker is not None:
+            if self._last_fut is not None:
+                self._last_fut["done"].wait()           # host: the worker has issued everything submitted so far
+                if self._worker.error is not None:
+                    err, self._worker.error = self._worker.error, None
+                    raise err
+                self._side_done = self._last_fut["event"]
+        if self._side_done is not None:
             torch.cuda.current_stream(self.device).wait_event(self._side_done)
+
+    @staticmethod
+    def _resolve(x):
+        """Value of something returned by _on_side (after _join_side)."""
+        if isinstance(x, dict) and "done" in x and "event" in x:
+            x["done"].wait()
+            return x["out"]
+        return x
 
     @staticmethod
     def _theta_of(model):
@@ -178,6 +245,7 @@ class Adaptor(BaseAdaptor):
             self.pampjpe_statistics[self.global_step] = [pampjpe]
         if o.dynamic_boa:
             self._join_side()                   # init_features were produced on the side stream
+            init_features = self._resolve(init_features)
             with torch.no_grad():
                 adapted = self.model(image, need_feature=True)[3]
                 sims = self.cal_feature_diff(init_features, adapted)
@@ -220,11 +288,13 @@ class Adaptor(BaseAdaptor):
               "dyb_regress_joints")
         return out.index_select(1, self._j14_idx) - out[:, 0:1, :]
 
-    def inference(self, batch, model, need_feature=False, tag=None):
+    def inference(self, batch, model, need_feature=False, tag=None, _step=None):
+        step = self.global_step if _step is None else _step
         if self._side is not None and self.options.deferred_metrics and not need_feature \
                 and torch.cuda.current_stream(self.device) != self._side:
             reads = [self._theta_of(model)] + [v for v in batch.values() if torch.is_tensor(v)]
-            return self._on_side(lambda: self.inference(batch, model, need_feature, tag), *reads)
+            out = self._on_side(lambda: self.inference(batch, model, need_feature, tag, _step=step), *reads)
+            return (None, None, None) if isinstance(out, dict) else out      # deferred: values come from flush_metrics()
         image, gt_pose, gt_betas, gender = batch['image'], batch['pose'], batch['betas'], batch['gender']
         model.eval()
         with torch.no_grad():
@@ -249,7 +319,7 @@ class Adaptor(BaseAdaptor):
                          'rotmat': pred_rotmat.cpu().numpy(), 'beta': pred_shape.cpu().numpy()},
                         os.path.join(self.exppath, 'result', f'Pred_{self.global_step}.pt'))
         if self.options.deferred_metrics:
-            self._pending.append(dict(step=self.global_step, tag=tag, pred=pred14, gt=gt14, mpjpe=mpjpe_t, pve=pve_t))
+            self._pending.append(dict(step=step, tag=tag, pred=pred14, gt=gt14, mpjpe=mpjpe_t, pve=pve_t))
             res = (mpjpe_t, None, pve_t)
         else:
             S1, S2 = pred14.cpu().numpy(), gt14.cpu().numpy()
@@ -260,6 +330,7 @@ class Adaptor(BaseAdaptor):
     def flush_metrics(self):
         """Resolve deferred records with one device->host transfer (and one batched SVD)."""
         if self._side is not None:
+            self._join_side()
             self._side.synchronize()
         rec = self._pending
         self._pending = []

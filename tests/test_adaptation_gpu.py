@@ -103,21 +103,22 @@ def test_side_stream_overlap_changes_nothing():
     from dynaboa_amd import assets
     frames = [assets.make_frame(s, 1, seed=22) for s in range(3)]
     outs = []
-    for overlap in (0, 1):
+    for overlap in (0, 1, 2):
         opts, ident = STREAMS["fo_inner3_frameonly"]
         ad, _ = make_adaptor(dict(opts, overlap_metrics=overlap), ident, deferred=1)
         r = ad.excute(frames, nframes=3)
         outs.append((ad.model.module.theta.detach().clone(), r))
-    assert torch.equal(outs[0][0], outs[1][0])
-    for k in ("mpjpe", "pampjpe", "pve"):
-        np.testing.assert_array_equal(np.array(outs[0][1][k], dtype=np.float64).ravel(), np.array(outs[1][1][k], dtype=np.float64).ravel())
+    for other in outs[1:]:
+        assert torch.equal(outs[0][0], other[0])
+        for k in ("mpjpe", "pampjpe", "pve"):
+            np.testing.assert_array_equal(np.array(outs[0][1][k], dtype=np.float64).ravel(), np.array(other[1][k], dtype=np.float64).ravel())
     full, ident = STREAMS["fo_inner1_full_forced"]
     outs = []
-    for overlap in (0, 1):
+    for overlap in (0, 1, 2):
         ad, _ = make_adaptor(dict(full, overlap_metrics=overlap), ident, deferred=1)
         ad.excute(frames, nframes=3)
         outs.append(ad.model.module.theta.detach().clone())
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_engine_graph_cache_is_bit_identical():
