@@ -41,14 +41,25 @@ RESNET_CONVS = [
     (1, 14, 14, 1024, 2048, 1, 2, 0), (2, 7, 7, 2048, 512, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1)]
 
 
-def conv_roofline(device, batch, fwd_per_frame, bwd_per_frame, reps=5):
+def pmc_traffic():
+    """HBM read bytes per launch of the conv kernel family from the committed PMC pass
+    (profiles/r01_pmc_igemm_traffic.json: rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950
+    correction calibrated on the 216 MB / 432 MB streaming kernels); None if the file is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")))
+        return float(d["hbm_read_bytes_per_launch"])
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def conv_roofline(device, batch, fwd_per_frame, bwd_per_frame, reps=20):
     """Live HIP-event timing of the dominant kernel family (igemm_mfma_kernel<fwd|dgrad|wgrad>) on
     torch's current stream, layer by layer at the bench batch size; algorithmic FLOPs = 2*M*N*K of
     the real (unpadded) convolution.  Returns achieved TFLOP/s over one frame's worth of launches."""
     from dynaboa_amd import _lib
     lib = _lib.load()
     st = torch.cuda.current_stream(device).cuda_stream
-    tot_flop = tot_ms = 0.0
+    tot_flop = tot_ms = tot_bytes = 0.0
     nlaunch = 0
     for cnt, H, W, C, K, R, s, p in RESNET_CONVS:
         Ho = (H + 2 * p - R) // s + 1
@@ -80,9 +91,12 @@ def conv_roofline(device, batch, fwd_per_frame, bwd_per_frame, reps=5):
             ms = e0.elapsed_time(e1) / reps
             tot_ms += ms * cnt * per_frame
             tot_flop += flop * cnt * per_frame
+            # algorithmic bytes of this launch: both operands read once + result written once
+            tot_bytes += 4.0 * (x.numel() * (creal / C) + w.numel() * (creal / C) + dy.numel()) * cnt * per_frame
             nlaunch += cnt * per_frame
     return dict(achieved=tot_flop / (tot_ms * 1e-3) / 1e12, conv_ms_per_frame=tot_ms, launches_per_frame=nlaunch,
-                avg_launch_us=tot_ms * 1e3 / nlaunch, gflop_per_frame=tot_flop / 1e9)
+                avg_launch_us=tot_ms * 1e3 / nlaunch, gflop_per_frame=tot_flop / 1e9,
+                algorithmic_bytes_per_launch=tot_bytes / nlaunch)
 
 
 def cpu_baseline_worker(inner_step=3, budget_s=20.0, max_frames=6):
@@ -237,7 +251,9 @@ def main():
         if not args.no_roofline:
             r = conv_roofline(device, args.batch, fwd_pf, args.inner_step + 1)
             out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),
+                               "traffic_note": "HBM READ bytes per launch (FETCH_SIZE x2, profiles/r01_pmc_igemm_traffic.json); "
+                                               "write side not collected", "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                                "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad> (+ split-K fold), per-frame launch mix",
                                "avg_launch_us": r["avg_launch_us"], "launches_per_frame": r["launches_per_frame"],
                                "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],

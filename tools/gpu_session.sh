@@ -19,6 +19,12 @@ for s in $STAGES; do
            find $OUT/prof -name "*stats*" | head -5 >> $OUT/prof.log
            python tools/trace_analyze.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) $OUT/trace_summary.json > $OUT/trace_summary.txt 2>&1
            rm -f $(find $OUT/prof -name "*kernel_trace.csv") ;;
+    pmc)   for C in FETCH_SIZE WRITE_SIZE; do
+             (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --overlap 0 --no_cpu_baseline --no_roofline) > $OUT/pmc_$C.log 2>&1
+             f=$(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1)
+             python tools/pmc_summarize.py $f $C $OUT/pmc_$C.json > $OUT/pmc_$C.txt 2>&1
+             rm -rf $OUT/pmc_$C
+           done ;;
     micro) timeout 300 python tools/microbench.py 1 > $OUT/microbench.log 2>&1 ;;
   esac
   echo "stage $s done rc=$?" >> $OUT/stages.log
