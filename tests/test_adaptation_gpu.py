@@ -167,3 +167,53 @@ def test_state_dict_roundtrip_and_missing_extension_is_loud(tmp_path):
     finally:
         _lib._lib, _lib.LIB_PATH = saved, _lib.LIB_PATH.replace(str(tmp_path / "nope.so"), "")
         _lib.LIB_PATH = __import__("os").path.join(__import__("os").path.dirname(_lib.__file__), "libdynaboa_hip.so")
+
+
+def test_hmr_forward_explicit_init_and_n_iter_vs_reference(ckpt_rand):
+    """HMR.forward(x, init_pose, init_shape, init_cam, n_iter=2) (reference model/hmr.py:127,132-137) against
+    golden g3 'alt_*' produced by the reference module itself."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr import hmr
+    g = golden("g3_hmr.npz")
+    mp = assets.make_smpl_mean_params(identity_pose=False, seed=3)
+    m = hmr(mp, seed=1).to("cuda:0").eval()
+    m.load_state_dict(ckpt_rand, strict=True)
+    img = assets.make_frame(0, batch_size=2, seed=22)["image"][:1].to("cuda:0")
+    with torch.no_grad():
+        r, s, c = m(img, init_pose=m.init_pose * 0.9, init_shape=m.init_shape + 0.1, init_cam=m.init_cam * 1.1, n_iter=2)
+        r3, s3, c3, feats = m(img, need_feature=True)
+    assert rel_err(r.cpu().numpy(), g["alt_rotmat"]) < 1e-5
+    assert rel_err(s.cpu().numpy(), g["alt_shape"]) < 1e-5 and rel_err(c.cpu().numpy(), g["alt_cam"]) < 1e-5
+    assert len(feats) == 15 and list(feats[1].shape) == [1, 256, 56, 56] and list(feats[12].shape) == [1, 1024]
+    assert rel_err(r3.cpu().numpy(), g["rotmat"][:1]) < 1e-5
+    with pytest.raises(NotImplementedError):
+        m.train()(img)
+
+
+def test_batch4_frame_matches_oracle(gmm_t, smpl_tabs):
+    """One full bilevel step at batch 4 (SURVEY 8d config 3 size class) against the CPU oracle:
+    predictions after the step, and the Adam first moment (= 0.5 * outer gradient after step 1)."""
+    from dynaboa_amd import assets
+    from oracle import ref_cpu as O
+    opts = dict(FRAME_ONLY, inner_step=2, batch_size=4)
+    ad, bundle = make_adaptor(opts, False)
+    ad.reset_records(1)
+    ad.global_step = 0
+    frame = assets.make_frame(3, 4, seed=22)
+    ad.model.eval()
+    ad.adaptation({k: v.to(ad.device) for k, v in frame.items()})
+    with torch.no_grad():
+        r, s, c = ad.model(frame["image"].to(ad.device))
+        j = ad.decode_smpl_params(r, s)["s3d"]
+    sd = {k.replace("module.", ""): v for k, v in bundle.checkpoint["model"].items()}
+    ref = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, opts)
+    rec = ref.adapt_frame(frame)
+    for name, a, b in (("rotmat", r, rec["pred"]["rotmat"]), ("shape", s, rec["pred"]["shape"]), ("cam", c, rec["pred"]["cam"]),
+                       ("joints", j, rec["pred"]["joints"])):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-3, name
+    hmr_m = ad.model.module
+    m1 = hmr_m._layout1.unpack(ad.optimizer.state[hmr_m.theta]["exp_avg"])
+    for k in ("conv1.weight", "layer2.0.conv2.weight", "layer4.2.conv3.weight", "fc1.weight", "decpose.bias"):
+        a, b = m1[k].double().flatten() * 2, rec["outer_grad"][k].double().flatten()
+        assert cosine(a, b) > 0.999, k
+        assert abs(float(a.norm() / b.norm()) - 1) < 2e-2, k
