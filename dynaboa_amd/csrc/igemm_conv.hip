@@ -18,9 +18,9 @@
 // 32x32 accumulator (16 VGPRs).  Operands are staged through LDS k-major ([32][64+4]) so the
 // MFMA fragment read (lane -> row lane&31, k = lane>>5) is a conflict-free ds_read_b32 and the
 // "contiguous along the tile row" sources are written with one ds_write_b128.  Global loads are
-// 16 B per lane, four per thread per K-step (two per operand), register-prefetched one K-step
-// ahead of the 16 MFMAs of the current step (two LDS buffers, one barrier per step): at batch 1
-// the loop is load-latency-bound, so fewer, fatter steps matter more than LDS footprint.  At batch 1 most layers have only 1..50 output tiles, so the K loop is
+// 16 B per lane, four per thread per K-step (two per operand), register-prefetched TWO K-steps
+// ahead of the 16 MFMAs of the current step (two register sets, two LDS buffers, one barrier per
+// step): at batch 1 the loop is load-latency-bound, so loads in flight matter more than footprint.  At batch 1 most layers have only 1..50 output tiles, so the K loop is
 // split over blockIdx.z into fp32 slabs that a second kernel (or the GroupNorm statistics
 // kernel) folds - deterministic, no atomics.
 #include "dyb_common.h"
@@ -221,17 +221,26 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   if (kt_begin < kt_end) {
-    float4 ra0 = load_a(kt_begin, 0), ra1 = load_a(kt_begin, 1), rb0 = load_b(kt_begin, 0), rb1 = load_b(kt_begin, 1);
-    store_a(0, 0, ra0); store_a(0, 1, ra1);
-    store_b(0, 0, rb0); store_b(0, 1, rb1);
+    // Two register sets: while the MFMAs of K-step kt run out of LDS, the loads of steps kt+1 (set
+    // P^1, about to be staged) and kt+2 (set P, just freed) are both in flight.  The loop is
+    // unrolled by two so the set indices are compile-time (no scratch).
+    float4 a0[2], b0[2], a1[2], b1[2];
+    a0[0] = load_a(kt_begin, 0); a0[1] = load_a(kt_begin, 1);
+    b0[0] = load_b(kt_begin, 0); b0[1] = load_b(kt_begin, 1);
+    if (kt_begin + 1 < kt_end) {
+      a1[0] = load_a(kt_begin + 1, 0); a1[1] = load_a(kt_begin + 1, 1);
+      b1[0] = load_b(kt_begin + 1, 0); b1[1] = load_b(kt_begin + 1, 1);
+    }
+    store_a(0, 0, a0[0]); store_a(0, 1, a0[1]);
+    store_b(0, 0, b0[0]); store_b(0, 1, b0[1]);
     __syncthreads();
     const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = (kt + 1) < kt_end;
-      if (more) {
-        ra0 = load_a(kt + 1, 0); ra1 = load_a(kt + 1, 1);
-        rb0 = load_b(kt + 1, 0); rb1 = load_b(kt + 1, 1);
+    auto step = [&](int kt, int buf, float4 (&fa)[2], float4 (&fb)[2], float4 (&na)[2], float4 (&nb)[2]) {
+      // fa/fb: set whose tile (kt) is already in LDS buf -> refill it with tile kt+2
+      // na/nb: set holding tile kt+1 -> staged into LDS buf^1 after the MFMAs
+      if (kt + 2 < kt_end) {
+        fa[0] = load_a(kt + 2, 0); fa[1] = load_a(kt + 2, 1);
+        fb[0] = load_b(kt + 2, 0); fb[1] = load_b(kt + 2, 1);
       }
 #pragma unroll
       for (int k2 = 0; k2 < BK; k2 += 2) {
@@ -239,12 +248,15 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
         float b = Bs[buf][k2 + khalf][bcol];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
-      if (more) {
-        store_a(buf ^ 1, 0, ra0); store_a(buf ^ 1, 1, ra1);
-        store_b(buf ^ 1, 0, rb0); store_b(buf ^ 1, 1, rb1);
+      if (kt + 1 < kt_end) {
+        store_a(buf ^ 1, 0, na[0]); store_a(buf ^ 1, 1, na[1]);
+        store_b(buf ^ 1, 0, nb[0]); store_b(buf ^ 1, 1, nb[1]);
       }
       __syncthreads();
-      buf ^= 1;
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      step(kt, 0, a0, b0, a1, b1);
+      if (kt + 1 < kt_end) step(kt + 1, 1, a1, b1, a0, b0);
     }
   }
 

@@ -233,7 +233,30 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   int row1 = row0 + rows_per_chunk;
   if (row1 > HW) row1 = HW;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int row = row0 + ty; row < row1; row += TY) {
+  auto accumulate = [&](float4 d, float4 v, float4 o) {
+    if (relu) {
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
+      d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+    a[0] += d.x; a[1] += d.y; a[2] += d.z; a[3] += d.w;
+    b[0] += d.x * ((v.x - mean) * rstd); b[1] += d.y * ((v.y - mean) * rstd);
+    b[2] += d.z * ((v.z - mean) * rstd); b[3] += d.w * ((v.w - mean) * rstd);
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int row = row0 + ty;
+  if (!folded) {
+    // plain gradient: two rows (six 16-byte loads) in flight per iteration - the loop is latency-bound
+    for (; row + TY < row1; row += 2 * TY) {
+      size_t o0 = ((size_t)n * HW + row) * C + (size_t)cq * 4, o1 = o0 + (size_t)TY * C;
+      float4 d0 = *reinterpret_cast<const float4*>(dout + o0), d1 = *reinterpret_cast<const float4*>(dout + o1);
+      float4 v0 = *reinterpret_cast<const float4*>(y + o0), v1 = *reinterpret_cast<const float4*>(y + o1);
+      float4 q0 = relu ? *reinterpret_cast<const float4*>(out + o0) : zero4;
+      float4 q1 = relu ? *reinterpret_cast<const float4*>(out + o1) : zero4;
+      accumulate(d0, v0, q0);
+      accumulate(d1, v1, q1);
+    }
+  }
+  for (; row < row1; row += TY) {
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 d = *reinterpret_cast<const float4*>(dout + off);
     float4 v = *reinterpret_cast<const float4*>(y + off);
@@ -257,14 +280,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       d.x += d1.x + d2.x; d.y += d1.y + d2.y; d.z += d1.z + d2.z; d.w += d1.w + d2.w;
       *reinterpret_cast<float4*>(folded + off) = d;
     }
-    if (relu) {
-      float4 o = *reinterpret_cast<const float4*>(out + off);
-      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
-      d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
-    }
-    a[0] += d.x; a[1] += d.y; a[2] += d.z; a[3] += d.w;
-    b[0] += d.x * ((v.x - mean) * rstd); b[1] += d.y * ((v.y - mean) * rstd);
-    b[2] += d.z * ((v.z - mean) * rstd); b[3] += d.w * ((v.w - mean) * rstd);
+    accumulate(d, v, relu ? *reinterpret_cast<const float4*>(out + off) : zero4);
   }
   float* mine = sm + threadIdx.x * 8;
 #pragma unroll
