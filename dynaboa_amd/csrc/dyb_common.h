@@ -53,6 +53,5 @@ struct ConvDesc {
 // statistics kernel to fold (igemm_conv.hip)
 int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y, void* ws, size_t ws_bytes,
                      int* nslabs, hipStream_t st);
-int dyb_conv_dgrad_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
-                       size_t ws_bytes, int* nslabs, hipStream_t st);
-int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);
+// chunking of the GroupNorm-backward partial sums (norm_pool.hip): nch row chunks x ncolb column blocks
+void dyb_gn_bwd_layout(int N, int HW, int C, int* nch, int* ncolb);

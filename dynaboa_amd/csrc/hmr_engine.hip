@@ -4,7 +4,7 @@
 //     2208, the three decoder heads fused into one [160][1024] matrix),
 //   * ONE activation arena per forward call (every conv output + every GroupNorm output is kept:
 //     that is exactly what backward needs; 22.2 M floats = 89 MB per image),
-//   * a workspace (split-K slabs, norm partials, four ping-pong gradient buffers).
+//   * a workspace (split-K slabs, norm partials, three gradient buffers, per-layer masked gradients).
 // One C call = one whole forward (or backward): ~180 (~330) stream-ordered launches, no host
 // syncs, no allocation, capturable in a hipGraph.  PyTorch only owns the memory and the stream.
 #include <string.h>
@@ -18,15 +18,16 @@
 // ---- low-level entry points defined in the sibling files -----------------------------------
 extern "C" {
 size_t dyb_conv2d_workspace_bytes(int, int, int, int, int, int, int, int, int);
-int dyb_conv2d_nhwc_dgrad(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int,
-                          void*, size_t, hipStream_t);
-int dyb_conv2d_nhwc_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t,
-                          hipStream_t);
 size_t dyb_groupnorm_workspace_bytes(int, int, int);
 int dyb_groupnorm_fwd(const float*, int, float*, const float*, const float*, const float*, float*, float*, int, int, int,
                       int, void*, size_t, hipStream_t);
-int dyb_groupnorm_bwd_fold(const float*, int, size_t, const float*, float*, const float*, const float*, const float*,
-                           const float*, float*, float*, float*, float*, int, int, int, int, void*, size_t, hipStream_t);
+size_t dyb_groupnorm_bwd_partial_floats(int, int, int);
+int dyb_groupnorm_bwd_reduce(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int,
+                             int, int, hipStream_t);
+int dyb_conv2d_nhwc_dgrad_gn(const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                             const float*, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+int dyb_conv2d_nhwc_wgrad_gn(const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                             float*, float*, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 int dyb_nchw3_to_nhwc4(const float*, float*, int, int, int, hipStream_t);
 int dyb_maxpool3x3s2_fwd(const float*, float*, uint32_t*, int, int, int, int, hipStream_t);
 int dyb_maxpool3x3s2_bwd(const float*, const uint32_t*, float*, int, int, int, int, hipStream_t);
@@ -48,10 +49,6 @@ int dyb_rot6d_bwd(const float*, int, const float*, float*, int, int, hipStream_t
 #define STATE_LD 160     // pose 144 | shape 10 | cam 3 | pad 3
 #define HID 1024
 #define MAX_ITER 3
-// Folding dgrad slabs inside the next GroupNorm backward was measured SLOWER than the wide stand-alone
-// fold (2.19-2.31 ms vs 2.11 ms per backward on MI355X): the GN reduce kernel has few workgroups,
-// so extra serial loads there cost more than a launch.  1 = always materialise; the path is kept.
-#define DYB_MAX_PENDING_SLABS 1
 
 enum TensorKind { K_CONV_W = 0, K_NORM_W = 1, K_NORM_B = 2, K_FC_W = 3, K_FC_B = 4, K_DEC_W = 5, K_DEC_B = 6 };
 
@@ -67,7 +64,8 @@ struct ConvL {
   int H, W, C, K, R, S, stride, pad, Ho, Wo;
   size_t w, gam, bet;          // parameter offsets
   size_t y, out, stats;        // activation offsets (conv output, normalised output, [B][4][2])
-  size_t dy;                   // offset (floats) of this layer's d(conv output) in the workspace dy arena
+  size_t dy;                   // offset (floats) of this layer's masked GroupNorm-output gradient in the workspace dm arena
+  size_t gnb;                  // offset (floats) of this layer's GroupNorm-backward partial sums in the workspace
 };
 struct BlockL {
   int c1, c2, c3, cd;          // indices into convs (cd = -1: identity shortcut)
@@ -105,7 +103,7 @@ struct HmrPlan {
   int poolH, poolW;            // max-pool output
   int featHW;                  // spatial size of the last feature map (7*7)
   // workspace carve (bytes)
-  size_t ws_conv, ws_conv_aux, ws_gn, ws_lin, ws_grad_each, ws_dy, ws_reg, ws_total;
+  size_t ws_conv, ws_conv_aux, ws_gn, ws_gnb, ws_lin, ws_grad_each, ws_dy, ws_reg, ws_total;
   // hipGraph cache: a whole forward / backward call is captured once per distinct set of pointer
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
@@ -201,7 +199,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.a_rot = aoff; aoff = align64(aoff + (size_t)B * 24 * 9);
   P.act_floats = aoff;
 
-  size_t wc = 0, wg = 0, maxact = 0, dyoff = 0;
+  size_t wc = 0, wg = 0, maxact = 0, dyoff = 0, gnboff = 0;
   P.events_ready = false;
   P.graph_mode = 0;
   P.g_hits = P.g_eager = P.g_captures = 0;
@@ -209,6 +207,8 @@ static HmrPlan* build_plan(int B, int H, int W) {
   for (auto& c : P.convs) {
     c.dy = dyoff;
     dyoff = align64(dyoff + (size_t)B * c.Ho * c.Wo * c.K);
+    c.gnb = gnboff;
+    gnboff = align64(gnboff + dyb_groupnorm_bwd_partial_floats(B, c.Ho * c.Wo, c.K));
     size_t s = dyb_conv2d_workspace_bytes(B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad);
     if (s > wc) wc = s;
     size_t g = dyb_groupnorm_workspace_bytes(B, c.Ho * c.Wo, c.K);
@@ -225,11 +225,12 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_conv_aux = P.ws_conv;
   P.ws_dy = dyoff * 4;
   P.ws_gn = align64(wg / 4) * 4;
+  P.ws_gnb = gnboff * 4;
   P.ws_lin = align64(wl / 4) * 4;
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_lin + 4 * P.ws_grad_each + P.ws_dy + P.ws_reg;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
   return pp;
 }
 
@@ -306,7 +307,8 @@ extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long l
 
 struct WsCarve {
   char *conv, *conv_aux, *gn, *lin;
-  float* g[4];
+  float* gnb;
+  float* g[3];
   float* dy;
   float* reg;
 };
@@ -316,8 +318,9 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   c.conv = b; b += P.ws_conv;
   c.conv_aux = b; b += P.ws_conv_aux;
   c.gn = b; b += P.ws_gn;
+  c.gnb = reinterpret_cast<float*>(b); b += P.ws_gnb;
   c.lin = b; b += P.ws_lin;
-  for (int i = 0; i < 4; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
+  for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
   c.dy = reinterpret_cast<float*>(b); b += P.ws_dy;
   c.reg = reinterpret_cast<float*>(b);
   return c;
@@ -462,58 +465,40 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   return DYB_OK;
 }
 
-// A gradient tensor that may still be spread over the split-K slabs of the data-gradient convolution
-// that produced it (plus an addend, the residual-edge gradient).  The next GroupNorm backward folds
-// it inside its reduce kernel, which removes one dependent launch per layer from the critical path.
-struct Pending {
-  const float* base;
-  int nslabs;
-  size_t stride;
-  const float* addend;
-};
-static Pending plain(const float* p) { return Pending{p, 1, 0, nullptr}; }
-
-// GroupNorm backward of layer ci (folding `din` into `fold_buf` when needed) -> this layer's own dy
-// buffer; then the weight gradient - off the critical path, so on the auxiliary stream when given,
-// ordered by one event per layer, with its own split-K slab region.
+// GroupNorm backward of layer ci, reduce half only: dm = din masked by the layer's ReLU lands in the
+// layer's own slot of the dm arena (relu == 0: dm aliases din, which then must itself be such a slot),
+// the partial sums in the layer's slot of the gnb arena.  dy = rstd*(gamma*dm - c1 - xhat*c2) is
+// never materialised: the data-gradient conv below and the weight-gradient conv form it in their
+// operand loaders.  The weight gradient (which also writes dgamma / dbeta) is off the critical path,
+// so it goes to the auxiliary stream when given, ordered by one event per layer, with its own split-K
+// slab region; everything it reads lives in per-layer slots that nothing overwrites during the call.
 static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
-                        const Pending& din, float* fold_buf, int relu, float* dres, const WsCarve& w, hipStream_t st,
+                        const float* din, int relu, const float** dm_out, const WsCarve& w, hipStream_t st,
                         hipStream_t aux) {
   const ConvL& c = P.convs[ci];
-  float* dy_buf = w.dy + c.dy;
-  RUN(dyb_groupnorm_bwd_fold(din.base, din.nslabs, din.stride, din.addend, fold_buf, acts + c.out, acts + c.y,
-                             acts + c.stats, params + c.gam, dy_buf, dres, grads + c.gam, grads + c.bet, P.B, c.Ho * c.Wo,
-                             c.K, relu, w.gn, P.ws_gn, st));
+  float* dm = relu ? w.dy + c.dy : const_cast<float*>(din);
+  float* part = w.gnb + c.gnb;
+  RUN(dyb_groupnorm_bwd_reduce(din, acts + c.out, acts + c.y, acts + c.stats, params + c.gam, dm, part, P.B, c.Ho * c.Wo,
+                               c.K, relu, st));
+  hipStream_t ws_st = st;
+  void* slabs = w.conv;
   if (aux) {
     if (hipEventRecord(P.ev_dy[ci], st) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(aux, P.ev_dy[ci], 0) != hipSuccess) return DYB_ERR_LAUNCH;
-    RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad,
-                              w.conv_aux, P.ws_conv_aux, aux));
-  } else {
-    RUN(dyb_conv2d_nhwc_wgrad(conv_in, dy_buf, grads + c.w, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv,
-                              P.ws_conv, st));
+    ws_st = aux;
+    slabs = w.conv_aux;
   }
+  RUN(dyb_conv2d_nhwc_wgrad_gn(conv_in, dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
+                               grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, ws_st));
+  *dm_out = dm;
   return DYB_OK;
 }
-// data gradient of layer ci; result either materialised in dx_buf (acc + addend) or left pending
-static int layer_dgrad(HmrPlan& P, int ci, const float* params, float* dx_buf, const float* addend, Pending* out,
-                       const WsCarve& w, hipStream_t st) {
+// data gradient of layer ci from its dm: dx_buf = conv_transpose(dy, w) (+ addend)
+static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* acts, const float* dm, float* dx_buf,
+                       const float* addend, const WsCarve& w, hipStream_t st) {
   const ConvL& c = P.convs[ci];
-  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
-  int ns = 1;
-  RUN(dyb_conv_dgrad_raw(d, w.dy + c.dy, params + c.w, dx_buf, addend, w.conv, P.ws_conv, out ? &ns : nullptr, st));
-  if (out) {
-    const size_t n = (size_t)P.B * c.H * c.W * c.C;
-    if (ns > 1 && ns <= DYB_MAX_PENDING_SLABS) {
-      *out = Pending{reinterpret_cast<const float*>(w.conv), ns, n, addend};
-    } else {
-      // many slabs: the wide stand-alone fold is cheaper than a long serial loop inside the
-      // (few-workgroup) GroupNorm reduce kernel
-      if (ns > 1) RUN(dyb_splitk_fold(reinterpret_cast<const float*>(w.conv), ns, n, addend, dx_buf, st));
-      *out = plain(dx_buf);
-    }
-  }
-  return DYB_OK;
+  return dyb_conv2d_nhwc_dgrad_gn(dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, params + c.w, dx_buf, addend,
+                                  P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv, P.ws_conv, st);
 }
 
 // d_rotmat: [B][24][9]; d_state: [B][160], only columns 144..156 (shape, cam) are read.
@@ -575,46 +560,40 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, FC1_IN_PAD, HID, grads + P.fc1_w, FC1_IN_PAD, grads + P.fc1_b, st));
   }
 
-  // ---- backbone, last block first.  Buffers: Ra/Rb ping-pong for the residual-edge gradient that
-  // travels between blocks as the pending gradient's addend, F = fold target, D = materialised dgrad.
-  float *Rin = nullptr, *Rfree0 = w.g[0], *Rfree1 = w.g[1], *F = w.g[2], *D = w.g[3];
-  RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, F, B, P.featHW, FEAT, st));
-  Pending cur = plain(F);     // a plain gradient needs no fold; a pending one is always folded into F
+  // ---- backbone, last block first.  D0/D1 ping-pong the data gradients travelling down the main
+  // branch, Rb holds the shortcut branch's data gradient; the residual-edge gradient of a block is the
+  // dm of its third GroupNorm (the ReLU-masked incoming gradient), used in place.
+  float *D0 = w.g[0], *D1 = w.g[1], *Rb = w.g[2];
+  RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, D0, B, P.featHW, FEAT, st));
+  float* cur = D0;
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
     const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
-    float* Rnew = (Rin == Rfree0) ? Rfree1 : Rfree0;          // residual-edge gradient of THIS block
+    float* nxt = (cur == D0) ? D1 : D0;
+    const float *dm3, *dm2, *dm1, *dmd;
     // out = relu(gn3(conv3(a2)) + res)
-    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, F, 1, Rnew, w, st, aux));
-    Pending p3, p2, pout;
-    RUN(layer_dgrad(P, b.c3, params, D, nullptr, &p3, w, st));
-    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, p3, F, 1, nullptr, w, st, aux));
-    RUN(layer_dgrad(P, b.c2, params, D, nullptr, &p2, w, st));
-    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, p2, F, 1, nullptr, w, st, aux));
-    float* Rother = (Rnew == Rfree0) ? Rfree1 : Rfree0;       // == Rin's buffer (dead after the c3 fold) or the spare
+    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, 1, &dm3, w, st, aux));
+    RUN(layer_dgrad(P, b.c3, params, acts, dm3, nxt, nullptr, w, st));
+    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, nxt, 1, &dm2, w, st, aux));
+    RUN(layer_dgrad(P, b.c2, params, acts, dm2, cur, nullptr, w, st));
+    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, cur, 1, &dm1, w, st, aux));
     if (b.cd >= 0) {
-      // shortcut branch: GN (no ReLU) on the residual-edge gradient, data gradient materialised in Rother
-      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, plain(Rnew), nullptr, 0, nullptr, w, st, aux));
-      RUN(layer_dgrad(P, b.cd, params, Rother, nullptr, nullptr, w, st));
-      RUN(layer_dgrad(P, b.c1, params, D, Rother, &pout, w, st));
-      Rin = Rother;
+      // shortcut branch: GroupNorm without ReLU on the residual-edge gradient
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, dm3, 0, &dmd, w, st, aux));
+      RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, w, st));
+      RUN(layer_dgrad(P, b.c1, params, acts, dm1, nxt, Rb, w, st));
     } else {
-      RUN(layer_dgrad(P, b.c1, params, D, Rnew, &pout, w, st));
-      Rin = Rnew;
+      RUN(layer_dgrad(P, b.c1, params, acts, dm1, nxt, dm3, w, st));
     }
-    cur = pout;
+    cur = nxt;
   }
-  // ---- stem: maxpool needs the gradient materialised -> GN/ReLU -> conv1 (no data gradient for the image)
+  // ---- stem: maxpool backward -> GN/ReLU -> conv1 (no data gradient for the image)
   const ConvL& stem = P.convs[0];
-  const float* gpool = cur.base;
-  if (cur.nslabs > 1 || cur.addend) {
-    RUN(dyb_splitk_fold(cur.base, cur.nslabs, (size_t)B * P.poolH * P.poolW * stem.K, cur.addend, F, st));
-    gpool = F;
-  }
-  float* gstem = (gpool == D) ? F : D;
-  RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), gstem, B, stem.Ho, stem.Wo, stem.K, st));
-  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, plain(gstem), nullptr, 1, nullptr, w, st, aux));
+  float* gstem = (cur == D0) ? D1 : D0;
+  RUN(dyb_maxpool3x3s2_bwd(cur, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), gstem, B, stem.Ho, stem.Wo, stem.K, st));
+  const float* dm0;
+  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, gstem, 1, &dm0, w, st, aux));
   if (aux) {
     if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;

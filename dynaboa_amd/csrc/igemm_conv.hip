@@ -18,11 +18,11 @@
 // 32x32 accumulator (16 VGPRs).  Operands are staged through LDS k-major ([32][64+4]) so the
 // MFMA fragment read (lane -> row lane&31, k = lane>>5) is a conflict-free ds_read_b32 and the
 // "contiguous along the tile row" sources are written with one ds_write_b128.  Global loads are
-// 16 B per lane, four per thread per K-step (two per operand), register-prefetched TWO K-steps
-// ahead of the 16 MFMAs of the current step (two register sets, two LDS buffers, one barrier per
-// step): at batch 1 the loop is load-latency-bound, so loads in flight matter more than footprint.  At batch 1 most layers have only 1..50 output tiles, so the K loop is
-// split over blockIdx.z into fp32 slabs that a second kernel (or the GroupNorm statistics
-// kernel) folds - deterministic, no atomics.
+// 16 B per lane, four per thread per K-step (two per operand), register-prefetched one K-step
+// ahead of the 16 MFMAs of the current step (two LDS buffers, one barrier per step; a second
+// register set - two steps in flight - measured no gain and cost half the occupancy).  At batch 1
+// most layers have only 1..50 output tiles, so the K loop is split over blockIdx.z into fp32 slabs
+// that a second kernel (or the GroupNorm statistics kernel) folds - deterministic, no atomics.
 #include "dyb_common.h"
 
 #define BM 64
@@ -112,6 +112,22 @@ __device__ __forceinline__ float4 dg_a_load(const IgemmArgs& g, const DgARow& ro
   }
   return v;
 }
+// float offset of that 16-byte piece inside a [N][Ho][Wo][K] tensor, or -1 for a structural zero
+__device__ __forceinline__ long dg_a_off(const IgemmArgs& g, const DgARow& row, int kk) {
+  if (row.valid && kk < g.Kdim) {
+    int rs = kk >> g.logK;
+    int ko = kk & (g.K - 1);
+    int r = rs / g.S;
+    int s = rs - r * g.S;
+    int th = row.h + g.pad - r, tw = row.w + g.pad - s;
+    int sm = g.stride - 1;
+    if (th >= 0 && tw >= 0 && (th & sm) == 0 && (tw & sm) == 0) {
+      int ho = th >> (g.stride >> 1), wo = tw >> (g.stride >> 1);
+      if (ho < g.Ho && wo < g.Wo) return (long)((((size_t)((row.n * g.Ho + ho) * g.Wo + wo)) << g.logK) + ko);
+    }
+  }
+  return -1;
+}
 // rows = cin, k = (r,s,ko) with ko fastest: W[(rs*C + c)*K + ko]         (dgrad B, transposing)
 __device__ __forceinline__ float4 dg_b_load(const IgemmArgs& g, int c, int kk) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,10 +173,46 @@ __device__ __forceinline__ float4 wg_a_load(const IgemmArgs& g, const WgARow& ro
   return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
+// ---- GroupNorm backward applied in the operand loader --------------------------------------------
+// The gradient w.r.t. a conv output y is  dy = rstd*(gamma*dm - c1 - xhat*c2)  with dm the (ReLU-
+// masked) gradient of the GroupNorm output, xhat = (y-mean)*rstd and c1, c2 two per-(image, group)
+// means.  dy is only ever consumed by the data-gradient conv (as its A operand) and the weight-
+// gradient conv (as its B operand), so instead of materialising it in a kernel of its own (one more
+// dependent launch on the critical chain per layer) both form it on the fly from (dm, y): the
+// coefficients come from the per-chunk partial sums that gn_bwd_reduce left behind, folded in each
+// workgroup's prologue while its first operand loads are in flight.  The weight-gradient launch also
+// folds the per-channel partials into dgamma / dbeta (it runs off the critical path).
+struct GnBwdFuse {
+  const float* y;          // [N][HW][K]  conv output that was normalised
+  const float* stats;      // [N][G][2]   mean, rstd
+  const float* gpart;      // [N][kparts][G][2]  per-chunk sums of gamma*dm, gamma*dm*xhat
+  const float* gamma;      // [K]
+  const float* partials;   // [N*nchunks][2][K]  per-channel sums (wgrad launch: dgamma / dbeta)
+  float* dgamma;
+  float* dbeta;
+  int kparts, nchunks, HW;
+  float inv_m;
+};
+struct Frag {
+  float4 d, v, ga;
+  bool ok;
+};
+__device__ __forceinline__ float4 gnb_apply(const Frag& f, const float* cf) {
+  const float mean = cf[0], rstd = cf[1], c1 = cf[2], c2 = cf[3];
+  float4 r;
+  r.x = rstd * (f.ga.x * f.d.x - c1 - ((f.v.x - mean) * rstd) * c2);
+  r.y = rstd * (f.ga.y * f.d.y - c1 - ((f.v.y - mean) * rstd) * c2);
+  r.z = rstd * (f.ga.z * f.d.z - c1 - ((f.v.z - mean) * rstd) * c2);
+  r.w = rstd * (f.ga.w * f.d.w - c1 - ((f.v.w - mean) * rstd) * c2);
+  return r;
+}
+
+template <int MODE, bool GB>
+__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
+  __shared__ float s_coef[GB ? 64 * DYB_GN_GROUPS * 4 : 4];   // [n][g] -> mean, rstd, c1, c2
+  __shared__ float s_raw[GB ? 64 * DYB_GN_GROUPS * 2 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -184,34 +236,76 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
   if constexpr (MODE == MODE_FWD) fa = fwd_a_row(g, m0 + t_row);
   if constexpr (MODE == MODE_DGRAD) da = dg_a_row(g, m0 + t_row);
   if constexpr (MODE == MODE_WGRAD) wa = wg_a_row(g, m0 + d_q);
+  const int logKg = g.logK - 2;                                 // log2(channels per group)
+  float4 wg_gamma = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (GB && MODE == MODE_WGRAD) {
+    if (n0 + d_q < g.Ncols) wg_gamma = *reinterpret_cast<const float4*>(f.gamma + n0 + d_q);
+  }
 
-  auto load_a = [&](int kt, int h) -> float4 {
-    if constexpr (MODE == MODE_FWD) return fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
-    else if constexpr (MODE == MODE_DGRAD) return dg_a_load(g, da, kt * BK + 16 * h + t_kq);
-    else return wg_a_load(g, wa, kt * BK + 16 * h + d_k);
+  auto load_a = [&](int kt, int h, Frag& o) {
+    if constexpr (MODE == MODE_FWD) o.d = fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
+    else if constexpr (MODE == MODE_DGRAD) {
+      if constexpr (GB) {
+        long off = dg_a_off(g, da, kt * BK + 16 * h + t_kq);
+        o.ok = off >= 0;
+        if (o.ok) {
+          o.d = *reinterpret_cast<const float4*>(g.A + off);
+          o.v = *reinterpret_cast<const float4*>(f.y + off);
+          o.ga = *reinterpret_cast<const float4*>(f.gamma + ((kt * BK + 16 * h + t_kq) & (g.K - 1)));
+        }
+      } else {
+        o.d = dg_a_load(g, da, kt * BK + 16 * h + t_kq);
+      }
+    } else o.d = wg_a_load(g, wa, kt * BK + 16 * h + d_k);
   };
-  auto load_b = [&](int kt, int h) -> float4 {
-    if constexpr (MODE == MODE_FWD) return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
-    else if constexpr (MODE == MODE_DGRAD) return dg_b_load(g, n0 + t_row, kt * BK + 16 * h + t_kq);
-    else return direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+  auto load_b = [&](int kt, int h, Frag& o) {
+    if constexpr (MODE == MODE_FWD) o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+    else if constexpr (MODE == MODE_DGRAD) o.d = dg_b_load(g, n0 + t_row, kt * BK + 16 * h + t_kq);
+    else {
+      if constexpr (GB) {
+        const int p = kt * BK + 16 * h + d_k, col = n0 + d_q;
+        o.ok = p < g.Kdim && col < g.Ncols;
+        if (o.ok) {
+          size_t off = (size_t)p * g.K + col;
+          o.d = *reinterpret_cast<const float4*>(g.B + off);
+          o.v = *reinterpret_cast<const float4*>(f.y + off);
+        }
+      } else {
+        o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+      }
+    }
   };
-  auto store_a = [&](int buf, int h, float4 v) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto store_a = [&](int buf, int kt, int h, const Frag& o) {
     if constexpr (MODE == MODE_WGRAD) {
-      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = v;
+      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = o.d;
     } else {
+      float4 v = o.d;
+      if constexpr (GB && MODE == MODE_DGRAD) {
+        const int ko = (kt * BK + 16 * h + t_kq) & (g.K - 1);
+        v = o.ok ? gnb_apply(o, &s_coef[(da.n * DYB_GN_GROUPS + (ko >> logKg)) * 4]) : zero4;
+      }
       As[buf][16 * h + t_kq + 0][t_row] = v.x;
       As[buf][16 * h + t_kq + 1][t_row] = v.y;
       As[buf][16 * h + t_kq + 2][t_row] = v.z;
       As[buf][16 * h + t_kq + 3][t_row] = v.w;
     }
   };
-  auto store_b = [&](int buf, int h, float4 v) {
+  auto store_b = [&](int buf, int kt, int h, const Frag& o) {
     if constexpr (MODE == MODE_DGRAD) {
-      Bs[buf][16 * h + t_kq + 0][t_row] = v.x;
-      Bs[buf][16 * h + t_kq + 1][t_row] = v.y;
-      Bs[buf][16 * h + t_kq + 2][t_row] = v.z;
-      Bs[buf][16 * h + t_kq + 3][t_row] = v.w;
+      Bs[buf][16 * h + t_kq + 0][t_row] = o.d.x;
+      Bs[buf][16 * h + t_kq + 1][t_row] = o.d.y;
+      Bs[buf][16 * h + t_kq + 2][t_row] = o.d.z;
+      Bs[buf][16 * h + t_kq + 3][t_row] = o.d.w;
     } else {
+      float4 v = o.d;
+      if constexpr (GB && MODE == MODE_WGRAD) {
+        const int p = kt * BK + 16 * h + d_k;
+        const int n = g.N > 1 ? p / f.HW : 0;
+        Frag t = o;
+        t.ga = wg_gamma;
+        v = o.ok ? gnb_apply(t, &s_coef[(n * DYB_GN_GROUPS + ((n0 + d_q) >> logKg)) * 4]) : zero4;
+      }
       *reinterpret_cast<float4*>(&Bs[buf][16 * h + d_k][d_q]) = v;
     }
   };
@@ -220,27 +314,51 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+  Frag ra[2], rb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { ra[h].d = ra[h].v = ra[h].ga = zero4; ra[h].ok = false; rb[h] = ra[h]; }
   if (kt_begin < kt_end) {
-    // Two register sets: while the MFMAs of K-step kt run out of LDS, the loads of steps kt+1 (set
-    // P^1, about to be staged) and kt+2 (set P, just freed) are both in flight.  The loop is
-    // unrolled by two so the set indices are compile-time (no scratch).
-    float4 a0[2], b0[2], a1[2], b1[2];
-    a0[0] = load_a(kt_begin, 0); a0[1] = load_a(kt_begin, 1);
-    b0[0] = load_b(kt_begin, 0); b0[1] = load_b(kt_begin, 1);
-    if (kt_begin + 1 < kt_end) {
-      a1[0] = load_a(kt_begin + 1, 0); a1[1] = load_a(kt_begin + 1, 1);
-      b1[0] = load_b(kt_begin + 1, 0); b1[1] = load_b(kt_begin + 1, 1);
+    load_a(kt_begin, 0, ra[0]); load_a(kt_begin, 1, ra[1]);
+    load_b(kt_begin, 0, rb[0]); load_b(kt_begin, 1, rb[1]);
+  }
+  if constexpr (GB) {
+    // fold the per-chunk group sums into (c1, c2) for every image: 8 values per image, L lanes each
+    const int nvals = g.N * DYB_GN_GROUPS * 2;
+    int L = 32;
+    while (L > 1 && L * nvals > 256) L >>= 1;
+    const int per_pass = 256 / L;
+    for (int base = 0; base < nvals; base += per_pass) {
+      const int v = base + tid / L, sub = tid % L;
+      float s = 0.f;
+      if (v < nvals) {
+        const float* gp = f.gpart + (size_t)(v >> 3) * f.kparts * 8 + (v & 7);
+        for (int k = sub; k < f.kparts; k += L) s += gp[(size_t)k * 8];
+      }
+      for (int m = L >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+      if (v < nvals && sub == 0) s_raw[v] = s * f.inv_m;
     }
-    store_a(0, 0, a0[0]); store_a(0, 1, a0[1]);
-    store_b(0, 0, b0[0]); store_b(0, 1, b0[1]);
+    __syncthreads();
+    for (int i = tid; i < g.N * DYB_GN_GROUPS; i += 256) {
+      s_coef[i * 4 + 0] = f.stats[i * 2];
+      s_coef[i * 4 + 1] = f.stats[i * 2 + 1];
+      s_coef[i * 4 + 2] = s_raw[i * 2];
+      s_coef[i * 4 + 3] = s_raw[i * 2 + 1];
+    }
+    __syncthreads();
+  }
+
+  if (kt_begin < kt_end) {
+    // register prefetch one K-step ahead, two LDS buffers, one barrier per step
+    store_a(0, kt_begin, 0, ra[0]); store_a(0, kt_begin, 1, ra[1]);
+    store_b(0, kt_begin, 0, rb[0]); store_b(0, kt_begin, 1, rb[1]);
     __syncthreads();
     const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
-    auto step = [&](int kt, int buf, float4 (&fa)[2], float4 (&fb)[2], float4 (&na)[2], float4 (&nb)[2]) {
-      // fa/fb: set whose tile (kt) is already in LDS buf -> refill it with tile kt+2
-      // na/nb: set holding tile kt+1 -> staged into LDS buf^1 after the MFMAs
-      if (kt + 2 < kt_end) {
-        fa[0] = load_a(kt + 2, 0); fa[1] = load_a(kt + 2, 1);
-        fb[0] = load_b(kt + 2, 0); fb[1] = load_b(kt + 2, 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if (more) {
+        load_a(kt + 1, 0, ra[0]); load_a(kt + 1, 1, ra[1]);
+        load_b(kt + 1, 0, rb[0]); load_b(kt + 1, 1, rb[1]);
       }
 #pragma unroll
       for (int k2 = 0; k2 < BK; k2 += 2) {
@@ -248,15 +366,11 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
         float b = Bs[buf][k2 + khalf][bcol];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
-      if (kt + 1 < kt_end) {
-        store_a(buf ^ 1, 0, na[0]); store_a(buf ^ 1, 1, na[1]);
-        store_b(buf ^ 1, 0, nb[0]); store_b(buf ^ 1, 1, nb[1]);
+      if (more) {
+        store_a(buf ^ 1, kt + 1, 0, ra[0]); store_a(buf ^ 1, kt + 1, 1, ra[1]);
+        store_b(buf ^ 1, kt + 1, 0, rb[0]); store_b(buf ^ 1, kt + 1, 1, rb[1]);
       }
       __syncthreads();
-    };
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-      step(kt, 0, a0, b0, a1, b1);
-      if (kt + 1 < kt_end) step(kt + 1, 1, a1, b1, a0, b0);
     }
   }
 
@@ -272,6 +386,41 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g) {
         float v = acc[r];
         if (g.nsplit == 1 && g.addend) v += g.addend[o];
         outp[o] = v;
+      }
+    }
+  }
+
+  if constexpr (GB && MODE == MODE_WGRAD) {
+    // dgamma / dbeta of the 64 channels of this column block: 4 lanes per channel split the
+    // (image, chunk) range of the per-channel partials and meet in LDS (reusing the A stage)
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
+      __syncthreads();
+      float(*s_gb)[64][2] = reinterpret_cast<float(*)[64][2]>(&As[0][0][0]);
+      const int cl = tid & 63, part = tid >> 6;
+      const int c = n0 + cl, C = g.K;
+      float A = 0.f, B = 0.f;
+      if (c < C) {
+        const int total = g.N * f.nchunks;
+        float A1 = 0.f, B1 = 0.f;
+        int k = part;
+        for (; k + 4 < total; k += 8) {
+          const float* p0 = f.partials + (size_t)k * 2 * C + c;
+          const float* p1 = f.partials + (size_t)(k + 4) * 2 * C + c;
+          float a0 = p0[0], b0 = p0[C], a1 = p1[0], b1 = p1[C];
+          A += a0; B += b0; A1 += a1; B1 += b1;
+        }
+        if (k < total) {
+          const float* p0 = f.partials + (size_t)k * 2 * C + c;
+          A += p0[0]; B += p0[C];
+        }
+        A += A1; B += B1;
+      }
+      s_gb[part][cl][0] = A;
+      s_gb[part][cl][1] = B;
+      __syncthreads();
+      if (part == 0 && c < C) {
+        f.dbeta[c] = (s_gb[0][cl][0] + s_gb[1][cl][0]) + (s_gb[2][cl][0] + s_gb[3][cl][0]);
+        f.dgamma[c] = (s_gb[0][cl][1] + s_gb[1][cl][1]) + (s_gb[2][cl][1] + s_gb[3][cl][1]);
       }
     }
   }
@@ -327,17 +476,29 @@ static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
   return DYB_OK;
 }
 
-// Split-K policy: aim for >= ~3 workgroups per CU (768) while keeping >= 2 K-steps (64 k) per split.
-static int choose_split(const IgemmArgs& g, size_t ws_floats) {
+// Split-K policy from measurements on MI355X at these sizes: a K-step costs ~0.5 us of exposed
+// latency, a dependent launch ~5.8 us (the stand-alone fold that dgrad / wgrad need), an extra slab
+// ~0.15 us inside the GroupNorm statistics kernel that folds the forward's slabs for free.
+//   backward modes: t(s) = ktiles/s * 0.5 + (s > 1 ? 5.8 + 0.1 s : 0)  -> never split below ~16 K-steps
+//   forward       : t(s) = ktiles/s * 0.5 + 0.15 s
+// bounded so that the grid stays <= ~1024 workgroups and every split keeps >= 2 K-steps.
+static int choose_split(const IgemmArgs& g, size_t ws_floats, int mode) {
   int tiles = dyb_cdiv(g.M, BM) * dyb_cdiv(g.Ncols, BN);
-  int want = dyb_cdiv(768, tiles);
-  int cap = g.ktiles / 2;
-  if (cap < 1) cap = 1;
-  int s = want < cap ? want : cap;
-  if (s < 1) s = 1;
+  int maxs = g.ktiles / 2;
+  if (maxs < 1) maxs = 1;
+  int gridcap = 1024 / tiles;
+  if (gridcap < 1) gridcap = 1;
+  if (maxs > gridcap) maxs = gridcap;
+  int best = 1;
+  float bt = 0.5f * g.ktiles;
+  for (int s = 2; s <= maxs; ++s) {
+    float steps = (float)dyb_cdiv(g.ktiles, s);
+    float t = 0.5f * steps + (mode == MODE_FWD ? 0.15f * s : 5.8f + 0.1f * s);
+    if (t < bt - 0.25f) { bt = t; best = s; }
+  }
   size_t per = (size_t)g.M * g.Ncols;
-  while (s > 1 && (size_t)s * per > ws_floats) --s;
-  return s;
+  while (best > 1 && (size_t)best * per > ws_floats) --best;
+  return best;
 }
 
 extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
@@ -347,7 +508,7 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
   for (int mode = 0; mode < 3; ++mode) {
     IgemmArgs g{};
     if (fill_args(g, d, mode) != DYB_OK) return 0;
-    int s = choose_split(g, (size_t)-1 / 8);
+    int s = choose_split(g, (size_t)-1 / 8, mode);
     size_t need = (s > 1) ? (size_t)s * g.M * g.Ncols * sizeof(float) : 0;
     if (need > best) best = need;
   }
@@ -358,13 +519,13 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
 // in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
 static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B, float* out, const float* addend,
-                     void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st) {
+                     void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st, const GnBwdFuse* fuse = nullptr) {
   DYB_REQUIRE(A && B && out, DYB_ERR_ARG);
   IgemmArgs g{};
   int rc = fill_args(g, d, mode);
   if (rc != DYB_OK) return rc;
   g.A = A; g.B = B;
-  g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0);
+  g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode);
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits
   if (raw_slabs_out) *raw_slabs_out = 1;
@@ -372,9 +533,15 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   g.out = split ? reinterpret_cast<float*>(ws) : out;
   g.addend = split ? nullptr : addend;
   dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit);
-  if (mode == MODE_FWD) hipLaunchKernelGGL(igemm_mfma_kernel<MODE_FWD>, grid, dim3(256), 0, st, g);
-  else if (mode == MODE_DGRAD) hipLaunchKernelGGL(igemm_mfma_kernel<MODE_DGRAD>, grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(igemm_mfma_kernel<MODE_WGRAD>, grid, dim3(256), 0, st, g);
+  GnBwdFuse f{};
+  if (fuse) {
+    DYB_REQUIRE(mode != MODE_FWD && d.N <= 64, DYB_ERR_UNSUPPORTED);
+    f = *fuse;
+    if (mode == MODE_DGRAD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, true>), grid, dim3(256), 0, st, g, f);
+    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true>), grid, dim3(256), 0, st, g, f);
+  } else if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false>), grid, dim3(256), 0, st, g, f);
+  else if (mode == MODE_DGRAD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, false>), grid, dim3(256), 0, st, g, f);
+  else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, false>), grid, dim3(256), 0, st, g, f);
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
@@ -393,25 +560,6 @@ int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y
   return run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, nslabs, st);
 }
 
-// out = sum_z slabs[z] (+ addend) over n floats (n % 4 == 0)
-int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st) {
-  size_t n4 = n / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
-                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4);
-  DYB_CHECK_LAUNCH();
-  return DYB_OK;
-}
-
-// data gradient that may leave `*nslabs` (>1) un-reduced split-K slabs in `ws` for the consumer (the
-// next GroupNorm backward) to fold together with `addend`; with *nslabs == 1 dx already holds
-// acc + addend.
-int dyb_conv_dgrad_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
-                       size_t ws_bytes, int* nslabs, hipStream_t st) {
-  return run_igemm(MODE_DGRAD, d, dy, w, dx, addend, ws, ws_bytes, nslabs, st);
-}
-
 extern "C" int dyb_conv2d_nhwc_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R,
                                    int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
   ConvDesc d{N, H, W, C, K, R, S, stride, pad};
@@ -428,4 +576,44 @@ extern "C" int dyb_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
                                      int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
   ConvDesc d{N, H, W, C, K, R, S, stride, pad};
   return run_igemm(MODE_WGRAD, d, x, dy, dw, nullptr, ws, ws_bytes, nullptr, st);
+}
+
+// ---- data / weight gradient with the GroupNorm backward of the conv's output formed in the loader ----
+// dm: masked gradient of the GroupNorm output, y_gn/stats: saved conv output and (mean, rstd), part: the
+// partial-sum block dyb_groupnorm_bwd_reduce wrote for this layer (N images, Ho*Wo pixels, K channels).
+static int make_fuse(GnBwdFuse& f, const ConvDesc& d, const float* y_gn, const float* stats, const float* part,
+                     const float* gamma, float* dgamma, float* dbeta) {
+  DYB_REQUIRE(y_gn && stats && part && gamma, DYB_ERR_ARG);
+  DYB_REQUIRE(d.K % 16 == 0, DYB_ERR_UNSUPPORTED);
+  int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
+  int nch = 0, ncolb = 0;
+  dyb_gn_bwd_layout(d.N, Ho * Wo, d.K, &nch, &ncolb);
+  f.y = y_gn; f.stats = stats; f.gamma = gamma;
+  f.partials = part;
+  f.gpart = part + (size_t)d.N * nch * 2 * d.K;
+  f.dgamma = dgamma; f.dbeta = dbeta;
+  f.kparts = nch * ncolb; f.nchunks = nch; f.HW = Ho * Wo;
+  f.inv_m = 1.0f / ((float)(d.K / DYB_GN_GROUPS) * (float)(Ho * Wo));
+  return DYB_OK;
+}
+extern "C" int dyb_conv2d_nhwc_dgrad_gn(const float* dm, const float* y_gn, const float* stats, const float* part,
+                                        const float* gamma, const float* w, float* dx, const float* addend, int N, int H,
+                                        int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
+                                        hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, y_gn, stats, part, gamma, nullptr, nullptr);
+  if (rc != DYB_OK) return rc;
+  return run_igemm(MODE_DGRAD, d, dm, w, dx, addend, ws, ws_bytes, nullptr, st, &f);
+}
+extern "C" int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const float* y_gn, const float* stats,
+                                        const float* part, const float* gamma, float* dw, float* dgamma, float* dbeta,
+                                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                                        size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(dgamma && dbeta, DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, y_gn, stats, part, gamma, dgamma, dbeta);
+  if (rc != DYB_OK) return rc;
+  return run_igemm(MODE_WGRAD, d, x, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f);
 }

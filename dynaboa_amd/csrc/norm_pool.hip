@@ -215,7 +215,7 @@ extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const
 // residual-edge gradient); it is folded here, once, and written to `folded` for the apply kernel.
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, int nslabs, size_t slab_stride,
                                                             const float* __restrict__ addend, float* __restrict__ folded,
-                                                            const float* __restrict__ out,
+                                                            float* __restrict__ dm, const float* __restrict__ out,
                                                             const float* __restrict__ y, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, float* __restrict__ partials,
                                                             float* __restrict__ gpart, int HW, int C, int rows_per_chunk,
@@ -233,11 +233,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   int row1 = row0 + rows_per_chunk;
   if (row1 > HW) row1 = HW;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-  auto accumulate = [&](float4 d, float4 v, float4 o) {
+  auto accumulate = [&](float4 d, float4 v, float4 o, size_t off) {
     if (relu) {
       d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
       d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
     }
+    if (dm) *reinterpret_cast<float4*>(dm + off) = d;     // masked gradient: residual-edge gradient / fused-dy operand
     a[0] += d.x; a[1] += d.y; a[2] += d.z; a[3] += d.w;
     b[0] += d.x * ((v.x - mean) * rstd); b[1] += d.y * ((v.y - mean) * rstd);
     b[2] += d.z * ((v.z - mean) * rstd); b[3] += d.w * ((v.w - mean) * rstd);
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       float4 v0 = *reinterpret_cast<const float4*>(y + o0), v1 = *reinterpret_cast<const float4*>(y + o1);
       float4 q0 = relu ? *reinterpret_cast<const float4*>(out + o0) : zero4;
       float4 q1 = relu ? *reinterpret_cast<const float4*>(out + o1) : zero4;
-      accumulate(d0, v0, q0);
-      accumulate(d1, v1, q1);
+      accumulate(d0, v0, q0, o0);
+      accumulate(d1, v1, q1, o1);
     }
   }
   for (; row < row1; row += TY) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       d.x += d1.x + d2.x; d.y += d1.y + d2.y; d.z += d1.z + d2.z; d.w += d1.w + d2.w;
       *reinterpret_cast<float4*>(folded + off) = d;
     }
-    accumulate(d, v, relu ? *reinterpret_cast<const float4*>(out + off) : zero4);
+    accumulate(d, v, relu ? *reinterpret_cast<const float4*>(out + off) : zero4, off);
   }
   float* mine = sm + threadIdx.x * 8;
 #pragma unroll
@@ -441,7 +442,8 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   float* partials = reinterpret_cast<float*>(ws);
   float* gpart = partials + (size_t)N * nch * 2 * C;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout_slabs, nslabs, slab_stride, addend,
-                     fold ? folded : (float*)nullptr, out, y, stats, gamma, partials, gpart, HW, C, rows, relu, TX);
+                     fold ? folded : (float*)nullptr, (float*)nullptr, out, y, stats, gamma, partials, gpart, HW, C, rows, relu,
+                     TX);
   DYB_CHECK_LAUNCH();
   const float* dsrc = fold ? folded : dout_slabs;
   size_t total4 = (size_t)N * HW * CQ;
@@ -451,6 +453,38 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   if (blocks < minb) blocks = minb;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dsrc, out, y, stats, (const float*)partials,
                      (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// ---- reduce-only form for consumers that form dy in their operand loaders (igemm_conv.hip) ----------
+void dyb_gn_bwd_layout(int N, int HW, int C, int* nch, int* ncolb) {
+  *nch = gn_chunks_bwd(HW, N, C);
+  int CQ = C / 4;
+  int TX = CQ < 256 ? CQ : 256;
+  *ncolb = CQ / TX;
+}
+extern "C" size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C) {
+  int nch, ncolb;
+  dyb_gn_bwd_layout(N, HW, C, &nch, &ncolb);
+  return (size_t)N * nch * 2 * C + (size_t)N * nch * ncolb * G * 2;
+}
+// dm = dout masked by the ReLU (relu == 0: dm may equal dout, nothing is written then); part receives
+// the per-channel and per-group partial sums ([N*nch][2][C] | [N][nch*ncolb][G][2]).
+extern "C" int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
+                                        const float* gamma, float* dm, float* part, int N, int HW, int C, int relu,
+                                        hipStream_t st) {
+  DYB_REQUIRE(dout && y && stats && gamma && dm && part, DYB_ERR_ARG);
+  DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  int nch, ncolb;
+  dyb_gn_bwd_layout(N, HW, C, &nch, &ncolb);
+  int CQ = C / 4;
+  int TX = CQ < 256 ? CQ : 256;
+  int rows = dyb_cdiv(HW, nch);
+  float* gpart = part + (size_t)N * nch * 2 * C;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, 1, (size_t)0, (const float*)nullptr,
+                     (float*)nullptr, dm == dout ? (float*)nullptr : dm, out, y, stats, gamma, part, gpart, HW, C, rows, relu,
+                     TX);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

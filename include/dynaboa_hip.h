@@ -60,6 +60,25 @@ int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_t slab_stri
                            float* dres, float* dgamma, float* dbeta, int N, int HW, int C, int relu, void* ws,
                            size_t ws_bytes, dyb_stream_t stream);
 
+/* GroupNorm backward split for consumers that form dy on the fly: the reduce half alone.  dm = dout
+ * masked by the ReLU (relu == 0: pass dm == dout, nothing is copied); `part`
+ * (dyb_groupnorm_bwd_partial_floats floats) receives the per-channel / per-group partial sums.  The
+ * two convolution gradients below consume (dm, y_gn, stats, part, gamma) in their operand loaders -
+ * dy = rstd*(gamma*dm - c1 - xhat*c2) never exists in memory - and the weight-gradient launch also
+ * writes dgamma / dbeta.  Same autograd as dyb_groupnorm_bwd + dyb_conv2d_nhwc_dgrad/_wgrad, one
+ * dependent launch less per layer (the engine's critical chain is launch-latency-bound at batch 1). */
+size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C);
+int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
+                             const float* gamma, float* dm, float* part, int N, int HW, int C, int relu,
+                             dyb_stream_t stream);
+int dyb_conv2d_nhwc_dgrad_gn(const float* dm, const float* y_gn, const float* stats, const float* part,
+                             const float* gamma, const float* w, float* dx, const float* addend, int N, int H, int W,
+                             int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
+                             dyb_stream_t stream);
+int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const float* y_gn, const float* stats, const float* part,
+                             const float* gamma, float* dw, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                             int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
 int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);

@@ -470,3 +470,52 @@ def case_groupnorm_fold(be, N, HW, C, nslabs, with_addend, seed=11):
         e[name] = rel_err(a, b)
     assert max(e.values()) < 1e-5, e
     return e
+
+
+# ------------------------------------------------------------------- conv + GroupNorm backward, dy never materialised
+def case_conv_gn_bwd_fused(be, N, H, W, C, K, R, stride, pad, relu=1, seed=21):
+    """out = relu?(GN(conv(x, w))): gradients w.r.t. x (+ addend), w, gamma, beta through
+    dyb_groupnorm_bwd_reduce -> dyb_conv2d_nhwc_dgrad_gn / _wgrad_gn, against torch autograd."""
+    rng = _rng(seed)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((R, R, C, K)) / np.sqrt(R * R * C)).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    HW = Ho * Wo
+    dout = rng.standard_normal((N, Ho, Wo, K)).astype(np.float32)
+    add = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wt = torch.from_numpy(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    o = F.group_norm(F.conv2d(xt, wt, stride=stride, padding=pad), 4, gt, bt, 1e-5)
+    if relu:
+        o = F.relu(o)
+    gx, gw, gg, gb = torch.autograd.grad(o, [xt, wt, gt, bt], torch.from_numpy(dout).permute(0, 3, 1, 2))
+
+    wsb = max(be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad), 16)
+    ws = be.empty((wsb // 4,))
+    gwsb = be.lib.dyb_groupnorm_workspace_bytes(N, HW, K)
+    gws = be.empty((gwsb // 4,))
+    X, Wt, GA, BE_, DO, ADD = be.dev(x), be.dev(w), be.dev(gamma), be.dev(beta), be.dev(dout), be.dev(add)
+    Y, OUT, ST = be.empty((N, HW, K)), be.empty((N, HW, K)), be.empty((N, 4, 2))
+    check(be.lib.dyb_conv2d_nhwc_fwd(be.ptr(X), be.ptr(Wt), be.ptr(Y), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb,
+                                     be.stream), "conv fwd")
+    check(be.lib.dyb_groupnorm_fwd(None, 1, be.ptr(Y), be.ptr(GA), be.ptr(BE_), None, be.ptr(OUT), be.ptr(ST), N, HW, K, relu,
+                                   be.ptr(gws), gwsb, be.stream), "gn fwd")
+    part = be.empty((be.lib.dyb_groupnorm_bwd_partial_floats(N, HW, K),))
+    DM = be.empty((N, HW, K)) if relu else DO
+    check(be.lib.dyb_groupnorm_bwd_reduce(be.ptr(DO), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(GA), be.ptr(DM), be.ptr(part),
+                                          N, HW, K, relu, be.stream), "gn bwd reduce")
+    DX, DW, DG, DB = be.empty(x.shape), be.empty(w.shape), be.empty((K,)), be.empty((K,))
+    check(be.lib.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM), be.ptr(Y), be.ptr(ST), be.ptr(part), be.ptr(GA), be.ptr(Wt), be.ptr(DX),
+                                          be.ptr(ADD), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb, be.stream), "dgrad gn")
+    ws2 = be.empty((wsb // 4,))
+    check(be.lib.dyb_conv2d_nhwc_wgrad_gn(be.ptr(X), be.ptr(DM), be.ptr(Y), be.ptr(ST), be.ptr(part), be.ptr(GA), be.ptr(DW),
+                                          be.ptr(DG), be.ptr(DB), N, H, W, C, K, R, R, stride, pad, be.ptr(ws2), wsb,
+                                          be.stream), "wgrad gn")
+    e = dict(dx=rel_err(be.host(DX), gx.permute(0, 2, 3, 1).numpy() + add),
+             dw=rel_err(be.host(DW), gw.permute(2, 3, 1, 0).numpy()),
+             dgamma=rel_err(be.host(DG), gg.numpy()), dbeta=rel_err(be.host(DB), gb.numpy()))
+    assert max(e.values()) < 5e-4, e
+    return e

@@ -39,6 +39,17 @@ def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 30, 128, 1, True)
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, K, R, stride, pad, relu
+    (1, 7, 7, 64, 64, 3, 1, 1, 1),       # 3x3, ragged M, ReLU mask
+    (3, 6, 6, 64, 128, 1, 1, 0, 1),      # batch 3: pixel tiles straddle images (per-image coefficients)
+    (2, 8, 8, 64, 64, 3, 2, 1, 1),       # stride 2
+    (1, 8, 8, 128, 256, 1, 2, 0, 0),     # downsample flavour: no ReLU, dm aliases dout
+])
+def test_conv_gn_bwd_fused(be, cfg):
+    K.case_conv_gn_bwd_fused(be, *cfg, seed=sum(cfg))
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)

@@ -45,6 +45,18 @@ def test_groupnorm(be, cfg):
     K.case_groupnorm(be, *cfg)
 
 
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_gn_bwd_fused_all_resnet_shapes(be, shape):
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv_gn_bwd_fused(be, 1, H, W, C, Kc, R, st, pad, relu=0 if (R == 1 and st == 2) else 1, seed=H + C + Kc + 1)
+
+
+@pytest.mark.parametrize("shape", [(56, 56, 64, 64, 3, 1, 1), (14, 14, 1024, 2048, 1, 2, 0), (7, 7, 512, 512, 3, 1, 1)])
+def test_conv_gn_bwd_fused_batch5(be, shape):
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv_gn_bwd_fused(be, 5, H, W, C, Kc, R, st, pad, seed=9)
+
+
 def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 784, 512, 4, True)
     K.case_groupnorm_fold(be, 1, 49, 2048, 36, False)
