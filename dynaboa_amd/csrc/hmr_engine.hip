@@ -7,6 +7,7 @@
 //   * a workspace (split-K slabs, norm partials, three gradient buffers, per-layer masked gradients).
 // One C call = one whole forward (or backward): ~180 (~330) stream-ordered launches, no host
 // syncs, no allocation, capturable in a hipGraph.  PyTorch only owns the memory and the stream.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -108,6 +109,7 @@ struct HmrPlan {
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
   int graph_mode;
+  int fold_in_reduce;          // leave data-gradient split-K slabs for the next GroupNorm-backward reduce to fold
   long g_hits, g_eager, g_captures, g_fail_begin, g_fail_body, g_fail_end, g_fail_inst, g_fail_launch;
   // cross-stream ordering for the weight-gradient convolutions (created on first use)
   std::vector<hipEvent_t> ev_dy;
@@ -202,6 +204,10 @@ static HmrPlan* build_plan(int B, int H, int W) {
   size_t wc = 0, wg = 0, maxact = 0, dyoff = 0, gnboff = 0;
   P.events_ready = false;
   P.graph_mode = 0;
+  {
+    const char* e = getenv("DYB_FOLD_IN_REDUCE");
+    P.fold_in_reduce = e ? atoi(e) : 1;     // measured 1.55 vs 1.75 ms per backward
+  }
   P.g_hits = P.g_eager = P.g_captures = 0;
   P.g_fail_begin = P.g_fail_body = P.g_fail_end = P.g_fail_inst = P.g_fail_launch = 0;
   for (auto& c : P.convs) {
@@ -465,21 +471,33 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   return DYB_OK;
 }
 
+// A gradient tensor that may still be spread over the split-K slabs of the data-gradient convolution
+// that produced it (plus an addend, the residual-edge gradient): the next GroupNorm-backward reduce
+// folds it while it reads it, which removes the stand-alone fold launch from the critical chain.
+struct Pending {
+  const float* base;
+  int nslabs;
+  size_t stride;
+  const float* addend;
+};
+static Pending plain(const float* p) { return Pending{p, 1, 0, nullptr}; }
+
 // GroupNorm backward of layer ci, reduce half only: dm = din masked by the layer's ReLU lands in the
-// layer's own slot of the dm arena (relu == 0: dm aliases din, which then must itself be such a slot),
-// the partial sums in the layer's slot of the gnb arena.  dy = rstd*(gamma*dm - c1 - xhat*c2) is
-// never materialised: the data-gradient conv below and the weight-gradient conv form it in their
-// operand loaders.  The weight gradient (which also writes dgamma / dbeta) is off the critical path,
-// so it goes to the auxiliary stream when given, ordered by one event per layer, with its own split-K
-// slab region; everything it reads lives in per-layer slots that nothing overwrites during the call.
+// layer's own slot of the dm arena (relu == 0 and din plain: dm aliases din, which then must itself be
+// such a slot), the partial sums in the layer's slot of the gnb arena.  dy = rstd*(gamma*dm - c1 -
+// xhat*c2) is never materialised: the data-gradient conv below and the weight-gradient conv form it in
+// their operand loaders.  The weight gradient (which also writes dgamma / dbeta) is off the critical
+// path, so it goes to the auxiliary stream when given, ordered by one event per layer, with its own
+// split-K slab region; everything it reads lives in per-layer slots that nothing overwrites during the call.
 static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
-                        const float* din, int relu, const float** dm_out, const WsCarve& w, hipStream_t st,
+                        const Pending& din, int relu, const float** dm_out, const WsCarve& w, hipStream_t st,
                         hipStream_t aux) {
   const ConvL& c = P.convs[ci];
-  float* dm = relu ? w.dy + c.dy : const_cast<float*>(din);
+  const bool alias = !relu && din.nslabs == 1 && !din.addend;
+  float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
-  RUN(dyb_groupnorm_bwd_reduce(din, acts + c.out, acts + c.y, acts + c.stats, params + c.gam, dm, part, P.B, c.Ho * c.Wo,
-                               c.K, relu, st));
+  RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, acts + c.out, acts + c.y, acts + c.stats,
+                              params + c.gam, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st));
   hipStream_t ws_st = st;
   void* slabs = w.conv;
   if (aux) {
@@ -493,12 +511,21 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
   *dm_out = dm;
   return DYB_OK;
 }
-// data gradient of layer ci from its dm: dx_buf = conv_transpose(dy, w) (+ addend)
+// data gradient of layer ci from its dm: conv_transpose(dy, w) (+ addend), materialised in dx_buf or -
+// when `out` is given and the policy splits K - left as slabs (+ the addend) for the next reduce
 static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* acts, const float* dm, float* dx_buf,
-                       const float* addend, const WsCarve& w, hipStream_t st) {
+                       const float* addend, Pending* out, const WsCarve& w, hipStream_t st) {
   const ConvL& c = P.convs[ci];
-  return dyb_conv2d_nhwc_dgrad_gn(dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, params + c.w, dx_buf, addend,
-                                  P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv, P.ws_conv, st);
+  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
+  GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam};
+  int ns = 1;
+  RUN(dyb_conv_dgrad_gn_raw(d, src, params + c.w, dx_buf, addend, w.conv, P.ws_conv, (out && P.fold_in_reduce) ? &ns : nullptr,
+                            st));
+  if (out) {
+    if (ns > 1) *out = Pending{reinterpret_cast<const float*>(w.conv), ns, (size_t)P.B * c.H * c.W * c.C, addend};
+    else *out = plain(dx_buf);
+  }
+  return DYB_OK;
 }
 
 // d_rotmat: [B][24][9]; d_state: [B][160], only columns 144..156 (shape, cam) are read.
@@ -565,35 +592,44 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   // dm of its third GroupNorm (the ReLU-masked incoming gradient), used in place.
   float *D0 = w.g[0], *D1 = w.g[1], *Rb = w.g[2];
   RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, D0, B, P.featHW, FEAT, st));
-  float* cur = D0;
+  Pending cur = plain(D0);
+  float* free_buf = D1;          // the D buffer `cur` does not occupy (a pending `cur` lives in the slab region)
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
     const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
-    float* nxt = (cur == D0) ? D1 : D0;
+    float* other = (free_buf == D0) ? D1 : D0;
     const float *dm3, *dm2, *dm1, *dmd;
+    Pending p3, p2, pout;
     // out = relu(gn3(conv3(a2)) + res)
     RUN(layer_gn_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, 1, &dm3, w, st, aux));
-    RUN(layer_dgrad(P, b.c3, params, acts, dm3, nxt, nullptr, w, st));
-    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, nxt, 1, &dm2, w, st, aux));
-    RUN(layer_dgrad(P, b.c2, params, acts, dm2, cur, nullptr, w, st));
-    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, cur, 1, &dm1, w, st, aux));
+    RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st));
+    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, p3, 1, &dm2, w, st, aux));
+    RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st));      // `cur` was consumed by the c3 reduce
+    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, p2, 1, &dm1, w, st, aux));
     if (b.cd >= 0) {
-      // shortcut branch: GroupNorm without ReLU on the residual-edge gradient
-      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, dm3, 0, &dmd, w, st, aux));
-      RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, w, st));
-      RUN(layer_dgrad(P, b.c1, params, acts, dm1, nxt, Rb, w, st));
+      // shortcut branch: GroupNorm without ReLU on the residual-edge gradient; its data gradient is materialised
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, plain(dm3), 0, &dmd, w, st, aux));
+      RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st));
+      RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, Rb, &pout, w, st));
     } else {
-      RUN(layer_dgrad(P, b.c1, params, acts, dm1, nxt, dm3, w, st));
+      RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, dm3, &pout, w, st));
     }
-    cur = nxt;
+    cur = pout;
+    if (cur.nslabs == 1) free_buf = other;       // cur sits in the old free buffer
   }
-  // ---- stem: maxpool backward -> GN/ReLU -> conv1 (no data gradient for the image)
+  // ---- stem: maxpool backward needs the gradient materialised -> GN/ReLU -> conv1 (no data gradient for the image)
   const ConvL& stem = P.convs[0];
-  float* gstem = (cur == D0) ? D1 : D0;
-  RUN(dyb_maxpool3x3s2_bwd(cur, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), gstem, B, stem.Ho, stem.Wo, stem.K, st));
+  const float* gpool = cur.base;
+  float* spare = free_buf;
+  if (cur.nslabs > 1) {
+    RUN(dyb_splitk_fold(cur.base, cur.nslabs, (size_t)B * P.poolH * P.poolW * stem.K, cur.addend, free_buf, st));
+    gpool = free_buf;
+    spare = (free_buf == D0) ? D1 : D0;
+  }
+  RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), spare, B, stem.Ho, stem.Wo, stem.K, st));
   const float* dm0;
-  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, gstem, 1, &dm0, w, st, aux));
+  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, plain(spare), 1, &dm0, w, st, aux));
   if (aux) {
     if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;

@@ -23,6 +23,8 @@
 // register set - two steps in flight - measured no gain and cost half the occupancy).  At batch 1
 // most layers have only 1..50 output tiles, so the K loop is split over blockIdx.z into fp32 slabs
 // that a second kernel (or the GroupNorm statistics kernel) folds - deterministic, no atomics.
+#include <stdlib.h>
+
 #include "dyb_common.h"
 
 #define BM 64
@@ -476,24 +478,36 @@ static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
   return DYB_OK;
 }
 
-// Split-K policy from measurements on MI355X at these sizes: a K-step costs ~0.5 us of exposed
-// latency, a dependent launch ~5.8 us (the stand-alone fold that dgrad / wgrad need), an extra slab
-// ~0.15 us inside the GroupNorm statistics kernel that folds the forward's slabs for free.
-//   backward modes: t(s) = ktiles/s * 0.5 + (s > 1 ? 5.8 + 0.1 s : 0)  -> never split below ~16 K-steps
-//   forward       : t(s) = ktiles/s * 0.5 + 0.15 s
-// bounded so that the grid stays <= ~1024 workgroups and every split keeps >= 2 K-steps.
-static int choose_split(const IgemmArgs& g, size_t ws_floats, int mode) {
+// Split-K policy, a small cost model fitted to measurements on MI355X at these sizes (the sweep is
+// tools/ab_split.sh; the landscape is flat within ~4 % around these values):
+//   a K-step costs ~0.5 us of exposed latency;
+//   forward       : the GroupNorm statistics kernel folds the slabs for ~0.15 us per slab;
+//   backward, raw : the next GroupNorm-backward reduce folds them for ~0.2 + 0.05 us per slab;
+//   backward, stand-alone fold launch (public entry points, shortcut branch): ~5.8 us + 0.1 per slab.
+// Bounded so that the grid stays <= ~1024 workgroups and every split keeps >= 2 K-steps.  The DYB_*
+// environment variables exist for that sweep only.
+static float env_float(const char* name, float dflt) {
+  const char* v = getenv(name);
+  return v ? (float)atof(v) : dflt;
+}
+// `raw`: the consumer folds the slabs itself (forward: GroupNorm statistics; backward: the next
+// GroupNorm-backward reduce), so a split costs per-slab read time there instead of a launch.
+static int choose_split(const IgemmArgs& g, size_t ws_floats, int mode, bool raw = false) {
+  static const float fold_us = env_float("DYB_BWD_FOLD_US", 5.8f), raw_fold_us = env_float("DYB_RAW_FOLD_US", 0.2f),
+                     raw_slab_us = env_float("DYB_RAW_SLAB_US", 0.05f), kstep_us = env_float("DYB_KSTEP_US", 0.5f),
+                     fwd_slab_us = env_float("DYB_FWD_SLAB_US", 0.15f);
+  static const int grid_cap = (int)env_float("DYB_GRID_CAP", 1024.f), min_steps = (int)env_float("DYB_MIN_STEPS", 2.f);
   int tiles = dyb_cdiv(g.M, BM) * dyb_cdiv(g.Ncols, BN);
-  int maxs = g.ktiles / 2;
+  int maxs = g.ktiles / (min_steps > 0 ? min_steps : 1);
   if (maxs < 1) maxs = 1;
-  int gridcap = 1024 / tiles;
+  int gridcap = grid_cap / tiles;
   if (gridcap < 1) gridcap = 1;
   if (maxs > gridcap) maxs = gridcap;
   int best = 1;
-  float bt = 0.5f * g.ktiles;
+  float bt = kstep_us * g.ktiles;
   for (int s = 2; s <= maxs; ++s) {
     float steps = (float)dyb_cdiv(g.ktiles, s);
-    float t = 0.5f * steps + (mode == MODE_FWD ? 0.15f * s : 5.8f + 0.1f * s);
+    float t = kstep_us * steps + (mode == MODE_FWD ? fwd_slab_us * s : raw ? raw_fold_us + raw_slab_us * s : fold_us + 0.1f * s);
     if (t < bt - 0.25f) { bt = t; best = s; }
   }
   size_t per = (size_t)g.M * g.Ncols;
@@ -509,6 +523,8 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
     IgemmArgs g{};
     if (fill_args(g, d, mode) != DYB_OK) return 0;
     int s = choose_split(g, (size_t)-1 / 8, mode);
+    int sr = choose_split(g, (size_t)-1 / 8, mode, true);
+    if (sr > s) s = sr;
     size_t need = (s > 1) ? (size_t)s * g.M * g.Ncols * sizeof(float) : 0;
     if (need > best) best = need;
   }
@@ -525,7 +541,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   int rc = fill_args(g, d, mode);
   if (rc != DYB_OK) return rc;
   g.A = A; g.B = B;
-  g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode);
+  g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode, raw_slabs_out != nullptr && mode != MODE_FWD);
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits
   if (raw_slabs_out) *raw_slabs_out = 1;
@@ -616,4 +632,21 @@ extern "C" int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const f
   int rc = make_fuse(f, d, y_gn, stats, part, gamma, dgamma, dbeta);
   if (rc != DYB_OK) return rc;
   return run_igemm(MODE_WGRAD, d, x, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f);
+}
+int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w, float* dx, const float* addend, void* ws,
+                          size_t ws_bytes, int* nslabs, hipStream_t st) {
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr);
+  if (rc != DYB_OK) return rc;
+  return run_igemm(MODE_DGRAD, d, src.dm, w, dx, addend, ws, ws_bytes, nslabs, st, &f);
+}
+// out = sum_z slabs[z] (+ addend) over n floats (n % 4 == 0)
+int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st) {
+  size_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
+                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
 }

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const int cqg = C >> 4;
   const int g = cq / cqg;
   const float mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + (size_t)cq * 4);   // used after the loop: load it early
   const int row0 = chunk * rows_per_chunk;
   int row1 = row0 + rows_per_chunk;
   if (row1 > HW) row1 = HW;
@@ -244,8 +245,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     b[2] += d.z * ((v.z - mean) * rstd); b[3] += d.w * ((v.w - mean) * rstd);
   };
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool fold = nslabs > 1 || addend != nullptr;
   int row = row0 + ty;
-  if (!folded) {
+  if (!fold) {
     // plain gradient: two rows (six 16-byte loads) in flight per iteration - the loop is latency-bound
     for (; row + TY < row1; row += 2 * TY) {
       size_t o0 = ((size_t)n * HW + row) * C + (size_t)cq * 4, o1 = o0 + (size_t)TY * C;
@@ -261,27 +263,28 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 d = *reinterpret_cast<const float4*>(dout + off);
     float4 v = *reinterpret_cast<const float4*>(y + off);
-    if (folded) {
-      float4 d1 = make_float4(0.f, 0.f, 0.f, 0.f), d2 = d1;
+    float4 q = relu ? *reinterpret_cast<const float4*>(out + off) : zero4;
+    if (fold) {
+      // three independent accumulators keep four slab loads in flight
+      float4 d1 = addend ? *reinterpret_cast<const float4*>(addend + off) : zero4;
+      float4 d2 = zero4, d3 = zero4;
       int z = 1;
-      for (; z + 1 < nslabs; z += 2) {
+      for (; z + 2 < nslabs; z += 3) {
         float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
-        float4 q = *reinterpret_cast<const float4*>(dout + (size_t)(z + 1) * slab_stride + off);
+        float4 r = *reinterpret_cast<const float4*>(dout + (size_t)(z + 1) * slab_stride + off);
+        float4 t = *reinterpret_cast<const float4*>(dout + (size_t)(z + 2) * slab_stride + off);
         d1.x += p.x; d1.y += p.y; d1.z += p.z; d1.w += p.w;
-        d2.x += q.x; d2.y += q.y; d2.z += q.z; d2.w += q.w;
+        d2.x += r.x; d2.y += r.y; d2.z += r.z; d2.w += r.w;
+        d3.x += t.x; d3.y += t.y; d3.z += t.z; d3.w += t.w;
       }
-      if (z < nslabs) {
+      for (; z < nslabs; ++z) {
         float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
-        d1.x += p.x; d1.y += p.y; d1.z += p.z; d1.w += p.w;
+        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
       }
-      if (addend) {
-        float4 p = *reinterpret_cast<const float4*>(addend + off);
-        d2.x += p.x; d2.y += p.y; d2.z += p.z; d2.w += p.w;
-      }
-      d.x += d1.x + d2.x; d.y += d1.y + d2.y; d.z += d1.z + d2.z; d.w += d1.w + d2.w;
-      *reinterpret_cast<float4*>(folded + off) = d;
+      d.x += (d1.x + d2.x) + d3.x; d.y += (d1.y + d2.y) + d3.y; d.z += (d1.z + d2.z) + d3.z; d.w += (d1.w + d2.w) + d3.w;
+      if (folded) *reinterpret_cast<float4*>(folded + off) = d;
     }
-    accumulate(d, v, relu ? *reinterpret_cast<const float4*>(out + off) : zero4, off);
+    accumulate(d, v, q, off);
   }
   float* mine = sm + threadIdx.x * 8;
 #pragma unroll
@@ -296,7 +299,6 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     float* p = partials + ((size_t)n * nchunks + chunk) * 2 * C + (size_t)cq * 4;
     *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
     *reinterpret_cast<float4*>(p + C) = make_float4(b[0], b[1], b[2], b[3]);
-    float4 ga = *reinterpret_cast<const float4*>(gamma + (size_t)cq * 4);
     sg[tx][0] = (ga.x * a[0] + ga.y * a[1]) + (ga.z * a[2] + ga.w * a[3]);
     sg[tx][1] = (ga.x * b[0] + ga.y * b[1]) + (ga.z * b[2] + ga.w * b[3]);
   }
@@ -473,8 +475,17 @@ extern "C" size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C) {
 extern "C" int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
                                         const float* gamma, float* dm, float* part, int N, int HW, int C, int relu,
                                         hipStream_t st) {
-  DYB_REQUIRE(dout && y && stats && gamma && dm && part, DYB_ERR_ARG);
+  return dyb_gn_bwd_reduce_slabs(dout, 1, 0, nullptr, out, y, stats, gamma, dm, part, N, HW, C, relu, st);
+}
+// same, the incoming gradient being sum_z dout[z*slab_stride + .] (+ addend): the un-folded split-K slabs
+// of the data-gradient convolution that produced it plus the residual-edge gradient (dm != dout required
+// then); saves the stand-alone fold launch on the critical chain.
+int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, const float* addend, const float* out,
+                            const float* y, const float* stats, const float* gamma, float* dm, float* part, int N, int HW,
+                            int C, int relu, hipStream_t st) {
+  DYB_REQUIRE(dout && y && stats && gamma && dm && part && nslabs >= 1, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
+  DYB_REQUIRE(!(nslabs > 1 || addend) || dm != dout, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   int nch, ncolb;
   dyb_gn_bwd_layout(N, HW, C, &nch, &ncolb);
@@ -482,7 +493,7 @@ extern "C" int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, con
   int TX = CQ < 256 ? CQ : 256;
   int rows = dyb_cdiv(HW, nch);
   float* gpart = part + (size_t)N * nch * 2 * C;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, 1, (size_t)0, (const float*)nullptr,
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
                      (float*)nullptr, dm == dout ? (float*)nullptr : dm, out, y, stats, gamma, part, gpart, HW, C, rows, relu,
                      TX);
   DYB_CHECK_LAUNCH();
