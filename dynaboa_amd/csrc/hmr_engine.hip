@@ -2,8 +2,9 @@
 // regressor of reference model/hmr.py:63-181, forward and backward, over
 //   * ONE flat fp32 parameter arena (conv weights re-laid [R][S][Cin][Cout], fc1 rows padded to
 //     2208, the three decoder heads fused into one [160][1024] matrix),
-//   * ONE activation arena per forward call (every conv output + every GroupNorm output is kept:
-//     that is exactly what backward needs; 22.2 M floats = 89 MB per image),
+//   * ONE activation arena per forward call: every raw conv output y (what backward needs) plus the
+//     block outputs; the GroupNorm+ReLU outputs INSIDE a bottleneck (bn1, bn2, downsample.1) have a
+//     single consumer and are never written - that consumer normalises y on the fly in its loader,
 //   * a workspace (split-K slabs, norm partials, three gradient buffers, per-layer masked gradients).
 // One C call = one whole forward (or backward): ~180 (~330) stream-ordered launches, no host
 // syncs, no allocation, capturable in a hipGraph.  PyTorch only owns the memory and the stream.
@@ -20,8 +21,12 @@
 extern "C" {
 size_t dyb_conv2d_workspace_bytes(int, int, int, int, int, int, int, int, int);
 size_t dyb_groupnorm_workspace_bytes(int, int, int);
-int dyb_groupnorm_fwd(const float*, int, float*, const float*, const float*, const float*, float*, float*, int, int, int,
-                      int, void*, size_t, hipStream_t);
+int dyb_groupnorm_stats(const float*, int, float*, float*, int, int, int, hipStream_t);
+int dyb_groupnorm_apply(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                        const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+int dyb_conv2d_nhwc_wgrad_gn_gnin(const float*, const float*, const float*, const float*, int, const float*, const float*,
+                                  const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int,
+                                  int, int, int, int, void*, size_t, hipStream_t);
 size_t dyb_groupnorm_bwd_partial_floats(int, int, int);
 int dyb_groupnorm_bwd_reduce(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int,
                              int, int, hipStream_t);
@@ -65,6 +70,7 @@ struct ConvL {
   int H, W, C, K, R, S, stride, pad, Ho, Wo;
   size_t w, gam, bet;          // parameter offsets
   size_t y, out, stats;        // activation offsets (conv output, normalised output, [B][4][2])
+  bool has_out;                // false: the normalised output is never materialised (out is invalid)
   size_t dy;                   // offset (floats) of this layer's masked GroupNorm-output gradient in the workspace dm arena
   size_t gnb;                  // offset (floats) of this layer's GroupNorm-backward partial sums in the workspace
 };
@@ -121,7 +127,7 @@ struct HmrPlan {
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 static int add_conv(HmrPlan& P, const std::string& cname, const std::string& nname, int H, int W, int Cin_ref, int Cout,
-                    int k, int stride, int pad, size_t& poff, size_t& aoff) {
+                    int k, int stride, int pad, size_t& poff, size_t& aoff, bool keep_out) {
   ConvL c{};
   int cin_pad = Cin_ref < 4 ? 4 : Cin_ref;
   c.H = H; c.W = W; c.C = cin_pad; c.K = Cout; c.R = k; c.S = k; c.stride = stride; c.pad = pad;
@@ -138,7 +144,9 @@ static int add_conv(HmrPlan& P, const std::string& cname, const std::string& nna
   poff = align64(poff + Cout);
   size_t n = (size_t)P.B * c.Ho * c.Wo * Cout;
   c.y = aoff; aoff = align64(aoff + n);
-  c.out = aoff; aoff = align64(aoff + n);
+  c.has_out = keep_out;
+  c.out = aoff;
+  if (keep_out) aoff = align64(aoff + n);
   c.stats = aoff; aoff = align64(aoff + (size_t)P.B * DYB_GN_GROUPS * 2);
   P.convs.push_back(c);
   return (int)P.convs.size() - 1;
@@ -150,7 +158,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.B = B; P.H = H; P.W = W;
   size_t poff = 0, aoff = 0;
   P.a_x4 = aoff; aoff = align64(aoff + (size_t)B * H * W * 4);
-  int stem = add_conv(P, "conv1", "bn1", H, W, 3, 64, 7, 2, 3, poff, aoff);
+  int stem = add_conv(P, "conv1", "bn1", H, W, 3, 64, 7, 2, 3, poff, aoff, true);
   int h = P.convs[stem].Ho, w = P.convs[stem].Wo;
   P.poolH = (h + 2 - 3) / 2 + 1;
   P.poolW = (w + 2 - 3) / 2 + 1;
@@ -164,14 +172,14 @@ static HmrPlan* build_plan(int B, int H, int W) {
       std::string pre = "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
       int stride = (bi == 0 && li > 0) ? 2 : 1;
       BlockL b{};
-      b.c1 = add_conv(P, pre + "conv1", pre + "bn1", h, w, inplanes, planes[li], 1, 1, 0, poff, aoff);
-      b.c2 = add_conv(P, pre + "conv2", pre + "bn2", h, w, planes[li], planes[li], 3, stride, 1, poff, aoff);
+      b.c1 = add_conv(P, pre + "conv1", pre + "bn1", h, w, inplanes, planes[li], 1, 1, 0, poff, aoff, false);
+      b.c2 = add_conv(P, pre + "conv2", pre + "bn2", h, w, planes[li], planes[li], 3, stride, 1, poff, aoff, false);
       int h2 = P.convs[b.c2].Ho, w2 = P.convs[b.c2].Wo;
-      b.c3 = add_conv(P, pre + "conv3", pre + "bn3", h2, w2, planes[li], planes[li] * 4, 1, 1, 0, poff, aoff);
+      b.c3 = add_conv(P, pre + "conv3", pre + "bn3", h2, w2, planes[li], planes[li] * 4, 1, 1, 0, poff, aoff, true);
       b.cd = -1;
       if (bi == 0)
         b.cd = add_conv(P, pre + "downsample.0", pre + "downsample.1", h, w, inplanes, planes[li] * 4, 1, stride, 0, poff,
-                        aoff);
+                        aoff, false);
       P.blocks.push_back(b);
       inplanes = planes[li] * 4;
       h = h2; w = w2;
@@ -236,7 +244,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_conv_aux + P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
   return pp;
 }
 
@@ -312,7 +320,8 @@ extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long l
   } while (0)
 
 struct WsCarve {
-  char *conv, *conv_aux, *gn, *lin;
+  char *conv, *conv_aux, *lin;
+  float* gn[3];                // forward GroupNorm partials: two alternating slots for the main branch, one for the shortcut
   float* gnb;
   float* g[3];
   float* dy;
@@ -323,7 +332,7 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   char* b = reinterpret_cast<char*>(ws);
   c.conv = b; b += P.ws_conv;
   c.conv_aux = b; b += P.ws_conv_aux;
-  c.gn = b; b += P.ws_gn;
+  for (int i = 0; i < 3; ++i) { c.gn[i] = reinterpret_cast<float*>(b); b += P.ws_gn; }
   c.gnb = reinterpret_cast<float*>(b); b += P.ws_gnb;
   c.lin = b; b += P.ws_lin;
   for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
@@ -332,14 +341,18 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   return c;
 }
 
-static int conv_gn(const HmrPlan& P, const ConvL& c, const float* params, float* acts, const float* x, const float* res,
-                   int relu, const WsCarve& w, hipStream_t st) {
+// conv (+ the producer's GroupNorm/ReLU applied in its loader when `prev` is given) -> statistics of
+// its raw output into `part_out`
+static int conv_stats(const HmrPlan& P, const ConvL& c, const float* params, float* acts, const float* x, const ConvL* prev,
+                      const float* part_prev, float* part_out, const WsCarve& w, hipStream_t st) {
   ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
   int nslabs = 1;
-  RUN(dyb_conv_fwd_raw(d, x, params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
-  RUN(dyb_groupnorm_fwd(reinterpret_cast<const float*>(w.conv), nslabs, acts + c.y, params + c.gam, params + c.bet, res,
-                        acts + c.out, acts + c.stats, P.B, c.Ho * c.Wo, c.K, relu, w.gn, P.ws_gn, st));
-  return DYB_OK;
+  if (prev)
+    RUN(dyb_conv_fwd_gnin_raw(d, acts + prev->y, part_prev, params + prev->gam, params + prev->bet, 1, acts + prev->stats,
+                              params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
+  else
+    RUN(dyb_conv_fwd_raw(d, x, params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
+  return dyb_groupnorm_stats(reinterpret_cast<const float*>(w.conv), nslabs, acts + c.y, part_out, P.B, c.Ho * c.Wo, c.K, st);
 }
 
 extern "C" int dyb_hmr_set_graph_mode(void* plan, int on) {
@@ -433,21 +446,28 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
                         const WsCarve& w, hipStream_t st) {
   const int B = P.B;
   const ConvL& stem = P.convs[0];
-  RUN(conv_gn(P, stem, params, acts, acts + P.a_x4, nullptr, 1, w, st));
+  RUN(conv_stats(P, stem, params, acts, acts + P.a_x4, nullptr, nullptr, w.gn[0], w, st));
+  RUN(dyb_groupnorm_apply(acts + stem.y, w.gn[0], params + stem.gam, params + stem.bet, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, acts + stem.out, acts + stem.stats, B, stem.Ho * stem.Wo, stem.K, 1, st));
   RUN(dyb_maxpool3x3s2_fwd(acts + stem.out, acts + P.a_pool, reinterpret_cast<uint32_t*>(acts + P.a_poolidx), B, stem.Ho,
                            stem.Wo, stem.K, st));
   const float* x = acts + P.a_pool;
   for (const BlockL& b : P.blocks) {
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
-    RUN(conv_gn(P, c1, params, acts, x, nullptr, 1, w, st));
-    RUN(conv_gn(P, c2, params, acts, acts + c1.out, nullptr, 1, w, st));
-    const float* res = x;
+    // 3 launches per conv become 2: bn1 / bn2 (+ReLU) are applied by conv2 / conv3 while loading
+    RUN(conv_stats(P, c1, params, acts, x, nullptr, nullptr, w.gn[0], w, st));
+    RUN(conv_stats(P, c2, params, acts, nullptr, &c1, w.gn[0], w.gn[1], w, st));
+    if (b.cd >= 0) RUN(conv_stats(P, P.convs[b.cd], params, acts, x, nullptr, nullptr, w.gn[2], w, st));
+    RUN(conv_stats(P, c3, params, acts, nullptr, &c2, w.gn[1], w.gn[0], w, st));
+    // out = relu(bn3(y3) + shortcut), the shortcut being x or downsample.1(yd) normalised on the fly
     if (b.cd >= 0) {
       const ConvL& cd = P.convs[b.cd];
-      RUN(conv_gn(P, cd, params, acts, x, nullptr, 0, w, st));
-      res = acts + cd.out;
+      RUN(dyb_groupnorm_apply(acts + c3.y, w.gn[0], params + c3.gam, params + c3.bet, acts + cd.y, w.gn[2], params + cd.gam,
+                              params + cd.bet, acts + cd.stats, acts + c3.out, acts + c3.stats, B, c3.Ho * c3.Wo, c3.K, 1, st));
+    } else {
+      RUN(dyb_groupnorm_apply(acts + c3.y, w.gn[0], params + c3.gam, params + c3.bet, x, nullptr, nullptr, nullptr, nullptr,
+                              acts + c3.out, acts + c3.stats, B, c3.Ho * c3.Wo, c3.K, 1, st));
     }
-    RUN(conv_gn(P, c3, params, acts, acts + c2.out, res, 1, w, st));
     x = acts + c3.out;
   }
   float* dsts[MAX_ITER];
@@ -490,14 +510,15 @@ static Pending plain(const float* p) { return Pending{p, 1, 0, nullptr}; }
 // path, so it goes to the auxiliary stream when given, ordered by one event per layer, with its own
 // split-K slab region; everything it reads lives in per-layer slots that nothing overwrites during the call.
 static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
-                        const Pending& din, int relu, const float** dm_out, const WsCarve& w, hipStream_t st,
-                        hipStream_t aux) {
+                        const ConvL* in_prev, const Pending& din, int relu, const float** dm_out, const WsCarve& w,
+                        hipStream_t st, hipStream_t aux) {
   const ConvL& c = P.convs[ci];
   const bool alias = !relu && din.nslabs == 1 && !din.addend;
   float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
-  RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, acts + c.out, acts + c.y, acts + c.stats,
-                              params + c.gam, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st));
+  // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
+  RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
+                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st));
   hipStream_t ws_st = st;
   void* slabs = w.conv;
   if (aux) {
@@ -506,8 +527,14 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
     ws_st = aux;
     slabs = w.conv_aux;
   }
-  RUN(dyb_conv2d_nhwc_wgrad_gn(conv_in, dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
-                               grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, ws_st));
+  if (in_prev)     // the conv's input was relu(gn(y_prev)), never materialised
+    RUN(dyb_conv2d_nhwc_wgrad_gn_gnin(acts + in_prev->y, acts + in_prev->stats, params + in_prev->gam, params + in_prev->bet, 1,
+                                      dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
+                                      grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv,
+                                      ws_st));
+  else
+    RUN(dyb_conv2d_nhwc_wgrad_gn(conv_in, dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
+                                 grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, ws_st));
   *dm_out = dm;
   return DYB_OK;
 }
@@ -602,14 +629,14 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
     const float *dm3, *dm2, *dm1, *dmd;
     Pending p3, p2, pout;
     // out = relu(gn3(conv3(a2)) + res)
-    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, acts + c2.out, cur, 1, &dm3, w, st, aux));
+    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, nullptr, &c2, cur, 1, &dm3, w, st, aux));
     RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st));
-    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, acts + c1.out, p3, 1, &dm2, w, st, aux));
+    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, aux));
     RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st));      // `cur` was consumed by the c3 reduce
-    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, p2, 1, &dm1, w, st, aux));
+    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, aux));
     if (b.cd >= 0) {
       // shortcut branch: GroupNorm without ReLU on the residual-edge gradient; its data gradient is materialised
-      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, plain(dm3), 0, &dmd, w, st, aux));
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, aux));
       RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st));
       RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, Rb, &pout, w, st));
     } else {
@@ -629,7 +656,7 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   }
   RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), spare, B, stem.Ho, stem.Wo, stem.K, st));
   const float* dm0;
-  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, plain(spare), 1, &dm0, w, st, aux));
+  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, nullptr, plain(spare), 1, &dm0, w, st, aux));
   if (aux) {
     if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;

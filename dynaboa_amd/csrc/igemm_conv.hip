@@ -52,7 +52,7 @@ struct IgemmArgs {
 
 // rows = output pixels, k = (r,s,c) with c fastest                       (fwd A)
 struct FwdARow {
-  int base_n, hi0, wi0;
+  int base_n, hi0, wi0, n;
   bool valid;
 };
 __device__ __forceinline__ FwdARow fwd_a_row(const IgemmArgs& g, int m) {
@@ -64,6 +64,7 @@ __device__ __forceinline__ FwdARow fwd_a_row(const IgemmArgs& g, int m) {
   int ho = t % g.Ho;
   int n = t / g.Ho;
   r.base_n = n * g.H * g.W;
+  r.n = n;
   r.hi0 = ho * g.stride - g.pad;
   r.wi0 = wo * g.stride - g.pad;
   return r;
@@ -80,6 +81,19 @@ __device__ __forceinline__ float4 fwd_a_load(const IgemmArgs& g, const FwdARow& 
       v = *reinterpret_cast<const float4*>(g.A + (((size_t)(row.base_n + hi * g.W + wi)) << g.logC) + c);
   }
   return v;
+}
+
+// float offset of that piece inside x[N][H][W][C], or -1 for a padding tap / out-of-range element
+__device__ __forceinline__ long fwd_a_off(const IgemmArgs& g, const FwdARow& row, int k) {
+  if (row.valid && k < g.Kdim) {
+    int rs = k >> g.logC;
+    int c = k & (g.C - 1);
+    int r = rs / g.S;
+    int s = rs - r * g.S;
+    int hi = row.hi0 + r, wi = row.wi0 + s;
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) return (long)((((size_t)(row.base_n + hi * g.W + wi)) << g.logC) + c);
+  }
+  return -1;
 }
 
 // rows = input pixels, k = (r,s,ko) with ko fastest                      (dgrad A)
@@ -209,12 +223,54 @@ __device__ __forceinline__ float4 gnb_apply(const Frag& f, const float* cf) {
   return r;
 }
 
-template <int MODE, bool GB>
-__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f) {
+__device__ __forceinline__ long wg_a_off(const IgemmArgs& g, const WgARow& row, int p) {
+  if (row.valid && p < g.Kdim) {
+    int wo = p % g.Wo;
+    int t = p / g.Wo;
+    int ho = t % g.Ho;
+    int n = t / g.Ho;
+    int hi = ho * g.stride - g.pad + row.r, wi = wo * g.stride - g.pad + row.s;
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) return (long)((((size_t)((n * g.H + hi) * g.W + wi)) << g.logC) + row.c);
+  }
+  return -1;
+}
+
+// ---- GroupNorm(+ReLU) of the PRODUCER applied in the operand loader ------------------------------
+// Inside a bottleneck the normalised activation relu(gn(y_prev)) has exactly one consumer, the next
+// conv (forward: its A operand; backward: the A operand of that conv's weight gradient), so it is
+// never written: the conv reads the producer's raw output y_prev and normalises on the fly.  Forward
+// launches fold the producer's per-chunk (sum, sum of squares) partials into (mean, rstd) in their
+// prologue (in double, as gn_apply does) and workgroup (0,0,0) saves them for backward; the
+// weight-gradient launch reads the saved ones.
+struct GnFwdFuse {
+  const float* partials;   // [N][nchunks][G][2]; NULL: use stats_in
+  const float* stats_in;   // [N][G][2]
+  const float* gamma;
+  const float* beta;
+  float* stats_out;        // [N][G][2] or NULL
+  int nchunks, HW;         // HW: pixels per image of the producer's output
+  float eps;
+  int relu;
+};
+__device__ __forceinline__ float4 gnf_apply(float4 y, float4 ga, float4 be, float mean, float rstd, int relu) {
+  float4 o;
+  o.x = fmaf((y.x - mean) * rstd, ga.x, be.x);
+  o.y = fmaf((y.y - mean) * rstd, ga.y, be.y);
+  o.z = fmaf((y.z - mean) * rstd, ga.z, be.z);
+  o.w = fmaf((y.w - mean) * rstd, ga.w, be.w);
+  if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+  return o;
+}
+__device__ __forceinline__ double igemm_shfl_xor_f64(double v, int m) { return __shfl_xor(v, m); }
+
+template <int MODE, bool GB, bool FA>
+__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f, GnFwdFuse nf) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
   __shared__ float s_coef[GB ? 64 * DYB_GN_GROUPS * 4 : 4];   // [n][g] -> mean, rstd, c1, c2
   __shared__ float s_raw[GB ? 64 * DYB_GN_GROUPS * 2 : 4];
+  __shared__ float s_nrm[FA ? 64 * DYB_GN_GROUPS * 2 : 4];     // [n][g] -> mean, rstd of the producer
+  __shared__ double s_rawd[FA ? 64 * DYB_GN_GROUPS * 2 : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -239,14 +295,34 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   if constexpr (MODE == MODE_DGRAD) da = dg_a_row(g, m0 + t_row);
   if constexpr (MODE == MODE_WGRAD) wa = wg_a_row(g, m0 + d_q);
   const int logKg = g.logK - 2;                                 // log2(channels per group)
+  const int logCg = g.logC - 2;
+  float4 wa_gamma = make_float4(0.f, 0.f, 0.f, 0.f), wa_beta = wa_gamma;
+  if constexpr (FA && MODE == MODE_WGRAD) {
+    if (wa.valid) {
+      wa_gamma = *reinterpret_cast<const float4*>(nf.gamma + wa.c);
+      wa_beta = *reinterpret_cast<const float4*>(nf.beta + wa.c);
+    }
+  }
   float4 wg_gamma = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (GB && MODE == MODE_WGRAD) {
     if (n0 + d_q < g.Ncols) wg_gamma = *reinterpret_cast<const float4*>(f.gamma + n0 + d_q);
   }
 
   auto load_a = [&](int kt, int h, Frag& o) {
-    if constexpr (MODE == MODE_FWD) o.d = fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
-    else if constexpr (MODE == MODE_DGRAD) {
+    if constexpr (MODE == MODE_FWD) {
+      if constexpr (FA) {
+        const int k = kt * BK + 16 * h + t_kq;
+        long off = fwd_a_off(g, fa, k);
+        o.ok = off >= 0;
+        if (o.ok) {
+          o.d = *reinterpret_cast<const float4*>(g.A + off);
+          o.v = *reinterpret_cast<const float4*>(nf.gamma + (k & (g.C - 1)));
+          o.ga = *reinterpret_cast<const float4*>(nf.beta + (k & (g.C - 1)));
+        }
+      } else {
+        o.d = fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
       if constexpr (GB) {
         long off = dg_a_off(g, da, kt * BK + 16 * h + t_kq);
         o.ok = off >= 0;
@@ -258,7 +334,15 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       } else {
         o.d = dg_a_load(g, da, kt * BK + 16 * h + t_kq);
       }
-    } else o.d = wg_a_load(g, wa, kt * BK + 16 * h + d_k);
+    } else {
+      if constexpr (FA) {
+        long off = wg_a_off(g, wa, kt * BK + 16 * h + d_k);
+        o.ok = off >= 0;
+        if (o.ok) o.d = *reinterpret_cast<const float4*>(g.A + off);
+      } else {
+        o.d = wg_a_load(g, wa, kt * BK + 16 * h + d_k);
+      }
+    }
   };
   auto load_b = [&](int kt, int h, Frag& o) {
     if constexpr (MODE == MODE_FWD) o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
@@ -280,9 +364,21 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto store_a = [&](int buf, int kt, int h, const Frag& o) {
     if constexpr (MODE == MODE_WGRAD) {
-      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = o.d;
+      float4 v = o.d;
+      if constexpr (FA) {
+        const int p = kt * BK + 16 * h + d_k;
+        const int n = g.N > 1 ? p / (g.Ho * g.Wo) : 0;
+        const float* st = &s_nrm[(n * DYB_GN_GROUPS + (wa.c >> logCg)) * 2];
+        v = o.ok ? gnf_apply(o.d, wa_gamma, wa_beta, st[0], st[1], nf.relu) : zero4;
+      }
+      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = v;
     } else {
       float4 v = o.d;
+      if constexpr (FA && MODE == MODE_FWD) {
+        const int c = (kt * BK + 16 * h + t_kq) & (g.C - 1);
+        const float* st = &s_nrm[(fa.n * DYB_GN_GROUPS + (c >> logCg)) * 2];
+        v = o.ok ? gnf_apply(o.d, o.v, o.ga, st[0], st[1], nf.relu) : zero4;
+      }
       if constexpr (GB && MODE == MODE_DGRAD) {
         const int ko = (kt * BK + 16 * h + t_kq) & (g.K - 1);
         v = o.ok ? gnb_apply(o, &s_coef[(da.n * DYB_GN_GROUPS + (ko >> logKg)) * 4]) : zero4;
@@ -345,6 +441,42 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       s_coef[i * 4 + 1] = f.stats[i * 2 + 1];
       s_coef[i * 4 + 2] = s_raw[i * 2];
       s_coef[i * 4 + 3] = s_raw[i * 2 + 1];
+    }
+    __syncthreads();
+  }
+
+  if constexpr (FA) {
+    const int nvals = g.N * DYB_GN_GROUPS * 2;
+    if (nf.partials) {
+      int L = 32;
+      while (L > 1 && L * nvals > 256) L >>= 1;
+      const int per_pass = 256 / L;
+      for (int base = 0; base < nvals; base += per_pass) {
+        const int v = base + tid / L, sub = tid % L;
+        double s = 0.0;
+        if (v < nvals) {
+          const float* pp = nf.partials + (size_t)(v >> 3) * nf.nchunks * 8 + (v & 7);
+          for (int k = sub; k < nf.nchunks; k += L) s += (double)pp[(size_t)k * 8];
+        }
+        for (int m = L >> 1; m >= 1; m >>= 1) s += igemm_shfl_xor_f64(s, m);
+        if (v < nvals && sub == 0) s_rawd[v] = s;
+      }
+      __syncthreads();
+      for (int i = tid; i < g.N * DYB_GN_GROUPS; i += 256) {
+        const double cnt = (double)nf.HW * (double)(g.C / DYB_GN_GROUPS);
+        const double mean = s_rawd[i * 2] / cnt;
+        double var = s_rawd[i * 2 + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)nf.eps));
+        s_nrm[i * 2] = m;
+        s_nrm[i * 2 + 1] = r;
+        if (nf.stats_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+          nf.stats_out[i * 2] = m;
+          nf.stats_out[i * 2 + 1] = r;
+        }
+      }
+    } else {
+      for (int i = tid; i < nvals; i += 256) s_nrm[i] = nf.stats_in[i];
     }
     __syncthreads();
   }
@@ -535,7 +667,8 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
 // in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
 static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B, float* out, const float* addend,
-                     void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st, const GnBwdFuse* fuse = nullptr) {
+                     void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st, const GnBwdFuse* fuse = nullptr,
+                     const GnFwdFuse* nfuse = nullptr) {
   DYB_REQUIRE(A && B && out, DYB_ERR_ARG);
   IgemmArgs g{};
   int rc = fill_args(g, d, mode);
@@ -550,14 +683,25 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   g.addend = split ? nullptr : addend;
   dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit);
   GnBwdFuse f{};
-  if (fuse) {
-    DYB_REQUIRE(mode != MODE_FWD && d.N <= 64, DYB_ERR_UNSUPPORTED);
-    f = *fuse;
-    if (mode == MODE_DGRAD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, true>), grid, dim3(256), 0, st, g, f);
-    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true>), grid, dim3(256), 0, st, g, f);
-  } else if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false>), grid, dim3(256), 0, st, g, f);
-  else if (mode == MODE_DGRAD) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, false>), grid, dim3(256), 0, st, g, f);
-  else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, false>), grid, dim3(256), 0, st, g, f);
+  GnFwdFuse nf{};
+  if (fuse) f = *fuse;
+  if (nfuse) nf = *nfuse;
+  DYB_REQUIRE(!(fuse || nfuse) || d.N <= 64, DYB_ERR_UNSUPPORTED);
+  const dim3 blk(256);
+  if (mode == MODE_FWD) {
+    DYB_REQUIRE(!fuse, DYB_ERR_UNSUPPORTED);
+    if (nfuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false, true>), grid, blk, 0, st, g, f, nf);
+    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false, false>), grid, blk, 0, st, g, f, nf);
+  } else if (mode == MODE_DGRAD) {
+    DYB_REQUIRE(!nfuse, DYB_ERR_UNSUPPORTED);
+    if (fuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, true, false>), grid, blk, 0, st, g, f, nf);
+    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, false, false>), grid, blk, 0, st, g, f, nf);
+  } else {
+    DYB_REQUIRE(!nfuse || fuse, DYB_ERR_UNSUPPORTED);
+    if (fuse && nfuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true, true>), grid, blk, 0, st, g, f, nf);
+    else if (fuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true, false>), grid, blk, 0, st, g, f, nf);
+    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, false, false>), grid, blk, 0, st, g, f, nf);
+  }
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
@@ -649,4 +793,48 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
                      reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+
+// ---- producer GroupNorm(+ReLU) applied in the loader (GnFwdFuse) ---------------------------------
+static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, const float* stats_in, const float* gamma,
+                       const float* beta, float* stats_out, int relu) {
+  nf.partials = partials; nf.stats_in = stats_in; nf.gamma = gamma; nf.beta = beta; nf.stats_out = stats_out;
+  nf.HW = d.H * d.W;
+  nf.nchunks = dyb_gn_fwd_chunks(d.N, nf.HW);
+  nf.eps = DYB_GN_EPS;
+  nf.relu = relu;
+}
+int dyb_conv_fwd_gnin_raw(const ConvDesc& d, const float* y_prev, const float* part_prev, const float* gamma_prev,
+                          const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y, void* ws,
+                          size_t ws_bytes, int* nslabs, hipStream_t st) {
+  DYB_REQUIRE(y_prev && part_prev && gamma_prev && beta_prev && d.C % 16 == 0, DYB_ERR_ARG);
+  GnFwdFuse nf{};
+  make_nfuse(nf, d, part_prev, nullptr, gamma_prev, beta_prev, stats_prev_out, relu_prev);
+  return run_igemm(MODE_FWD, d, y_prev, w, y, nullptr, ws, ws_bytes, nslabs, st, nullptr, &nf);
+}
+// y = conv(relu?(gn(y_prev)), w): y_prev is the producer's raw conv output [N][H][W][C], part_prev its
+// dyb_groupnorm_stats partials; the producer's (mean, rstd) are saved to stats_prev_out.
+extern "C" int dyb_conv2d_nhwc_fwd_gnin(const float* y_prev, const float* part_prev, const float* gamma_prev,
+                                        const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y,
+                                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                                        size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  return dyb_conv_fwd_gnin_raw(d, y_prev, part_prev, gamma_prev, beta_prev, relu_prev, stats_prev_out, w, y, ws, ws_bytes,
+                               nullptr, st);
+}
+// weight gradient of such a conv: A operand relu?(gn(y_prev)) formed on the fly from the saved
+// (mean, rstd) of the producer, B operand dy formed on the fly as in dyb_conv2d_nhwc_wgrad_gn.
+extern "C" int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                                             const float* beta_prev, int relu_prev, const float* dm, const float* y_gn,
+                                             const float* stats, const float* part, const float* gamma, float* dw,
+                                             float* dgamma, float* dbeta, int N, int H, int W, int C, int K, int R, int S,
+                                             int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(y_prev && stats_prev && gamma_prev && beta_prev && dgamma && dbeta && C % 16 == 0, DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, y_gn, stats, part, gamma, dgamma, dbeta);
+  if (rc != DYB_OK) return rc;
+  GnFwdFuse nf{};
+  make_nfuse(nf, d, nullptr, stats_prev, gamma_prev, beta_prev, nullptr, relu_prev);
+  return run_igemm(MODE_WGRAD, d, y_prev, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f, &nf);
 }

@@ -71,33 +71,54 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// The residual operand may itself be a GroupNorm (no ReLU) of a raw conv output - the shortcut
+// branch's downsample.1 - normalised here on the fly from its own partials instead of in a launch of
+// its own.
+struct GnResidual {
+  const float* y;          // plain residual, or the raw conv output to normalise when partials != NULL
+  const float* partials;   // [N][nchunks][G][2] or NULL
+  const float* gamma;
+  const float* beta;
+  float* stats;            // [N][G][2] saved (mean, rstd) of the residual's GroupNorm
+  int nchunks;
+};
+
 // grid (blocks_per_image, N), block 256
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ partials,
                                                        int nchunks, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       const float* __restrict__ beta, GnResidual rs,
                                                        float* __restrict__ out, float* __restrict__ stats, int HW, int C,
                                                        int relu, float eps) {
-  __shared__ float s_mean[G], s_rstd[G];
+  __shared__ float s_mean[2][G], s_rstd[2][G];
   const int n = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int CQ = C >> 2, cqg = C >> 4;
   const size_t total = (size_t)HW * CQ;
   const size_t base = (size_t)n * HW * C;
+  const float* res = rs.y;
+  const bool res_gn = rs.partials != nullptr;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // issue this thread's first element loads BEFORE the statistics prologue: the two memory round
   // trips (partials, data) then overlap instead of adding up (these kernels are latency-bound)
   const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), ga0 = v0, be0 = v0, r0 = v0;
+  float4 v0 = zero4, ga0 = zero4, be0 = zero4, r0 = zero4, rg0 = zero4, rb0 = zero4;
   if (i0 < total) {
     int cq = (int)(i0 % CQ);
     v0 = *reinterpret_cast<const float4*>(y + base + i0 * 4);
     ga0 = *reinterpret_cast<const float4*>(gamma + cq * 4);
     be0 = *reinterpret_cast<const float4*>(beta + cq * 4);
     if (res) r0 = *reinterpret_cast<const float4*>(res + base + i0 * 4);
+    if (res_gn) {
+      rg0 = *reinterpret_cast<const float4*>(rs.gamma + cq * 4);
+      rb0 = *reinterpret_cast<const float4*>(rs.beta + cq * 4);
+    }
   }
-  {
+  for (int which = 0; which < (res_gn ? 2 : 1); ++which) {
+    const float* pp = which ? rs.partials : partials;
+    const int nch = which ? rs.nchunks : nchunks;
     double a = 0.0, b = 0.0;
-    for (int ch = lane; ch < nchunks; ch += 64) {
-      const float* p = partials + (((size_t)n * nchunks + ch) * G + wave) * 2;
+    for (int ch = lane; ch < nch; ch += 64) {
+      const float* p = pp + (((size_t)n * nch + ch) * G + wave) * 2;
       a += (double)p[0];
       b += (double)p[1];
     }
@@ -109,11 +130,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       double var = b / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
       float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
-      s_mean[wave] = m;
-      s_rstd[wave] = r;
+      s_mean[which][wave] = m;
+      s_rstd[which][wave] = r;
       if (blockIdx.x == 0) {
-        stats[((size_t)n * G + wave) * 2 + 0] = m;
-        stats[((size_t)n * G + wave) * 2 + 1] = r;
+        float* so = which ? rs.stats : stats;
+        so[((size_t)n * G + wave) * 2 + 0] = m;
+        so[((size_t)n * G + wave) * 2 + 1] = r;
       }
     }
   }
@@ -121,21 +143,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     int cq = (int)(i % CQ);
     int g = cq / cqg;
-    float mean = s_mean[g], rstd = s_rstd[g];
-    float4 v, ga, be, r;
+    float mean = s_mean[0][g], rstd = s_rstd[0][g];
+    float4 v, ga, be, r, rg, rb;
     if (i == i0) {
-      v = v0; ga = ga0; be = be0; r = r0;
+      v = v0; ga = ga0; be = be0; r = r0; rg = rg0; rb = rb0;
     } else {
       v = *reinterpret_cast<const float4*>(y + base + i * 4);
       ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
       be = *reinterpret_cast<const float4*>(beta + cq * 4);
-      r = res ? *reinterpret_cast<const float4*>(res + base + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r = res ? *reinterpret_cast<const float4*>(res + base + i * 4) : zero4;
+      rg = res_gn ? *reinterpret_cast<const float4*>(rs.gamma + cq * 4) : zero4;
+      rb = res_gn ? *reinterpret_cast<const float4*>(rs.beta + cq * 4) : zero4;
     }
     float4 o;
-    o.x = (v.x - mean) * rstd * ga.x + be.x;
-    o.y = (v.y - mean) * rstd * ga.y + be.y;
-    o.z = (v.z - mean) * rstd * ga.z + be.z;
-    o.w = (v.w - mean) * rstd * ga.w + be.w;
+    o.x = fmaf((v.x - mean) * rstd, ga.x, be.x);
+    o.y = fmaf((v.y - mean) * rstd, ga.y, be.y);
+    o.z = fmaf((v.z - mean) * rstd, ga.z, be.z);
+    o.w = fmaf((v.w - mean) * rstd, ga.w, be.w);
+    if (res_gn) {
+      float rm = s_mean[1][g], rr = s_rstd[1][g];
+      r.x = fmaf((r.x - rm) * rr, rg.x, rb.x);
+      r.y = fmaf((r.y - rm) * rr, rg.y, rb.y);
+      r.z = fmaf((r.z - rm) * rr, rg.z, rb.z);
+      r.w = fmaf((r.w - rm) * rr, rg.w, rb.w);
+    }
     if (res) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
@@ -173,6 +204,46 @@ extern "C" size_t dyb_groupnorm_workspace_bytes(int N, int HW, int C) {
   return (fwd > bwd ? fwd : bwd) * sizeof(float);
 }
 
+int dyb_gn_fwd_chunks(int N, int HW) { return gn_chunks(HW, N); }
+
+// statistics half: folds the split-K slabs (nslabs > 1) into y and leaves per-chunk (sum, sum of
+// squares) partials [N][dyb_gn_fwd_chunks][G][2] in `partials`
+extern "C" int dyb_groupnorm_stats(const float* slabs, int nslabs, float* y, float* partials, int N, int HW, int C,
+                                   hipStream_t st) {
+  DYB_REQUIRE(y && partials, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(nslabs >= 1 && (nslabs == 1 || slabs), DYB_ERR_ARG);
+  int nch = gn_chunks(HW, N);
+  int rows = dyb_cdiv(HW, nch);
+  const float* src = nslabs > 1 ? slabs : y;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, N), dim3(256), 0, st, src, y, nslabs, (size_t)N * HW * C, partials, HW,
+                     C, rows);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// apply half: out = relu?(gn(y) + residual), the residual being absent (NULL), plain, or - when
+// res_partials != NULL - the GroupNorm (no ReLU) of the raw conv output `residual` with its own
+// partials / gamma / beta (its (mean, rstd) are saved to res_stats).
+extern "C" int dyb_groupnorm_apply(const float* y, const float* partials, const float* gamma, const float* beta,
+                                   const float* residual, const float* res_partials, const float* res_gamma,
+                                   const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C,
+                                   int relu, hipStream_t st) {
+  DYB_REQUIRE(y && partials && gamma && beta && out && stats, DYB_ERR_ARG);
+  DYB_REQUIRE(!res_partials || (residual && res_gamma && res_beta && res_stats), DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  int nch = gn_chunks(HW, N);
+  size_t total4 = (size_t)HW * (C / 4);
+  int bpi = (int)((total4 + 1023) / 1024);
+  int cap = 1024 / N > 1 ? 1024 / N : 1;
+  if (bpi > cap) bpi = cap;
+  if (bpi < 1) bpi = 1;
+  GnResidual rs{residual, res_partials, res_gamma, res_beta, res_stats, nch};
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, st, y, partials, nch, gamma, beta, rs, out, stats, HW, C,
+                     relu, DYB_GN_EPS);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
 // y: conv output [N][HW][C] (written here when nslabs > 1 from `slabs`), out: normalised result,
 // stats: [N][G][2] (mean, rstd) saved for backward.
 extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const float* gamma, const float* beta,
@@ -180,24 +251,13 @@ extern "C" int dyb_groupnorm_fwd(const float* slabs, int nslabs, float* y, const
                                  void* ws, size_t ws_bytes, hipStream_t st) {
   DYB_REQUIRE(y && gamma && beta && out && stats && ws, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
-  DYB_REQUIRE(nslabs >= 1 && (nslabs == 1 || slabs), DYB_ERR_ARG);
   int nch = gn_chunks(HW, N);
   DYB_REQUIRE(ws_bytes >= (size_t)N * nch * G * 2 * sizeof(float), DYB_ERR_WORKSPACE);
-  int rows = dyb_cdiv(HW, nch);
   float* partials = reinterpret_cast<float*>(ws);
-  const float* src = nslabs > 1 ? slabs : y;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, N), dim3(256), 0, st, src, y, nslabs, (size_t)N * HW * C, partials, HW,
-                     C, rows);
-  DYB_CHECK_LAUNCH();
-  size_t total4 = (size_t)HW * (C / 4);
-  int bpi = (int)((total4 + 1023) / 1024);
-  int cap = 1024 / N > 1 ? 1024 / N : 1;
-  if (bpi > cap) bpi = cap;
-  if (bpi < 1) bpi = 1;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, st, (const float*)y, (const float*)partials, nch,
-                     gamma, beta, residual, out, stats, HW, C, relu, DYB_GN_EPS);
-  DYB_CHECK_LAUNCH();
-  return DYB_OK;
+  int rc = dyb_groupnorm_stats(slabs, nslabs, y, partials, N, HW, C, st);
+  if (rc != DYB_OK) return rc;
+  return dyb_groupnorm_apply(y, partials, gamma, beta, residual, nullptr, nullptr, nullptr, nullptr, out, stats, N, HW, C,
+                             relu, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -217,7 +277,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ addend, float* __restrict__ folded,
                                                             float* __restrict__ dm, const float* __restrict__ out,
                                                             const float* __restrict__ y, const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, float* __restrict__ partials,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ partials,
                                                             float* __restrict__ gpart, int HW, int C, int rows_per_chunk,
                                                             int relu, int TX) {
   __shared__ float sm[256 * 8];
@@ -234,7 +295,15 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   int row1 = row0 + rows_per_chunk;
   if (row1 > HW) row1 = HW;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  // out == NULL with relu: the activation was never materialised (it was normalised on the fly by its
+  // one consumer); its sign is recomputed from y with exactly the consumer's expression
+  const bool mask_y = relu && out == nullptr;
+  const float4 be = mask_y ? *reinterpret_cast<const float4*>(beta + (size_t)cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   auto accumulate = [&](float4 d, float4 v, float4 o, size_t off) {
+    if (mask_y) {
+      o.x = fmaf((v.x - mean) * rstd, ga.x, be.x); o.y = fmaf((v.y - mean) * rstd, ga.y, be.y);
+      o.z = fmaf((v.z - mean) * rstd, ga.z, be.z); o.w = fmaf((v.w - mean) * rstd, ga.w, be.w);
+    }
     if (relu) {
       d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f;
       d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
@@ -253,8 +322,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       size_t o0 = ((size_t)n * HW + row) * C + (size_t)cq * 4, o1 = o0 + (size_t)TY * C;
       float4 d0 = *reinterpret_cast<const float4*>(dout + o0), d1 = *reinterpret_cast<const float4*>(dout + o1);
       float4 v0 = *reinterpret_cast<const float4*>(y + o0), v1 = *reinterpret_cast<const float4*>(y + o1);
-      float4 q0 = relu ? *reinterpret_cast<const float4*>(out + o0) : zero4;
-      float4 q1 = relu ? *reinterpret_cast<const float4*>(out + o1) : zero4;
+      float4 q0 = (relu && out) ? *reinterpret_cast<const float4*>(out + o0) : zero4;
+      float4 q1 = (relu && out) ? *reinterpret_cast<const float4*>(out + o1) : zero4;
       accumulate(d0, v0, q0, o0);
       accumulate(d1, v1, q1, o1);
     }
@@ -263,7 +332,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 d = *reinterpret_cast<const float4*>(dout + off);
     float4 v = *reinterpret_cast<const float4*>(y + off);
-    float4 q = relu ? *reinterpret_cast<const float4*>(out + off) : zero4;
+    float4 q = (relu && out) ? *reinterpret_cast<const float4*>(out + off) : zero4;
     if (fold) {
       // three independent accumulators keep four slab loads in flight
       float4 d1 = addend ? *reinterpret_cast<const float4*>(addend + off) : zero4;
@@ -444,8 +513,8 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   float* partials = reinterpret_cast<float*>(ws);
   float* gpart = partials + (size_t)N * nch * 2 * C;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout_slabs, nslabs, slab_stride, addend,
-                     fold ? folded : (float*)nullptr, (float*)nullptr, out, y, stats, gamma, partials, gpart, HW, C, rows, relu,
-                     TX);
+                     fold ? folded : (float*)nullptr, (float*)nullptr, out, y, stats, gamma, (const float*)nullptr, partials, gpart,
+                     HW, C, rows, relu, TX);
   DYB_CHECK_LAUNCH();
   const float* dsrc = fold ? folded : dout_slabs;
   size_t total4 = (size_t)N * HW * CQ;
@@ -471,20 +540,21 @@ extern "C" size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C) {
   return (size_t)N * nch * 2 * C + (size_t)N * nch * ncolb * G * 2;
 }
 // dm = dout masked by the ReLU (relu == 0: dm may equal dout, nothing is written then); part receives
-// the per-channel and per-group partial sums ([N*nch][2][C] | [N][nch*ncolb][G][2]).
+// the per-channel and per-group partial sums ([N*nch][2][C] | [N][nch*ncolb][G][2]).  out == NULL with
+// relu: the mask is recomputed from y as fma(xhat, gamma, beta) > 0 (beta required).
 extern "C" int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
-                                        const float* gamma, float* dm, float* part, int N, int HW, int C, int relu,
-                                        hipStream_t st) {
-  return dyb_gn_bwd_reduce_slabs(dout, 1, 0, nullptr, out, y, stats, gamma, dm, part, N, HW, C, relu, st);
+                                        const float* gamma, const float* beta, float* dm, float* part, int N, int HW, int C,
+                                        int relu, hipStream_t st) {
+  return dyb_gn_bwd_reduce_slabs(dout, 1, 0, nullptr, out, y, stats, gamma, beta, dm, part, N, HW, C, relu, st);
 }
 // same, the incoming gradient being sum_z dout[z*slab_stride + .] (+ addend): the un-folded split-K slabs
 // of the data-gradient convolution that produced it plus the residual-edge gradient (dm != dout required
 // then); saves the stand-alone fold launch on the critical chain.
 int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, const float* addend, const float* out,
-                            const float* y, const float* stats, const float* gamma, float* dm, float* part, int N, int HW,
-                            int C, int relu, hipStream_t st) {
+                            const float* y, const float* stats, const float* gamma, const float* beta, float* dm,
+                            float* part, int N, int HW, int C, int relu, hipStream_t st) {
   DYB_REQUIRE(dout && y && stats && gamma && dm && part && nslabs >= 1, DYB_ERR_ARG);
-  DYB_REQUIRE(!relu || out, DYB_ERR_ARG);
+  DYB_REQUIRE(!relu || out || beta, DYB_ERR_ARG);      // ReLU mask: from the saved activation, or recomputed from y
   DYB_REQUIRE(!(nslabs > 1 || addend) || dm != dout, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   int nch, ncolb;
@@ -494,8 +564,8 @@ int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, c
   int rows = dyb_cdiv(HW, nch);
   float* gpart = part + (size_t)N * nch * 2 * C;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
-                     (float*)nullptr, dm == dout ? (float*)nullptr : dm, out, y, stats, gamma, part, gpart, HW, C, rows, relu,
-                     TX);
+                     (float*)nullptr, dm == dout ? (float*)nullptr : dm, out, y, stats, gamma, beta, part, gpart, HW, C, rows,
+                     relu, TX);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -69,8 +69,8 @@ int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_t slab_stri
  * dependent launch less per layer (the engine's critical chain is launch-latency-bound at batch 1). */
 size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C);
 int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
-                             const float* gamma, float* dm, float* part, int N, int HW, int C, int relu,
-                             dyb_stream_t stream);
+                             const float* gamma, const float* beta, float* dm, float* part, int N, int HW, int C,
+                             int relu, dyb_stream_t stream);
 int dyb_conv2d_nhwc_dgrad_gn(const float* dm, const float* y_gn, const float* stats, const float* part,
                              const float* gamma, const float* w, float* dx, const float* addend, int N, int H, int W,
                              int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
@@ -78,6 +78,27 @@ int dyb_conv2d_nhwc_dgrad_gn(const float* dm, const float* y_gn, const float* st
 int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const float* y_gn, const float* stats, const float* part,
                              const float* gamma, float* dw, float* dgamma, float* dbeta, int N, int H, int W, int C,
                              int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+
+/* GroupNorm forward split the same way.  dyb_groupnorm_stats: the statistics half alone (partials =
+ * dyb_groupnorm_workspace_bytes(N,HW,C) bytes).  dyb_groupnorm_apply: the apply half; its residual may be
+ * NULL, plain, or (res_partials != NULL) the GroupNorm without ReLU of a raw conv output - the
+ * shortcut branch's downsample.1 (model/hmr.py:66-70) - normalised on the fly.
+ * dyb_conv2d_nhwc_fwd_gnin: y = conv(relu?(gn(y_prev))) with the producer's GroupNorm applied in the
+ * operand loader from its partials (inside a bottleneck, model/hmr.py:43-52, bn1/bn2 outputs have a
+ * single consumer and are never written); dyb_conv2d_nhwc_wgrad_gn_gnin is the matching weight gradient. */
+int dyb_groupnorm_stats(const float* slabs, int nslabs, float* y, float* partials, int N, int HW, int C,
+                        dyb_stream_t stream);
+int dyb_groupnorm_apply(const float* y, const float* partials, const float* gamma, const float* beta,
+                        const float* residual, const float* res_partials, const float* res_gamma, const float* res_beta,
+                        float* res_stats, float* out, float* stats, int N, int HW, int C, int relu, dyb_stream_t stream);
+int dyb_conv2d_nhwc_fwd_gnin(const float* y_prev, const float* part_prev, const float* gamma_prev, const float* beta_prev,
+                             int relu_prev, float* stats_prev_out, const float* w, float* y, int N, int H, int W, int C,
+                             int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                                  const float* beta_prev, int relu_prev, const float* dm, const float* y_gn,
+                                  const float* stats, const float* part, const float* gamma, float* dw, float* dgamma,
+                                  float* dbeta, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                  void* ws, size_t ws_bytes, dyb_stream_t stream);
 
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */

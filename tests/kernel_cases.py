@@ -505,7 +505,7 @@ def case_conv_gn_bwd_fused(be, N, H, W, C, K, R, stride, pad, relu=1, seed=21):
                                    be.ptr(gws), gwsb, be.stream), "gn fwd")
     part = be.empty((be.lib.dyb_groupnorm_bwd_partial_floats(N, HW, K),))
     DM = be.empty((N, HW, K)) if relu else DO
-    check(be.lib.dyb_groupnorm_bwd_reduce(be.ptr(DO), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(GA), be.ptr(DM), be.ptr(part),
+    check(be.lib.dyb_groupnorm_bwd_reduce(be.ptr(DO), be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(DM), be.ptr(part),
                                           N, HW, K, relu, be.stream), "gn bwd reduce")
     DX, DW, DG, DB = be.empty(x.shape), be.empty(w.shape), be.empty((K,)), be.empty((K,))
     check(be.lib.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM), be.ptr(Y), be.ptr(ST), be.ptr(part), be.ptr(GA), be.ptr(Wt), be.ptr(DX),
@@ -517,5 +517,137 @@ def case_conv_gn_bwd_fused(be, N, H, W, C, K, R, stride, pad, relu=1, seed=21):
     e = dict(dx=rel_err(be.host(DX), gx.permute(0, 2, 3, 1).numpy() + add),
              dw=rel_err(be.host(DW), gw.permute(2, 3, 1, 0).numpy()),
              dgamma=rel_err(be.host(DG), gg.numpy()), dbeta=rel_err(be.host(DB), gb.numpy()))
+    assert max(e.values()) < 5e-4, e
+    return e
+
+
+# ------------------------------------------------------------------- a whole bottleneck through the fused entry points
+def case_bottleneck_fused(be, N, H, W, Cin, planes, stride, downsample, seed=31):
+    """reference model/hmr.py:40-60 (Bottleneck): conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 (+ downsample) -relu with the
+    launch structure of the engine: bn1 / bn2 / downsample.1 outputs never materialised (normalised in the consumer's
+    loader), dy never materialised (formed in the dgrad / wgrad loaders).  Output and every gradient vs torch autograd."""
+    rng = _rng(seed)
+    Cout = planes * 4
+    assert downsample or (Cin == Cout and stride == 1)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+
+    def wgt(R, Ci, Co):
+        return (rng.standard_normal((R, R, Ci, Co)) / np.sqrt(R * R * Ci)).astype(np.float32)
+
+    def gb(C):
+        return (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w1, w2, w3 = wgt(1, Cin, planes), wgt(3, planes, planes), wgt(1, planes, Cout)
+    (g1, b1), (g2, b2), (g3, b3) = gb(planes), gb(planes), gb(Cout)
+    wd = wgt(1, Cin, Cout) if downsample else None
+    gd, bd = gb(Cout) if downsample else (None, None)
+    dout = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+
+    # ---- torch reference
+    T = lambda a: torch.from_numpy(a).requires_grad_(True)
+    cw = lambda w: torch.from_numpy(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    tw1, tw2, tw3 = cw(w1), cw(w2), cw(w3)
+    tg = [T(a) for a in (g1, b1, g2, b2, g3, b3)]
+    a1 = F.relu(F.group_norm(F.conv2d(xt, tw1), 4, tg[0], tg[1], 1e-5))
+    a2 = F.relu(F.group_norm(F.conv2d(a1, tw2, stride=stride, padding=1), 4, tg[2], tg[3], 1e-5))
+    o = F.group_norm(F.conv2d(a2, tw3), 4, tg[4], tg[5], 1e-5)
+    leaves = [xt, tw1, tw2, tw3] + tg
+    if downsample:
+        twd, tgd, tbd = cw(wd), T(gd), T(bd)
+        o = o + F.group_norm(F.conv2d(xt, twd, stride=stride), 4, tgd, tbd, 1e-5)
+        leaves += [twd, tgd, tbd]
+    else:
+        o = o + xt
+    o = F.relu(o)
+    grads = torch.autograd.grad(o, leaves, torch.from_numpy(dout).permute(0, 3, 1, 2))
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).numpy()
+    rscw = lambda t: t.detach().permute(2, 3, 1, 0).numpy()
+
+    # ---- device: forward as the engine issues it
+    L = be.lib
+    X, DO = be.dev(x), be.dev(dout)
+    W1, W2, W3 = be.dev(w1), be.dev(w2), be.dev(w3)
+    G1, B1, G2, B2, G3, B3 = [be.dev(a) for a in (g1, b1, g2, b2, g3, b3)]
+    shapes = dict(c1=(N, H, W, Cin, planes, 1, 1, 1, 0), c2=(N, H, W, planes, planes, 3, 3, stride, 1),
+                  c3=(N, Ho, Wo, planes, Cout, 1, 1, 1, 0), cd=(N, H, W, Cin, Cout, 1, 1, stride, 0))
+    wsb = max(max(L.dyb_conv2d_workspace_bytes(*sh) for sh in shapes.values()), 16)
+    ws, ws2 = be.empty((wsb // 4,)), be.empty((wsb // 4,))
+    HW1, HW2 = H * W, Ho * Wo
+    pA = be.empty((max(L.dyb_groupnorm_workspace_bytes(N, HW1, planes), L.dyb_groupnorm_workspace_bytes(N, HW2, Cout)) // 4,))
+    pB = be.empty((L.dyb_groupnorm_workspace_bytes(N, HW2, planes) // 4,))
+    pD = be.empty((L.dyb_groupnorm_workspace_bytes(N, HW2, Cout) // 4,))
+    Y1, Y2, Y3 = be.empty((N, HW1, planes)), be.empty((N, HW2, planes)), be.empty((N, HW2, Cout))
+    S1, S2, S3, SD = [be.empty((N, 4, 2)) for _ in range(4)]
+    OUT = be.empty((N, HW2, Cout))
+    check(L.dyb_conv2d_nhwc_fwd(be.ptr(X), be.ptr(W1), be.ptr(Y1), *shapes["c1"], be.ptr(ws), wsb, be.stream), "c1")
+    check(L.dyb_groupnorm_stats(None, 1, be.ptr(Y1), be.ptr(pA), N, HW1, planes, be.stream), "s1")
+    check(L.dyb_conv2d_nhwc_fwd_gnin(be.ptr(Y1), be.ptr(pA), be.ptr(G1), be.ptr(B1), 1, be.ptr(S1), be.ptr(W2), be.ptr(Y2),
+                                     *shapes["c2"], be.ptr(ws), wsb, be.stream), "c2")
+    check(L.dyb_groupnorm_stats(None, 1, be.ptr(Y2), be.ptr(pB), N, HW2, planes, be.stream), "s2")
+    if downsample:
+        WD, GD, BD, YD = be.dev(wd), be.dev(gd), be.dev(bd), be.empty((N, HW2, Cout))
+        check(L.dyb_conv2d_nhwc_fwd(be.ptr(X), be.ptr(WD), be.ptr(YD), *shapes["cd"], be.ptr(ws), wsb, be.stream), "cd")
+        check(L.dyb_groupnorm_stats(None, 1, be.ptr(YD), be.ptr(pD), N, HW2, Cout, be.stream), "sd")
+    check(L.dyb_conv2d_nhwc_fwd_gnin(be.ptr(Y2), be.ptr(pB), be.ptr(G2), be.ptr(B2), 1, be.ptr(S2), be.ptr(W3), be.ptr(Y3),
+                                     *shapes["c3"], be.ptr(ws), wsb, be.stream), "c3")
+    check(L.dyb_groupnorm_stats(None, 1, be.ptr(Y3), be.ptr(pA), N, HW2, Cout, be.stream), "s3")
+    if downsample:
+        check(L.dyb_groupnorm_apply(be.ptr(Y3), be.ptr(pA), be.ptr(G3), be.ptr(B3), be.ptr(YD), be.ptr(pD), be.ptr(GD),
+                                    be.ptr(BD), be.ptr(SD), be.ptr(OUT), be.ptr(S3), N, HW2, Cout, 1, be.stream), "a3")
+    else:
+        check(L.dyb_groupnorm_apply(be.ptr(Y3), be.ptr(pA), be.ptr(G3), be.ptr(B3), be.ptr(X), None, None, None, None,
+                                    be.ptr(OUT), be.ptr(S3), N, HW2, Cout, 1, be.stream), "a3")
+    e = dict(out=rel_err(be.host(OUT).reshape(N, Ho, Wo, Cout), nhwc(o)))
+
+    # ---- backward as the engine issues it
+    def part(HW, C):
+        return be.empty((L.dyb_groupnorm_bwd_partial_floats(N, HW, C),))
+    P1, P2, P3, PD = part(HW1, planes), part(HW2, planes), part(HW2, Cout), part(HW2, Cout)
+    DM3, DM2, DM1 = be.empty((N, HW2, Cout)), be.empty((N, HW2, planes)), be.empty((N, HW1, planes))
+    DW1, DW2, DW3 = be.empty(w1.shape), be.empty(w2.shape), be.empty(w3.shape)
+    DG = {k: be.empty((c,)) for k, c in dict(g1=planes, b1=planes, g2=planes, b2=planes, g3=Cout, b3=Cout, gd=Cout, bd=Cout).items()}
+    T3, T2, DX, RB = be.empty((N, HW2, planes)), be.empty((N, HW1, planes)), be.empty(x.shape), be.empty(x.shape)
+    check(L.dyb_groupnorm_bwd_reduce(be.ptr(DO), be.ptr(OUT), be.ptr(Y3), be.ptr(S3), be.ptr(G3), be.ptr(B3), be.ptr(DM3),
+                                     be.ptr(P3), N, HW2, Cout, 1, be.stream), "r3")
+    check(L.dyb_conv2d_nhwc_wgrad_gn_gnin(be.ptr(Y2), be.ptr(S2), be.ptr(G2), be.ptr(B2), 1, be.ptr(DM3), be.ptr(Y3), be.ptr(S3),
+                                          be.ptr(P3), be.ptr(G3), be.ptr(DW3), be.ptr(DG["g3"]), be.ptr(DG["b3"]), *shapes["c3"],
+                                          be.ptr(ws2), wsb, be.stream), "wg3")
+    check(L.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM3), be.ptr(Y3), be.ptr(S3), be.ptr(P3), be.ptr(G3), be.ptr(W3), be.ptr(T3), None,
+                                     *shapes["c3"], be.ptr(ws), wsb, be.stream), "dg3")
+    check(L.dyb_groupnorm_bwd_reduce(be.ptr(T3), None, be.ptr(Y2), be.ptr(S2), be.ptr(G2), be.ptr(B2), be.ptr(DM2), be.ptr(P2),
+                                     N, HW2, planes, 1, be.stream), "r2")          # mask recomputed from y2
+    check(L.dyb_conv2d_nhwc_wgrad_gn_gnin(be.ptr(Y1), be.ptr(S1), be.ptr(G1), be.ptr(B1), 1, be.ptr(DM2), be.ptr(Y2), be.ptr(S2),
+                                          be.ptr(P2), be.ptr(G2), be.ptr(DW2), be.ptr(DG["g2"]), be.ptr(DG["b2"]), *shapes["c2"],
+                                          be.ptr(ws2), wsb, be.stream), "wg2")
+    check(L.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM2), be.ptr(Y2), be.ptr(S2), be.ptr(P2), be.ptr(G2), be.ptr(W2), be.ptr(T2), None,
+                                     *shapes["c2"], be.ptr(ws), wsb, be.stream), "dg2")
+    check(L.dyb_groupnorm_bwd_reduce(be.ptr(T2), None, be.ptr(Y1), be.ptr(S1), be.ptr(G1), be.ptr(B1), be.ptr(DM1), be.ptr(P1),
+                                     N, HW1, planes, 1, be.stream), "r1")
+    check(L.dyb_conv2d_nhwc_wgrad_gn(be.ptr(X), be.ptr(DM1), be.ptr(Y1), be.ptr(S1), be.ptr(P1), be.ptr(G1), be.ptr(DW1),
+                                     be.ptr(DG["g1"]), be.ptr(DG["b1"]), *shapes["c1"], be.ptr(ws2), wsb, be.stream), "wg1")
+    if downsample:
+        DWD = be.empty(wd.shape)
+        check(L.dyb_groupnorm_bwd_reduce(be.ptr(DM3), None, be.ptr(YD), be.ptr(SD), be.ptr(GD), be.ptr(BD), be.ptr(DM3),
+                                         be.ptr(PD), N, HW2, Cout, 0, be.stream), "rd")     # no ReLU: dm aliases dout
+        check(L.dyb_conv2d_nhwc_wgrad_gn(be.ptr(X), be.ptr(DM3), be.ptr(YD), be.ptr(SD), be.ptr(PD), be.ptr(GD), be.ptr(DWD),
+                                         be.ptr(DG["gd"]), be.ptr(DG["bd"]), *shapes["cd"], be.ptr(ws2), wsb, be.stream), "wgd")
+        check(L.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM3), be.ptr(YD), be.ptr(SD), be.ptr(PD), be.ptr(GD), be.ptr(WD), be.ptr(RB),
+                                         None, *shapes["cd"], be.ptr(ws), wsb, be.stream), "dgd")
+        addend = RB
+    else:
+        addend = DM3
+    check(L.dyb_conv2d_nhwc_dgrad_gn(be.ptr(DM1), be.ptr(Y1), be.ptr(S1), be.ptr(P1), be.ptr(G1), be.ptr(W1), be.ptr(DX),
+                                     be.ptr(addend), *shapes["c1"], be.ptr(ws), wsb, be.stream), "dg1")
+    e["dx"] = rel_err(be.host(DX), nhwc(grads[0]))
+    for i, (k, D) in enumerate([("dw1", DW1), ("dw2", DW2), ("dw3", DW3)]):
+        e[k] = rel_err(be.host(D), rscw(grads[1 + i]))
+    for i, k in enumerate(["g1", "b1", "g2", "b2", "g3", "b3"]):
+        e["d" + k] = rel_err(be.host(DG[k]), grads[4 + i].numpy())
+    if downsample:
+        e["dwd"] = rel_err(be.host(DWD), rscw(grads[10]))
+        e["dgd"] = rel_err(be.host(DG["gd"]), grads[11].numpy())
+        e["dbd"] = rel_err(be.host(DG["bd"]), grads[12].numpy())
     assert max(e.values()) < 5e-4, e
     return e

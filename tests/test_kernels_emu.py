@@ -50,6 +50,16 @@ def test_conv_gn_bwd_fused(be, cfg):
     K.case_conv_gn_bwd_fused(be, *cfg, seed=sum(cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, planes, stride, downsample
+    (1, 6, 6, 64, 16, 1, False),      # identity shortcut
+    (2, 8, 8, 64, 32, 2, True),       # stride-2 block with downsample, batch 2
+    (3, 5, 5, 32, 16, 1, True),       # ragged tiles straddling images
+])
+def test_bottleneck_fused(be, cfg):
+    K.case_bottleneck_fused(be, *cfg, seed=sum(int(v) for v in cfg))
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)

@@ -57,6 +57,16 @@ def test_conv_gn_bwd_fused_batch5(be, shape):
     K.case_conv_gn_bwd_fused(be, 5, H, W, C, Kc, R, st, pad, seed=9)
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, planes, stride, downsample   (the distinct bottleneck shapes of ResNet-50 at 224x224)
+    (1, 56, 56, 64, 64, 1, True), (1, 56, 56, 256, 64, 1, False), (1, 56, 56, 256, 128, 2, True),
+    (1, 28, 28, 512, 128, 1, False), (1, 28, 28, 512, 256, 2, True), (1, 14, 14, 1024, 256, 1, False),
+    (1, 14, 14, 1024, 512, 2, True), (1, 7, 7, 2048, 512, 1, False), (4, 14, 14, 1024, 256, 1, False),
+    (3, 28, 28, 512, 256, 2, True)])
+def test_bottleneck_fused(be, cfg):
+    K.case_bottleneck_fused(be, *cfg, seed=sum(int(v) for v in cfg))
+
+
 def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 784, 512, 4, True)
     K.case_groupnorm_fold(be, 1, 49, 2048, 36, False)
