@@ -560,6 +560,10 @@ def case_bottleneck_fused(be, N, H, W, Cin, planes, stride, downsample, seed=31)
         leaves += [twd, tgd, tbd]
     else:
         o = o + xt
+    # a pre-activation within rounding distance of 0 may take either side of the final ReLU in two correct fp32
+    # evaluations, and one flipped element there moves every gradient by O(1e-3): take those elements out of play
+    near0 = (o.detach().abs() < 1e-5).permute(0, 2, 3, 1).numpy()
+    dout[near0] = 0.0
     o = F.relu(o)
     grads = torch.autograd.grad(o, leaves, torch.from_numpy(dout).permute(0, 3, 1, 2))
     nhwc = lambda t: t.detach().permute(0, 2, 3, 1).numpy()
