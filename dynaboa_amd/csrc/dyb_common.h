@@ -57,7 +57,7 @@ int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y
 void dyb_gn_bwd_layout(int N, int HW, int C, int* nch, int* ncolb);
 int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, const float* addend, const float* out,
                             const float* y, const float* stats, const float* gamma, const float* beta, float* dm,
-                            float* part, int N, int HW, int C, int relu, hipStream_t st);
+                            float* part, int N, int HW, int C, int relu, hipStream_t st, hipEvent_t done);
 int dyb_gn_fwd_chunks(int N, int HW);
 // data gradient with the GroupNorm backward in its loader that may leave `*nslabs` (>1) un-reduced
 // split-K slabs in `ws` (addend NOT applied then) for the next GroupNorm-backward reduce to fold
@@ -70,3 +70,5 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
 int dyb_conv_fwd_gnin_raw(const ConvDesc& d, const float* y_prev, const float* part_prev, const float* gamma_prev,
                           const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y, void* ws,
                           size_t ws_bytes, int* nslabs, hipStream_t st);
+int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, const float* tail,
+                         int tail_ld, int tail_cols, int tail_dst_col, hipStream_t st);

@@ -472,10 +472,7 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   }
   float* dsts[MAX_ITER];
   for (int t = 0; t < n_iter; ++t) dsts[t] = acts + P.a_xc[t];
-  RUN(dyb_avgpool_fwd(x, dsts, n_iter, FC1_IN_PAD, B, P.featHW, FEAT, st));
-  if (hipMemcpy2DAsync(acts + P.a_xc[0] + FEAT, FC1_IN_PAD * sizeof(float), init_state, STATE_LD * sizeof(float),
-                       STATE_LD * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return DYB_ERR_LAUNCH;
+  RUN(dyb_avgpool_fwd_tail(x, dsts, n_iter, FC1_IN_PAD, B, P.featHW, FEAT, init_state, STATE_LD, STATE_LD, FEAT, st));
   for (int t = 0; t < n_iter; ++t) {
     const float* xc = acts + P.a_xc[t];
     RUN(dyb_linear_fwd(xc, FC1_IN_PAD, params + P.fc1_w, FC1_IN_PAD, params + P.fc1_b, nullptr, 0, acts + P.a_h1[t], HID, B,
@@ -518,11 +515,11 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
   float* part = w.gnb + c.gnb;
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
-                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st));
+                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st,
+                              aux ? P.ev_dy[ci] : nullptr));
   hipStream_t ws_st = st;
   void* slabs = w.conv;
   if (aux) {
-    if (hipEventRecord(P.ev_dy[ci], st) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(aux, P.ev_dy[ci], 0) != hipSuccess) return DYB_ERR_LAUNCH;
     ws_st = aux;
     slabs = w.conv_aux;

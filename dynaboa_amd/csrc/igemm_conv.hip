@@ -429,8 +429,18 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       const int v = base + tid / L, sub = tid % L;
       float s = 0.f;
       if (v < nvals) {
+        // the fold sits on the kernel's critical path: eight independent loads in flight per lane,
+        // not a dependent chain (up to 8*L = 256 partials per value in one round trip at batch 1)
         const float* gp = f.gpart + (size_t)(v >> 3) * f.kparts * 8 + (v & 7);
-        for (int k = sub; k < f.kparts; k += L) s += gp[(size_t)k * 8];
+        for (int k0 = sub; k0 < f.kparts; k0 += 8 * L) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j * L;
+            t[j] = k < f.kparts ? gp[(size_t)k * 8] : 0.f;
+          }
+          s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
       }
       for (int m = L >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
       if (v < nvals && sub == 0) s_raw[v] = s * f.inv_m;
@@ -456,7 +466,16 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         double s = 0.0;
         if (v < nvals) {
           const float* pp = nf.partials + (size_t)(v >> 3) * nf.nchunks * 8 + (v & 7);
-          for (int k = sub; k < nf.nchunks; k += L) s += (double)pp[(size_t)k * 8];
+          for (int k0 = sub; k0 < nf.nchunks; k0 += 8 * L) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int k = k0 + j * L;
+              t[j] = k < nf.nchunks ? pp[(size_t)k * 8] : 0.f;
+            }
+            s += (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) +
+                 (((double)t[4] + (double)t[5]) + ((double)t[6] + (double)t[7]));
+          }
         }
         for (int m = L >> 1; m >= 1; m >>= 1) s += igemm_shfl_xor_f64(s, m);
         if (v < nvals && sub == 0) s_rawd[v] = s;

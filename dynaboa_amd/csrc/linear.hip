@@ -27,13 +27,28 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     float acc[LIN_BT];
 #pragma unroll
     for (int t = 0; t < LIN_BT; ++t) acc[t] = 0.f;
-    for (int i4 = lane; i4 < I4; i4 += 64) {
-      float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)i4 * 4);
+    // four weight pieces (+ the matching x pieces) in flight per round trip: the row stream is the
+    // latency chain of this kernel at batch 1 (fc1: 9 pieces per lane)
+    for (int i0 = lane; i0 < I4; i0 += 256) {
+      float4 wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i4 = i0 + 64 * j;
+        wv[j] = i4 < I4 ? *reinterpret_cast<const float4*>(wr + (size_t)i4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int t = 0; t < LIN_BT; ++t) {
         if (b0 + t < B) {
-          float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + t) * ldx + (size_t)i4 * 4);
-          acc[t] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+          float4 xv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i4 = i0 + 64 * j;
+            xv[j] = i4 < I4 ? *reinterpret_cast<const float4*>(x + (size_t)(b0 + t) * ldx + (size_t)i4 * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[t] += (wv[j].x * xv[j].x + wv[j].y * xv[j].y) + (wv[j].z * xv[j].z + wv[j].w * xv[j].w);
         }
       }
     }
@@ -115,7 +130,12 @@ __global__ __launch_bounds__(256) void linear_dx_fold_kernel(const float* __rest
   if (idx >= B * I) return;
   int b = idx / I, i = idx % I;
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += partial[((size_t)z * B + b) * I + i];
+  for (int z0 = 0; z0 < nsplit; z0 += 8) {         // eight loads in flight, not a dependent chain of nsplit
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (z0 + j < nsplit) ? partial[((size_t)(z0 + j) * B + b) * I + i] : 0.f;
+    s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
   if (i < split_col) {
     float* d = dstA + (size_t)b * ldA + i;
     *d = accA ? (*d + s) : s;

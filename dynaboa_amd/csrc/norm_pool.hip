@@ -12,6 +12,8 @@
 //              out = relu?((y-mean)*rstd*gamma + beta (+ residual)); saves mean/rstd.
 //   backward : gn_bwd_reduce (per-channel sums of dy and dy*xhat + per-group gamma-weighted sums)
 //              -> gn_bwd_apply (coefficients, dx, the residual-edge gradient, dgamma/dbeta).
+#include <hip/hip_ext.h>
+
 #include "dyb_common.h"
 
 #define G DYB_GN_GROUPS
@@ -37,21 +39,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
     float4 v = *reinterpret_cast<const float4*>(src + off);
     if (nslabs > 1) {
-      float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1, v3 = v1;
-      int z = 1;
-      for (; z + 2 < nslabs; z += 3) {
-        float4 a = *reinterpret_cast<const float4*>(src + (size_t)z * slab_stride + off);
-        float4 b = *reinterpret_cast<const float4*>(src + (size_t)(z + 1) * slab_stride + off);
-        float4 c = *reinterpret_cast<const float4*>(src + (size_t)(z + 2) * slab_stride + off);
-        v1.x += a.x; v1.y += a.y; v1.z += a.z; v1.w += a.w;
-        v2.x += b.x; v2.y += b.y; v2.z += b.z; v2.w += b.w;
-        v3.x += c.x; v3.y += c.y; v3.z += c.z; v3.w += c.w;
+      // eight slab loads in flight per round trip (the fold is the latency chain of this kernel)
+      for (int z0 = 1; z0 < nslabs; z0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          t[j] = (z0 + j < nslabs) ? *reinterpret_cast<const float4*>(src + (size_t)(z0 + j) * slab_stride + off)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x += ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
+        v.y += ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
+        v.z += ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
+        v.w += ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
       }
-      for (; z < nslabs; ++z) {
-        float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * slab_stride + off);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      v.x += (v1.x + v2.x) + v3.x; v.y += (v1.y + v2.y) + v3.y; v.z += (v1.z + v2.z) + v3.z; v.w += (v1.w + v2.w) + v3.w;
       *reinterpret_cast<float4*>(y + off) = v;
     }
     s1 += (v.x + v.y) + (v.z + v.w);
@@ -117,10 +116,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const float* pp = which ? rs.partials : partials;
     const int nch = which ? rs.nchunks : nchunks;
     double a = 0.0, b = 0.0;
-    for (int ch = lane; ch < nch; ch += 64) {
-      const float* p = pp + (((size_t)n * nch + ch) * G + wave) * 2;
-      a += (double)p[0];
-      b += (double)p[1];
+    for (int c0 = lane; c0 < nch; c0 += 256) {
+      float2 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = c0 + 64 * j;
+        t[j] = ch < nch ? *reinterpret_cast<const float2*>(pp + (((size_t)n * nch + ch) * G + wave) * 2) : make_float2(0.f, 0.f);
+      }
+      a += ((double)t[0].x + (double)t[1].x) + ((double)t[2].x + (double)t[3].x);
+      b += ((double)t[0].y + (double)t[1].y) + ((double)t[2].y + (double)t[3].y);
     }
     a = wave_sum_f64(a);
     b = wave_sum_f64(b);
@@ -334,23 +338,21 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     float4 v = *reinterpret_cast<const float4*>(y + off);
     float4 q = (relu && out) ? *reinterpret_cast<const float4*>(out + off) : zero4;
     if (fold) {
-      // three independent accumulators keep four slab loads in flight
-      float4 d1 = addend ? *reinterpret_cast<const float4*>(addend + off) : zero4;
-      float4 d2 = zero4, d3 = zero4;
-      int z = 1;
-      for (; z + 2 < nslabs; z += 3) {
-        float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
-        float4 r = *reinterpret_cast<const float4*>(dout + (size_t)(z + 1) * slab_stride + off);
-        float4 t = *reinterpret_cast<const float4*>(dout + (size_t)(z + 2) * slab_stride + off);
-        d1.x += p.x; d1.y += p.y; d1.z += p.z; d1.w += p.w;
-        d2.x += r.x; d2.y += r.y; d2.z += r.z; d2.w += r.w;
-        d3.x += t.x; d3.y += t.y; d3.z += t.z; d3.w += t.w;
-      }
-      for (; z < nslabs; ++z) {
-        float4 p = *reinterpret_cast<const float4*>(dout + (size_t)z * slab_stride + off);
+      // eight slab loads in flight per round trip
+      if (addend) {
+        float4 p = *reinterpret_cast<const float4*>(addend + off);
         d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
       }
-      d.x += (d1.x + d2.x) + d3.x; d.y += (d1.y + d2.y) + d3.y; d.z += (d1.z + d2.z) + d3.z; d.w += (d1.w + d2.w) + d3.w;
+      for (int z0 = 1; z0 < nslabs; z0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          t[j] = (z0 + j < nslabs) ? *reinterpret_cast<const float4*>(dout + (size_t)(z0 + j) * slab_stride + off) : zero4;
+        d.x += ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
+        d.y += ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
+        d.z += ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
+        d.w += ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
+      }
       if (folded) *reinterpret_cast<float4*>(folded + off) = d;
     }
     accumulate(d, v, q, off);
@@ -545,14 +547,14 @@ extern "C" size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C) {
 extern "C" int dyb_groupnorm_bwd_reduce(const float* dout, const float* out, const float* y, const float* stats,
                                         const float* gamma, const float* beta, float* dm, float* part, int N, int HW, int C,
                                         int relu, hipStream_t st) {
-  return dyb_gn_bwd_reduce_slabs(dout, 1, 0, nullptr, out, y, stats, gamma, beta, dm, part, N, HW, C, relu, st);
+  return dyb_gn_bwd_reduce_slabs(dout, 1, 0, nullptr, out, y, stats, gamma, beta, dm, part, N, HW, C, relu, st, nullptr);
 }
 // same, the incoming gradient being sum_z dout[z*slab_stride + .] (+ addend): the un-folded split-K slabs
 // of the data-gradient convolution that produced it plus the residual-edge gradient (dm != dout required
 // then); saves the stand-alone fold launch on the critical chain.
 int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, const float* addend, const float* out,
                             const float* y, const float* stats, const float* gamma, const float* beta, float* dm,
-                            float* part, int N, int HW, int C, int relu, hipStream_t st) {
+                            float* part, int N, int HW, int C, int relu, hipStream_t st, hipEvent_t done) {
   DYB_REQUIRE(dout && y && stats && gamma && dm && part && nslabs >= 1, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out || beta, DYB_ERR_ARG);      // ReLU mask: from the saved activation, or recomputed from y
   DYB_REQUIRE(!(nslabs > 1 || addend) || dm != dout, DYB_ERR_ARG);
@@ -563,9 +565,17 @@ int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, c
   int TX = CQ < 256 ? CQ : 256;
   int rows = dyb_cdiv(HW, nch);
   float* gpart = part + (size_t)N * nch * 2 * C;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
-                     (float*)nullptr, dm == dout ? (float*)nullptr : dm, out, y, stats, gamma, beta, part, gpart, HW, C, rows,
-                     relu, TX);
+  // `done`: the event rides on the kernel's own completion signal - a separate hipEventRecord would put a
+  // marker packet into the stream and ~6 us of bubble in front of the next kernel (measured)
+  float* folded_none = nullptr;
+  float* dm_arg = dm == dout ? (float*)nullptr : dm;
+  if (done)
+    hipExtLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, nullptr, done, 0, dout, nslabs,
+                          slab_stride, addend, folded_none, dm_arg, out, y, stats, gamma, beta, part, gpart, HW, C, rows, relu,
+                          TX);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
+                       folded_none, dm_arg, out, y, stats, gamma, beta, part, gpart, HW, C, rows, relu, TX);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -693,20 +703,49 @@ extern "C" int dyb_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float*
 struct AvgDst {
   float* p[4];
 };
+// 4 lanes per (image, channel quad) split the pixels, each with up to 7 loads in flight per round trip
+// (a 7x7 map: 2 trips); workgroups past the pooling ones copy `tail` (the regressor's initial state,
+// reference model/hmr.py:157-159 torch.cat([xf, pred_pose, pred_shape, pred_cam], 1)) behind the
+// pooled features of the first destination, which saves a separate copy launch.
+struct AvgTail {
+  const float* src;   // [N][src_ld] or NULL
+  int src_ld, cols, dst_col;
+};
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, AvgDst dst, int ndst, int ld, int N,
-                                                          int HW, int C) {
-  const int CQ = C >> 2;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * CQ) return;
-  int n = i / CQ, cq = i % CQ;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = 0; p < HW; ++p) {
-    float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p) * C + (size_t)cq * 4);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                                                          int HW, int C, AvgTail tail, int pool_blocks) {
+  if ((int)blockIdx.x >= pool_blocks) {
+    int i = (blockIdx.x - pool_blocks) * 256 + threadIdx.x;
+    if (i < N * tail.cols) {
+      int n = i / tail.cols, c = i % tail.cols;
+      dst.p[0][(size_t)n * ld + tail.dst_col + c] = tail.src[(size_t)n * tail.src_ld + c];
+    }
+    return;
   }
-  float inv = 1.0f / (float)HW;
-  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-  for (int d = 0; d < ndst; ++d) *reinterpret_cast<float4*>(dst.p[d] + (size_t)n * ld + (size_t)cq * 4) = s;
+  const int CQ = C >> 2;
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, part = threadIdx.x & 3;
+  const bool live = i < N * CQ;
+  const int n = live ? i / CQ : 0, cq = live ? i % CQ : 0;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    for (int p0 = part; p0 < HW; p0 += 28) {
+      float4 t[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int p = p0 + 4 * j;
+        t[j] = p < HW ? *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p) * C + (size_t)cq * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { s.x += t[j].x; s.y += t[j].y; s.z += t[j].z; s.w += t[j].w; }
+    }
+  }
+  s.x += __shfl_xor(s.x, 1); s.y += __shfl_xor(s.y, 1); s.z += __shfl_xor(s.z, 1); s.w += __shfl_xor(s.w, 1);
+  s.x += __shfl_xor(s.x, 2); s.y += __shfl_xor(s.y, 2); s.z += __shfl_xor(s.z, 2); s.w += __shfl_xor(s.w, 2);
+  if (live && part == 0) {
+    float inv = 1.0f / (float)HW;
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    for (int d = 0; d < ndst; ++d) *reinterpret_cast<float4*>(dst.p[d] + (size_t)n * ld + (size_t)cq * 4) = s;
+  }
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dxf, int ld, float* __restrict__ dx,
                                                           int N, int HW, int C) {
@@ -721,15 +760,22 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     *reinterpret_cast<float4*>(dx + i * 4) = g;
   }
 }
-extern "C" int dyb_avgpool_fwd(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C,
-                               hipStream_t st) {
+int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, const float* tail,
+                         int tail_ld, int tail_cols, int tail_dst_col, hipStream_t st) {
   DYB_REQUIRE(x && dsts && ndst >= 1 && ndst <= 4 && C % 4 == 0 && ld % 4 == 0, DYB_ERR_ARG);
   AvgDst d{};
   for (int i = 0; i < ndst; ++i) d.p[i] = dsts[i];
-  int blocks = dyb_cdiv(N * (C / 4), 256);
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, d, ndst, ld, N, HW, C);
+  int pool_blocks = dyb_cdiv(N * (C / 4) * 4, 256);
+  AvgTail t{tail, tail_ld, tail ? tail_cols : 0, tail_dst_col};
+  int tail_blocks = tail ? dyb_cdiv(N * tail_cols, 256) : 0;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(pool_blocks + tail_blocks), dim3(256), 0, st, x, d, ndst, ld, N, HW, C, t,
+                     pool_blocks);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+extern "C" int dyb_avgpool_fwd(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C,
+                               hipStream_t st) {
+  return dyb_avgpool_fwd_tail(x, dsts, ndst, ld, N, HW, C, nullptr, 0, 0, 0, st);
 }
 extern "C" int dyb_avgpool_bwd(const float* dxf, int ld, float* dx, int N, int HW, int C, hipStream_t st) {
   DYB_REQUIRE(dxf && dx && C % 4 == 0 && ld % 4 == 0, DYB_ERR_ARG);
