@@ -506,33 +506,48 @@ static Pending plain(const float* p) { return Pending{p, 1, 0, nullptr}; }
 // their operand loaders.  The weight gradient (which also writes dgamma / dbeta) is off the critical
 // path, so it goes to the auxiliary stream when given, ordered by one event per layer, with its own
 // split-K slab region; everything it reads lives in per-layer slots that nothing overwrites during the call.
+struct WgradJob {
+  int ci;
+  const float* conv_in;
+  const ConvL* in_prev;
+  const float* dm;
+};
+static int run_wgrad(HmrPlan& P, const WgradJob& j, const float* params, const float* acts, float* grads, const WsCarve& w,
+                     void* slabs, hipStream_t st) {
+  const ConvL& c = P.convs[j.ci];
+  const float* part = w.gnb + c.gnb;
+  if (j.in_prev)     // the conv's input was relu(gn(y_prev)), never materialised
+    return dyb_conv2d_nhwc_wgrad_gn_gnin(acts + j.in_prev->y, acts + j.in_prev->stats, params + j.in_prev->gam,
+                                         params + j.in_prev->bet, 1, j.dm, acts + c.y, acts + c.stats, part, params + c.gam,
+                                         grads + c.w, grads + c.gam, grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride,
+                                         c.pad, slabs, P.ws_conv, st);
+  return dyb_conv2d_nhwc_wgrad_gn(j.conv_in, j.dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
+                                  grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, st);
+}
+// `jobs`: weight gradients whose inputs are ready once the reduce carrying `done` has run; the caller
+// flushes them to the auxiliary stream once per bottleneck (one cross-stream edge per block instead of
+// one per layer: each edge costs ~9 us of host time).  Without an auxiliary stream they run in line.
 static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
                         const ConvL* in_prev, const Pending& din, int relu, const float** dm_out, const WsCarve& w,
-                        hipStream_t st, hipStream_t aux) {
+                        hipStream_t st, std::vector<WgradJob>* jobs, hipEvent_t done) {
   const ConvL& c = P.convs[ci];
   const bool alias = !relu && din.nslabs == 1 && !din.addend;
   float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
-                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st,
-                              aux ? P.ev_dy[ci] : nullptr));
-  hipStream_t ws_st = st;
-  void* slabs = w.conv;
-  if (aux) {
-    if (hipStreamWaitEvent(aux, P.ev_dy[ci], 0) != hipSuccess) return DYB_ERR_LAUNCH;
-    ws_st = aux;
-    slabs = w.conv_aux;
-  }
-  if (in_prev)     // the conv's input was relu(gn(y_prev)), never materialised
-    RUN(dyb_conv2d_nhwc_wgrad_gn_gnin(acts + in_prev->y, acts + in_prev->stats, params + in_prev->gam, params + in_prev->bet, 1,
-                                      dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
-                                      grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv,
-                                      ws_st));
-  else
-    RUN(dyb_conv2d_nhwc_wgrad_gn(conv_in, dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
-                                 grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, ws_st));
+                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st, done));
+  WgradJob j{ci, conv_in, in_prev, dm};
+  if (jobs) jobs->push_back(j);
+  else RUN(run_wgrad(P, j, params, acts, grads, w, w.conv, st));
   *dm_out = dm;
+  return DYB_OK;
+}
+static int flush_wgrads(HmrPlan& P, std::vector<WgradJob>& jobs, hipEvent_t done, const float* params, const float* acts,
+                        float* grads, const WsCarve& w, hipStream_t aux) {
+  if (hipStreamWaitEvent(aux, done, 0) != hipSuccess) return DYB_ERR_LAUNCH;
+  for (const WgradJob& j : jobs) RUN(run_wgrad(P, j, params, acts, grads, w, w.conv_aux, aux));
+  jobs.clear();
   return DYB_OK;
 }
 // data gradient of layer ci from its dm: conv_transpose(dy, w) (+ addend), materialised in dx_buf or -
@@ -618,6 +633,8 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, D0, B, P.featHW, FEAT, st));
   Pending cur = plain(D0);
   float* free_buf = D1;          // the D buffer `cur` does not occupy (a pending `cur` lives in the slab region)
+  std::vector<WgradJob> jobs_store;
+  std::vector<WgradJob>* jobs = aux ? &jobs_store : nullptr;
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
@@ -625,18 +642,22 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
     float* other = (free_buf == D0) ? D1 : D0;
     const float *dm3, *dm2, *dm1, *dmd;
     Pending p3, p2, pout;
+    hipEvent_t ev = aux ? P.ev_dy[b.c1] : nullptr;      // rides on the block's last reduce
     // out = relu(gn3(conv3(a2)) + res)
-    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, nullptr, &c2, cur, 1, &dm3, w, st, aux));
+    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, nullptr, &c2, cur, 1, &dm3, w, st, jobs, nullptr));
     RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st));
-    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, aux));
+    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, jobs, nullptr));
     RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st));      // `cur` was consumed by the c3 reduce
-    RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, aux));
     if (b.cd >= 0) {
+      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, nullptr));
       // shortcut branch: GroupNorm without ReLU on the residual-edge gradient; its data gradient is materialised
-      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, aux));
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, jobs, ev));
+      if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
       RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st));
       RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, Rb, &pout, w, st));
     } else {
+      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, ev));
+      if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
       RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, dm3, &pout, w, st));
     }
     cur = pout;
@@ -653,7 +674,9 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   }
   RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), spare, B, stem.Ho, stem.Wo, stem.K, st));
   const float* dm0;
-  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, nullptr, plain(spare), 1, &dm0, w, st, aux));
+  RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, nullptr, plain(spare), 1, &dm0, w, st, jobs,
+                   aux ? P.ev_dy[0] : nullptr));
+  if (aux) RUN(flush_wgrads(P, jobs_store, P.ev_dy[0], params, acts, grads, w, aux));
   if (aux) {
     if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
     if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;
