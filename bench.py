@@ -42,61 +42,39 @@ RESNET_CONVS = [
 
 
 def pmc_traffic():
-    """HBM read bytes per launch of the conv kernel family from the committed PMC pass
-    (profiles/r01_pmc_igemm_traffic.json: rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950
-    correction calibrated on the 216 MB / 432 MB streaming kernels); None if the file is absent."""
+    """HBM bytes per launch (read + write) of the conv kernel family from the committed PMC passes
+    (profiles/r01_pmc_igemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, each in its own run;
+    reads x2 = the gfx950 correction, calibrated there on the 216 / 432 MB streaming kernels; writes
+    calibrate exact); None if the file is absent."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")))
-        return float(d["hbm_read_bytes_per_launch"])
+        return float(d["hbm_bytes_per_launch"])
     except Exception:      # noqa: BLE001
         return None
 
 
-def conv_roofline(device, batch, fwd_per_frame, bwd_per_frame, reps=20):
-    """Live HIP-event timing of the dominant kernel family (igemm_mfma_kernel<fwd|dgrad|wgrad>) on
-    torch's current stream, layer by layer at the bench batch size; algorithmic FLOPs = 2*M*N*K of
-    the real (unpadded) convolution.  Returns achieved TFLOP/s over one frame's worth of launches."""
+def conv_roofline(run, lo, hi, main_stream):
+    """Dominant kernel family = igemm_mfma_kernel<fwd|dgrad|wgrad, with/without the GroupNorm loaders>.
+    Measured IN the path: frames [lo, hi) of the same loop are run once more with a timing scope open on the
+    issuing thread, inside which the library times every conv launch on its own dispatch (HIP start/stop
+    events carried by the launch itself, on whichever stream - main or the weight-gradient side stream -
+    it was issued to), whichever host thread issued it (main, autograd, metric worker)."""
+    import ctypes
     from dynaboa_amd import _lib
     lib = _lib.load()
-    st = torch.cuda.current_stream(device).cuda_stream
-    tot_flop = tot_ms = tot_bytes = 0.0
-    nlaunch = 0
-    for cnt, H, W, C, K, R, s, p in RESNET_CONVS:
-        Ho = (H + 2 * p - R) // s + 1
-        creal = 3 if C == 4 else C
-        flop = 2.0 * batch * Ho * Ho * K * R * R * creal
-        x = torch.randn(batch, H, W, C, device=device)
-        w = torch.randn(R, R, C, K, device=device) * 0.05
-        dy = torch.randn(batch, Ho, Ho, K, device=device)
-        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
-        wsb = int(lib.dyb_conv2d_workspace_bytes(batch, H, W, C, K, R, R, s, p))
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
-
-        def run(mode):
-            if mode == 0:
-                return lib.dyb_conv2d_nhwc_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
-            if mode == 1:
-                return lib.dyb_conv2d_nhwc_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), None, batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
-            return lib.dyb_conv2d_nhwc_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), batch, H, W, C, K, R, R, s, p, ws.data_ptr(), wsb, st)
-        for mode, per_frame in ((0, fwd_per_frame), (1, bwd_per_frame), (2, bwd_per_frame)):
-            if mode == 1 and C == 4:
-                continue                                   # the image needs no data gradient
-            run(mode)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                run(mode)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            tot_ms += ms * cnt * per_frame
-            tot_flop += flop * cnt * per_frame
-            # algorithmic bytes of this launch: both operands read once + result written once
-            tot_bytes += 4.0 * (x.numel() * (creal / C) + w.numel() * (creal / C) + dy.numel()) * cnt * per_frame
-            nlaunch += cnt * per_frame
-    return dict(achieved=tot_flop / (tot_ms * 1e-3) / 1e12, conv_ms_per_frame=tot_ms, launches_per_frame=nlaunch,
-                avg_launch_us=tot_ms * 1e3 / nlaunch, gflop_per_frame=tot_flop / 1e9,
-                algorithmic_bytes_per_launch=tot_bytes / nlaunch)
+    nfr = hi - lo
+    if lib.dyb_conv_timing_begin(int(nfr * 1500)) != 0:
+        return None
+    with torch.cuda.stream(main_stream):
+        run(lo, hi)
+    torch.cuda.synchronize()
+    ms, n, flop, nbytes = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+    if lib.dyb_conv_timing_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(flop), ctypes.byref(nbytes)) != 0 or n.value == 0:
+        return None
+    return dict(achieved=flop.value / (ms.value * 1e-3) / 1e12, conv_ms_per_frame=ms.value / nfr,
+                launches_per_frame=n.value / nfr, avg_launch_us=ms.value * 1e3 / n.value,
+                gflop_per_frame=flop.value / nfr / 1e9, algorithmic_bytes_per_launch=nbytes.value / n.value,
+                sample_frames=nfr)
 
 
 def cpu_baseline_worker(inner_step=3, budget_s=20.0, max_frames=6):
@@ -182,10 +160,11 @@ def main():
     o.eval_lower = 1 if args.schedule == "faithful" else 0
     ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
     total = args.warmup + args.steps
+    n_roof = 0 if args.no_roofline else 4           # extra frames for the instrumented roofline pass (outside the clock)
     # this rank's shard of the synthetic stream, resident in HBM before the clock starts
     frames = [{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + s, args.batch, seed=22).items()}
-              for s in range(total)]
-    ad.reset_records(total)
+              for s in range(total + n_roof)]
+    ad.reset_records(total + n_roof)
 
     def run(lo, hi):
         for s in range(lo, hi):
@@ -249,12 +228,16 @@ def main():
                           "gathered_frames": int(gathered.numel()) if gathered is not None else None,
                           "engine_graphs": __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(args.batch).graph_stats()}}
         if not args.no_roofline:
-            r = conv_roofline(device, args.batch, fwd_pf, args.inner_step + 1)
+            r = conv_roofline(run, total, total + n_roof, main_stream)
+            ad.flush_metrics()
+        if not args.no_roofline and r is not None:
             out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),
-                               "traffic_note": "HBM READ bytes per launch (FETCH_SIZE x2, profiles/r01_pmc_igemm_traffic.json); "
-                                               "write side not collected", "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad> (+ split-K fold), per-frame launch mix",
+                               "traffic_note": "HBM read (FETCH_SIZE x2) + write (WRITE_SIZE) bytes per launch, "
+                                               "profiles/r01_pmc_igemm_traffic.json", "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad, +/- GroupNorm loaders>: every conv launch of the "
+                                         "adaptation chain (main + weight-gradient streams), timed on its own dispatch inside the path",
+                               "sample_frames": r["sample_frames"],
                                "avg_launch_us": r["avg_launch_us"], "launches_per_frame": r["launches_per_frame"],
                                "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],
                                "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3,

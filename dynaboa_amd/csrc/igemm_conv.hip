@@ -23,7 +23,11 @@
 // register set - two steps in flight - measured no gain and cost half the occupancy).  At batch 1
 // most layers have only 1..50 output tiles, so the K loop is split over blockIdx.z into fp32 slabs
 // that a second kernel (or the GroupNorm statistics kernel) folds - deterministic, no atomics.
+#include <hip/hip_ext.h>
 #include <stdlib.h>
+
+#include <mutex>
+#include <vector>
 
 #include "dyb_common.h"
 
@@ -682,6 +686,47 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
   return best;
 }
 
+// ---- optional per-launch timing of the conv kernels (bench.py's roofline leg) ----------------------
+// While a timing scope is open (process-wide: torch's autograd issues the backward from its own thread,
+// the metric forwards come from a third) every igemm launch carries a (start, stop) event
+// pair on its own dispatch (hipExtLaunchKernelGGL: no extra packets in the stream), so the durations
+// are those of the kernels as they run inside the real path, on whatever stream they were issued to.
+struct IgemmTiming {
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  double flop = 0.0, bytes = 0.0;
+};
+static IgemmTiming* g_timing = nullptr;
+static std::mutex g_timing_mu;
+
+extern "C" int dyb_conv_timing_begin(int max_launches) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  DYB_REQUIRE(max_launches > 0 && !g_timing, DYB_ERR_ARG);
+  IgemmTiming* t = new IgemmTiming();
+  t->ev.resize((size_t)max_launches * 2);
+  for (auto& e : t->ev)
+    if (hipEventCreate(&e) != hipSuccess) return DYB_ERR_LAUNCH;
+  g_timing = t;
+  return DYB_OK;
+}
+// Closes the scope (the caller has synchronised the device): total kernel milliseconds, number of timed
+// launches, algorithmic flop and algorithmic bytes (operands read once + result written once) they stand for.
+extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, double* bytes) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  DYB_REQUIRE(g_timing && ms_total && launches && flop && bytes, DYB_ERR_ARG);
+  IgemmTiming* t = g_timing;
+  g_timing = nullptr;
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < t->used; i += 2) {
+    float one = 0.f;
+    if (hipEventElapsedTime(&one, t->ev[i], t->ev[i + 1]) == hipSuccess) ms += one;
+  }
+  *ms_total = ms; *launches = (long long)(t->used / 2); *flop = t->flop; *bytes = t->bytes;
+  for (auto& e : t->ev) (void)hipEventDestroy(e);
+  delete t;
+  return DYB_OK;
+}
+
 // Runs one mode.  If `raw_slabs_out` is non-null and the policy picks nsplit>1 the slabs are left
 // in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
@@ -707,20 +752,39 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!(fuse || nfuse) || d.N <= 64, DYB_ERR_UNSUPPORTED);
   const dim3 blk(256);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::unique_lock<std::mutex> tlock(g_timing_mu, std::defer_lock);
+  if (g_timing) tlock.lock();                 // unlocked fast path when no scope is open
+  if (g_timing && g_timing->used + 2 <= g_timing->ev.size()) {
+    ev0 = g_timing->ev[g_timing->used];
+    ev1 = g_timing->ev[g_timing->used + 1];
+    g_timing->used += 2;
+    const double creal = d.C == 4 ? 3.0 : (double)d.C;        // the stem's 4th input channel is padding
+    const double px = (double)d.N * conv_out_dim(d.H, d.R, d.stride, d.pad) * conv_out_dim(d.W, d.S, d.stride, d.pad);
+    g_timing->flop += 2.0 * px * d.K * d.R * d.S * creal;
+    g_timing->bytes += 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
+  }
+#define DYB_IGEMM_LAUNCH(M_, GB_, FA_)                                                                          \
+  do {                                                                                                          \
+    if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf); \
+    else hipLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, g, f, nf);                     \
+  } while (0)
   if (mode == MODE_FWD) {
     DYB_REQUIRE(!fuse, DYB_ERR_UNSUPPORTED);
-    if (nfuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false, true>), grid, blk, 0, st, g, f, nf);
-    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_FWD, false, false>), grid, blk, 0, st, g, f, nf);
+    if (nfuse) DYB_IGEMM_LAUNCH(MODE_FWD, false, true);
+    else DYB_IGEMM_LAUNCH(MODE_FWD, false, false);
   } else if (mode == MODE_DGRAD) {
     DYB_REQUIRE(!nfuse, DYB_ERR_UNSUPPORTED);
-    if (fuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, true, false>), grid, blk, 0, st, g, f, nf);
-    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_DGRAD, false, false>), grid, blk, 0, st, g, f, nf);
+    if (fuse) DYB_IGEMM_LAUNCH(MODE_DGRAD, true, false);
+    else DYB_IGEMM_LAUNCH(MODE_DGRAD, false, false);
   } else {
     DYB_REQUIRE(!nfuse || fuse, DYB_ERR_UNSUPPORTED);
-    if (fuse && nfuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true, true>), grid, blk, 0, st, g, f, nf);
-    else if (fuse) hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, true, false>), grid, blk, 0, st, g, f, nf);
-    else hipLaunchKernelGGL((igemm_mfma_kernel<MODE_WGRAD, false, false>), grid, blk, 0, st, g, f, nf);
+    if (fuse && nfuse) DYB_IGEMM_LAUNCH(MODE_WGRAD, true, true);
+    else if (fuse) DYB_IGEMM_LAUNCH(MODE_WGRAD, true, false);
+    else DYB_IGEMM_LAUNCH(MODE_WGRAD, false, false);
   }
+#undef DYB_IGEMM_LAUNCH
+  if (tlock.owns_lock()) tlock.unlock();
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }

@@ -100,6 +100,13 @@ int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, 
                                   float* dbeta, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                   void* ws, size_t ws_bytes, dyb_stream_t stream);
 
+/* Measurement aid for bench.py's roofline leg: between _begin and _end every convolution kernel launched
+ * from the calling thread is timed on its own dispatch (start/stop events on the launch, no extra stream
+ * packets).  _end (after a device synchronise) returns the summed kernel time, the launch count and the
+ * algorithmic flop / bytes those launches stand for. */
+int dyb_conv_timing_begin(int max_launches);
+int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, double* bytes);
+
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
 int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);
