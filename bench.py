@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--full_losses", type=int, default=0, help="1: the reference's default term set (teacher+motion+exemplars+dynamic loop)")
     ap.add_argument("--overlap", type=int, default=2,
                     help="1: metric / feature forwards on a side HIP stream (same results); 2: also issued from a second host thread")
+    ap.add_argument("--second_order", type=int, default=0,
+                    help="1: second-order MAML (BASELINE config 5's ablation arm); the reference and the default run are first-order")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_baseline_only", action="store_true")
@@ -155,6 +157,7 @@ def main():
     else:
         o = DB.frame_only_options(inner_step=args.inner_step)
     o.batch_size = args.batch
+    o.second_order = args.second_order
     o.deferred_metrics = 1
     o.overlap_metrics = args.overlap
     o.eval_lower = 1 if args.schedule == "faithful" else 0
@@ -216,9 +219,12 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
-                                      "inner_step=%d + 1 outer, first-order (reference parity mode), %s; schedule=%s "
+                                      "inner_step=%d + 1 outer, %s, %s; schedule=%s "
                                       "(%d HMR forwards + %d backwards per frame); metric/feature forwards %s" %
-                                      (args.batch, args.inner_step, "reference default loss set" if args.full_losses else "frame losses only",
+                                      (args.batch, args.inner_step,
+                                       "second-order (finite-difference Hessian-vector products: +2 forward+backward per inner step)"
+                                       if args.second_order else "first-order (reference parity mode)",
+                                       "reference default loss set" if args.full_losses else "frame losses only",
                                        args.schedule, fwd_pf, args.inner_step + 1,
                                        {0: "in line", 1: "overlapped on a side HIP stream",
                                         2: "overlapped on a side HIP stream issued by a second host thread"}[args.overlap]),

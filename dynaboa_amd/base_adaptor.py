@@ -83,7 +83,9 @@ class BaseAdaptor:
         ck = self._checkpoint()["model"]
         model = hmr(self._mean_params(), seed=0)
         if self.options.use_boa:
-            self.model = MAML(model, lr=self.options.fastlr, first_order=True).to(self.device)
+            # the reference hard-codes first_order=True (base_adaptor.py:119); `second_order` is this build's switch
+            self.model = MAML(model, lr=self.options.fastlr,
+                              first_order=not getattr(self.options, "second_order", 0)).to(self.device)
             self.model.load_state_dict(ck, strict=True)
         else:
             self.model = model.to(self.device)
@@ -235,36 +237,57 @@ class BaseAdaptor:
     def _level(self, level, image, gt_keypoints_2d, h36m_batch, learner):
         o = self.options
         tag = "ll" if level == "lower" else "ul"
+        quiet = getattr(self, "_replay", None) is not None     # a second-order re-evaluation: no logging, same exemplars
         rot, shape, cam, feats = learner(image, need_feature=True)
         smpl_out = self.decode_smpl_params(rot, shape)
         s3d = smpl_out["s3d"]
         loss = None
         s2d = None
+        log = {} if quiet else self.fit_losses
         if getattr(o, f"use_frame_losses_{level}"):
             loss, comps = frame_losses(rot, shape, cam, s3d, gt_keypoints_2d, self.gmm_f, o.s2dloss_weight,
                                        o.shape_prior_weight, o.pose_prior_weight)
-            if level == "lower":
-                self.kp2dlosses_lower.append(comps[0])
-            else:
-                self.kp2dlosses_upper[self.global_step] = comps[0]
-            self.fit_losses[f"{tag}/s2dloss"], self.fit_losses[f"{tag}/shape_prior"] = comps[0], comps[1]
-            self.fit_losses[f"{tag}/pose_prior"], self.fit_losses[f"{tag}/unlabelloss"] = comps[2], loss.detach()
-        if getattr(o, f"use_temporal_losses_{level}"):
-            s2d = self.projection(cam, s3d)["normed"]
-            if o.use_meanteacher:
-                t = self.cal_teacher_loss(image, rot, shape, s2d, s3d) * o.teacherloss_weight
-                loss = t if loss is None else loss + t
-            if o.use_motion and (self.global_step - o.interval) > 0:
-                loss = loss + self.cal_motion_loss(learner, s2d[:, 25:], gt_keypoints_2d[:, 25:], prefix="ul") * o.motionloss_weight
-        if o.retrieval:
-            h36m_batch = self.retrieval(feats[5])
-        if getattr(o, f"{level}_level_mixtrain"):
-            lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag)
-            loss = loss + lab * o.labelloss_weight
+            if not quiet:
+                if level == "lower":
+                    self.kp2dlosses_lower.append(comps[0])
+                else:
+                    self.kp2dlosses_upper[self.global_step] = comps[0]
+            log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"] = comps[0], comps[1]
+            log[f"{tag}/pose_prior"], log[f"{tag}/unlabelloss"] = comps[2], loss.detach()
+        keep, self.fit_losses = self.fit_losses, log           # the term helpers below log into self.fit_losses
+        try:
+            if getattr(o, f"use_temporal_losses_{level}"):
+                s2d = self.projection(cam, s3d)["normed"]
+                if o.use_meanteacher:
+                    t = self.cal_teacher_loss(image, rot, shape, s2d, s3d) * o.teacherloss_weight
+                    loss = t if loss is None else loss + t
+                if o.use_motion and (self.global_step - o.interval) > 0:
+                    loss = loss + self.cal_motion_loss(learner, s2d[:, 25:], gt_keypoints_2d[:, 25:], prefix="ul") * o.motionloss_weight
+            if o.retrieval:
+                h36m_batch = self._replay["h36m"] if quiet else self.retrieval(feats[5])
+            self._last_h36m = h36m_batch
+            if getattr(o, f"{level}_level_mixtrain"):
+                lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag)
+                loss = loss + lab * o.labelloss_weight
+        finally:
+            self.fit_losses = keep
         # the reference builds the sum with in-place `loss += ...` on the tensor it stored as
         # '<tag>/unlabelloss' (base_adaptor.py:244,250,254,266), so what it logs under that key is this total
-        self.fit_losses[f"{tag}/total"] = loss.detach()
+        log[f"{tag}/total"] = loss.detach()
         return loss, feats
+
+    def level_closure(self, level, image, gt_keypoints_2d, h36m_batch):
+        """The loss `_level` just returned, as a function of the learner (for MAML.adapt(..., closure=) in
+        second-order mode): same data, same retrieved exemplars, nothing logged."""
+        used = getattr(self, "_last_h36m", None)
+
+        def closure(learner):
+            self._replay = dict(h36m=used)
+            try:
+                return self._level(level, image, gt_keypoints_2d, h36m_batch, learner)[0]
+            finally:
+                self._replay = None
+        return closure
 
     def lower_level_adaptation(self, image, gt_keypoints_2d, h36m_batch, learner=None):
         return self._level("lower", image, gt_keypoints_2d, h36m_batch, learner)

@@ -64,6 +64,9 @@ parser.add_argument('--interval', type=int, default=5)
 parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
+parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
+                    help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
+                         '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')
 parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
 parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
@@ -228,7 +231,10 @@ class Adaptor(BaseAdaptor):
         learner = self.model.clone()
         for i in range(o.inner_step):
             lower_loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
-            learner.adapt(lower_loss)
+            if learner.first_order:
+                learner.adapt(lower_loss)           # the reference's call (dynaboa_benchmark.py:140)
+            else:
+                learner.adapt(lower_loss, closure=self.level_closure("lower", image, gt_keypoints_2d, h36m_batch))
             if o.eval_lower:
                 m, p, _ = self.inference(batch, learner, tag=('lower', i))
                 self.mpjpe_all_lower[i].append(m); self.pampjpe_all_lower[i].append(p)

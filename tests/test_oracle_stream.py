@@ -59,3 +59,23 @@ def test_stream(tag, gmm_t, smpl_tabs):
     if "teacher_delta_norms" in g.files and ad.o["use_meanteacher"]:
         tn = np.array([float((ad.teacher[k].double() - sd0[k].double()).norm()) for k in names])
         np.testing.assert_allclose(tn, g["teacher_delta_norms"], rtol=1e-2)
+
+
+@pytest.mark.slow
+def test_second_order_first_frame_gradient(gmm_t, smpl_tabs):
+    """The oracle in second-order mode reproduces the reference's outer gradient under learn2learn
+    first_order=False (golden g5_so_*), which sits 16-40 % away from the first-order gradient of the same
+    frame (golden g5_fo_inner2_*): the two goldens are far enough apart for the test to tell them apart."""
+    gso, gfo = golden("g5_so_inner2_frameonly.npz"), golden("g5_fo_inner2_frameonly.npz")
+    mp = assets.make_smpl_mean_params(identity_pose=False, seed=3)
+    sd = assets.make_synthetic_checkpoint(22, mp, randomize_norm=True, prefix="")["model"]
+    ad = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, dict(FRAME_ONLY, inner_step=2), first_order=False)
+    torch.set_num_threads(8)
+    rec = ad.adapt_frame(assets.make_frame(0, 1, seed=22))
+    names = [str(x) for x in gso["names"]]
+    gn = np.array([float(rec["outer_grad"][k].double().norm()) for k in names])
+    np.testing.assert_allclose(gn, gso["g1_norms"], rtol=2e-2)
+    assert np.median(np.abs(gso["g1_norms"] - gfo["g1_norms"]) / gfo["g1_norms"]) > 0.05
+    for k in SLICE_PARAMS:
+        x = rec["outer_grad"][k].flatten()[:256].double().numpy()
+        assert rel_err(x, gso["g1_" + k]) < 0.1 * rel_err(gfo["g1_" + k], gso["g1_" + k]) + 2e-2, k

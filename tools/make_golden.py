@@ -230,7 +230,7 @@ def g3(out):
 
 
 # ---------------------------------------------------------------------------- adaptor under test
-def make_ref_adaptor(opts_over, identity_pose=False, randomize_norm=True, smpl_seed=0):
+def make_ref_adaptor(opts_over, identity_pose=False, randomize_norm=True, smpl_seed=0, first_order=True):
     import dynaboa_benchmark as DB          # reference module (stubs installed)
     prior = load_file("ref_prior", "utils/smplify/prior.py")
     opts = DB.parser.parse_args([])
@@ -243,7 +243,7 @@ def make_ref_adaptor(opts_over, identity_pose=False, randomize_norm=True, smpl_s
     a.exppath = tempfile.mkdtemp()
     os.makedirs(os.path.join(a.exppath, "result"), exist_ok=True)
     model, sd = build_ref_hmr(randomize_norm=randomize_norm, identity_pose=identity_pose)
-    a.model = MAMLStub(model, lr=opts.fastlr, first_order=True).eval()
+    a.model = MAMLStub(model, lr=opts.fastlr, first_order=first_order).eval()
     a.optimizer = torch.optim.Adam(a.model.parameters(), lr=opts.lr, betas=(opts.beta1, opts.beta2),
                                    foreach=False)
     if opts.use_meanteacher:
@@ -301,8 +301,8 @@ def g4(out):
 
 
 # ---------------------------------------------------------------------------- G5 adaptation stream
-def run_stream(tag, out, opts_over, nframes, identity_pose=False):
-    a, sd0 = make_ref_adaptor(opts_over, identity_pose=identity_pose)
+def run_stream(tag, out, opts_over, nframes, identity_pose=False, first_order=True):
+    a, sd0 = make_ref_adaptor(opts_over, identity_pose=identity_pose, first_order=first_order)
     names = [n for n, _ in a.model.module.named_parameters()]
     theta0 = {n: p.detach().clone() for n, p in a.model.module.named_parameters()}
     rec = dict(lower=[], upper=[], mpjpe=[], pampjpe=[], pve=[], steps=[])
@@ -323,6 +323,14 @@ def run_stream(tag, out, opts_over, nframes, identity_pose=False):
             so = a.decode_smpl_params(r, s)
         preds.append(dict(rotmat=r.numpy(), shape=s.numpy(), cam=c.numpy(), joints=so["s3d"].numpy(),
                           vsum=np.array([float(so["vts"].double().sum()), float(so["vts"].double().abs().sum())])))
+        if step == 0:
+            # after the first Adam step exp_avg = (1 - beta1) * outer gradient: the gradient itself, per tensor
+            st0 = a.optimizer.state
+            pm0 = dict(zip(names, a.model.module.parameters()))
+            first = dict(g1_norms=np.array([float(st0[pm0[n]]["exp_avg"].double().norm()) / (1 - opts_over.get("beta1", a.options.beta1))
+                                            for n in names]))
+            for n in SLICE_PARAMS:
+                first["g1_" + n] = head(st0[pm0[n]]["exp_avg"]) / (1 - a.options.beta1)
     st = a.optimizer.state
     pmap = dict(zip(names, a.model.module.parameters()))
     payload = dict(
@@ -338,6 +346,7 @@ def run_stream(tag, out, opts_over, nframes, identity_pose=False):
         payload["d_" + n] = head(pmap[n].detach().double() - theta0[n].double())
         payload["m_" + n] = head(st[pmap[n]]["exp_avg"])
         payload["v_" + n] = head(st[pmap[n]]["exp_avg_sq"])
+    payload.update(first)
     for i, p in enumerate(preds):
         for k, v in p.items():
             payload[f"pred{i}_{k}"] = v
@@ -357,6 +366,16 @@ def g5(out):
     # the reference's full default term set (teacher + motion + labelled exemplars + dynamic loop)
     run_stream("fo_inner1_full", out, dict(inner_step=1, interval=2, optim_steps=2), 5)
     g5_forced(out)
+
+
+def g5so(out):
+    """Second-order MAML (learn2learn first_order=False: create_graph=True through every inner adapt) and its
+    first-order twin on the same stream: the pair lets a test show an implementation follows the SO gradient and
+    not merely the FO one (they differ by the alpha * Hessian-vector terms)."""
+    frame_only = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0,
+                      use_motion=0, dynamic_boa=0, use_temporal_losses_upper=0)
+    run_stream("so_inner2_frameonly", out, dict(frame_only, inner_step=2), 2, first_order=False)
+    run_stream("fo_inner2_frameonly", out, dict(frame_only, inner_step=2), 2, first_order=True)
 
 
 def g5_forced(out):

@@ -26,12 +26,15 @@ def main(path, out):
     agg = defaultdict(lambda: [0, 0.0])
     byname = defaultdict(lambda: [0, 0.0])
     byq = defaultdict(lambda: [0, 0.0])
+    byqk = defaultdict(lambda: [0, 0.0])
     for s, e, name, grid, wg, q in rows[lo:hi]:
         short = name.split("(")[0].replace("void ", "").split("<")[0]
         byname[short][0] += 1
         byname[short][1] += e - s
         byq[q][0] += 1
         byq[q][1] += e - s
+        byqk[(q, short)][0] += 1
+        byqk[(q, short)][1] += e - s
     for s, e, name, grid, wg, q in rows[lo:hi]:
         short = name.split("(")[0].replace("void ", "")
         blocks = tuple(g // wg if i == 0 else g for i, g in enumerate(grid))
@@ -44,11 +47,15 @@ def main(path, out):
                            p90=float(np.percentile(gaps, 90) / 1e3), p99=float(np.percentile(gaps, 99) / 1e3)),
                by_kernel_grid=[dict(k=k, calls=c, avg_us=round(a, 2), total_us=round(t, 1)) for k, c, a, t in table[:70]])
     res["by_kernel"] = [dict(k=k, calls=c, total_us=round(t / 1e3, 1)) for k, (c, t) in sorted(byname.items(), key=lambda x: -x[1][1])]
+    res["by_queue_kernel"] = [dict(q=q, k=k, calls=c, total_us=round(t / 1e3, 1))
+                              for (q, k), (c, t) in sorted(byqk.items(), key=lambda x: (x[0][0], -x[1][1]))]
     res["by_queue"] = {q: dict(kernels=c, busy_ms=t / 1e6) for q, (c, t) in byq.items()}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: v for k, v in res.items() if k not in ("by_kernel_grid", "by_kernel", "by_queue")}))
+    print(json.dumps({k: v for k, v in res.items() if k not in ("by_kernel_grid", "by_kernel", "by_queue", "by_queue_kernel")}))
     print(res["by_queue"])
     for r in res["by_kernel"][:40]:
+        print(r)
+    for r in res["by_queue_kernel"]:
         print(r)
 
 
