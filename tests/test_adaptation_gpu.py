@@ -262,7 +262,8 @@ def test_second_order_needs_closure():
     from dynaboa_amd import assets
     ad, _ = make_adaptor(dict(FRAME_ONLY, inner_step=1, second_order=1), False)
     batch = {k: v.to(ad.device) for k, v in assets.make_frame(0, 1, seed=22).items()}
+    ad.model.eval()
     learner = ad.model.clone()
     loss, _ = ad.lower_level_adaptation(batch["image"], batch["smpl_j2d"], None, learner)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="closure"):
         learner.adapt(loss)
