@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from . import assets as A
 from . import constants
 from .hmr import hmr
+from .fused_level import level_forward
 from .losses import MaxMixturePrior, frame_losses, pose_prior, projection_normed
 from .maml import MAML
 from .optim import Adam, ema_update
@@ -238,15 +239,24 @@ class BaseAdaptor:
         o = self.options
         tag = "ll" if level == "lower" else "ul"
         quiet = getattr(self, "_replay", None) is not None     # a second-order re-evaluation: no logging, same exemplars
-        rot, shape, cam, feats = learner(image, need_feature=True)
-        smpl_out = self.decode_smpl_params(rot, shape)
-        s3d = smpl_out["s3d"]
         loss = None
         s2d = None
         log = {} if quiet else self.fit_losses
+        fused = getattr(o, "fused_level", 1) and getattr(o, f"use_frame_losses_{level}")
+        if fused:
+            # model -> SMPL -> frame-loss head as ONE autograd node (fused_level.py); same numbers as the
+            # three-module composition below, which stays for use_frame_losses_* = 0 and as the cross-check
+            loss, comps, rot, shape, cam, s3d, _vts, feats = level_forward(
+                learner, self.smpl_neutral, self.gmm_f, image, gt_keypoints_2d, o.s2dloss_weight, o.shape_prior_weight,
+                o.pose_prior_weight)
+        else:
+            rot, shape, cam, feats = learner(image, need_feature=True)
+            smpl_out = self.decode_smpl_params(rot, shape)
+            s3d = smpl_out["s3d"]
         if getattr(o, f"use_frame_losses_{level}"):
-            loss, comps = frame_losses(rot, shape, cam, s3d, gt_keypoints_2d, self.gmm_f, o.s2dloss_weight,
-                                       o.shape_prior_weight, o.pose_prior_weight)
+            if not fused:
+                loss, comps = frame_losses(rot, shape, cam, s3d, gt_keypoints_2d, self.gmm_f, o.s2dloss_weight,
+                                           o.shape_prior_weight, o.pose_prior_weight)
             if not quiet:
                 if level == "lower":
                     self.kp2dlosses_lower.append(comps[0])

@@ -67,6 +67,9 @@ parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
                     help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
                          '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')
+parser.add_argument('--fused_level', type=int, default=1, choices=[0, 1],
+                    help='1: model -> SMPL -> frame-loss head of each adaptation level as one autograd node (same results); '
+                         '0: the three-module composition')
 parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
 parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '

@@ -33,7 +33,10 @@
 
 #define BM 64
 #define BN 64
+#ifndef BK
 #define BK 32
+#endif
+#define NH (BK / 16)      // 16-byte pieces per operand per thread per K-step
 #define LDS_LD (64 + 4)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -416,12 +419,14 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  Frag ra[2], rb[2];
+  Frag ra[NH], rb[NH];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { ra[h].d = ra[h].v = ra[h].ga = zero4; ra[h].ok = false; rb[h] = ra[h]; }
+  for (int h = 0; h < NH; ++h) { ra[h].d = ra[h].v = ra[h].ga = zero4; ra[h].ok = false; rb[h] = ra[h]; }
   if (kt_begin < kt_end) {
-    load_a(kt_begin, 0, ra[0]); load_a(kt_begin, 1, ra[1]);
-    load_b(kt_begin, 0, rb[0]); load_b(kt_begin, 1, rb[1]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) load_a(kt_begin, h, ra[h]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) load_b(kt_begin, h, rb[h]);
   }
   if constexpr (GB) {
     // fold the per-chunk group sums into (c1, c2) for every image: 8 values per image, L lanes each
@@ -506,16 +511,18 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 
   if (kt_begin < kt_end) {
     // register prefetch one K-step ahead, two LDS buffers, one barrier per step
-    store_a(0, kt_begin, 0, ra[0]); store_a(0, kt_begin, 1, ra[1]);
-    store_b(0, kt_begin, 0, rb[0]); store_b(0, kt_begin, 1, rb[1]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { store_a(0, kt_begin, h, ra[h]); store_b(0, kt_begin, h, rb[h]); }
     __syncthreads();
     const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int buf = (kt - kt_begin) & 1;
       const bool more = kt + 1 < kt_end;
       if (more) {
-        load_a(kt + 1, 0, ra[0]); load_a(kt + 1, 1, ra[1]);
-        load_b(kt + 1, 0, rb[0]); load_b(kt + 1, 1, rb[1]);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) load_a(kt + 1, h, ra[h]);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) load_b(kt + 1, h, rb[h]);
       }
 #pragma unroll
       for (int k2 = 0; k2 < BK; k2 += 2) {
@@ -524,8 +531,8 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
       if (more) {
-        store_a(buf ^ 1, kt + 1, 0, ra[0]); store_a(buf ^ 1, kt + 1, 1, ra[1]);
-        store_b(buf ^ 1, kt + 1, 0, rb[0]); store_b(buf ^ 1, kt + 1, 1, rb[1]);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { store_a(buf ^ 1, kt + 1, h, ra[h]); store_b(buf ^ 1, kt + 1, h, rb[h]); }
       }
       __syncthreads();
     }

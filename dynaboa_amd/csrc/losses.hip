@@ -364,3 +364,55 @@ extern "C" int dyb_frame_losses(const float* rotmat, const float* shape, int lds
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+
+// ---- gradient assembly of the fused HMR + SMPL + frame-loss autograd node (dynaboa_amd/fused_level.py) ----
+// out[i] = g * a[i] (+ ext[i]);  g: device scalar (the incoming gradient of the loss total), NULL = 1
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                        const float* __restrict__ ext, float* __restrict__ out, size_t n) {
+  const float s = g ? g[0] : 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = s * a[i] + (ext ? ext[i] : 0.f);
+}
+extern "C" int dyb_scale_add(const float* g, const float* a, const float* ext, float* out, size_t n, hipStream_t st) {
+  DYB_REQUIRE(a && out && n > 0, DYB_ERR_ARG);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(scale_add_kernel, dim3(blocks), dim3(256), 0, st, g, a, ext, out, n);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// d_rot[B][216]   = g*drot_loss + drot_smpl (+ drot_ext)
+// d_state[B][160] : cols 144..153 = g*dshape_loss + dbetas_smpl (+ dshape_ext), cols 154..156 = g*dcam_loss (+ dcam_ext)
+// (exactly what dyb_hmr_backward consumes; the loss-side pieces come from dyb_frame_losses, the SMPL-side ones from dyb_lbs_bwd)
+struct HeadGradArgs {
+  const float *g, *drot_l, *drot_s, *drot_e, *dshape_l, *dbetas_s, *dshape_e, *dcam_l, *dcam_e;
+  float *d_rot, *d_state;
+  int B;
+};
+__global__ __launch_bounds__(256) void head_grad_kernel(HeadGradArgs a) {
+  const float s = a.g ? a.g[0] : 1.f;
+  const int per = 216 + 13;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B * per; i += gridDim.x * 256) {
+    const int b = i / per, j = i % per;
+    if (j < 216) {
+      const int o = b * 216 + j;
+      a.d_rot[o] = s * a.drot_l[o] + a.drot_s[o] + (a.drot_e ? a.drot_e[o] : 0.f);
+    } else if (j < 226) {
+      const int c = j - 216;
+      a.d_state[b * 160 + 144 + c] = s * a.dshape_l[b * 10 + c] + a.dbetas_s[b * 10 + c] + (a.dshape_e ? a.dshape_e[b * 10 + c] : 0.f);
+    } else {
+      const int c = j - 226;
+      a.d_state[b * 160 + 154 + c] = s * a.dcam_l[b * 3 + c] + (a.dcam_e ? a.dcam_e[b * 3 + c] : 0.f);
+    }
+  }
+}
+extern "C" int dyb_head_grad_combine(const float* g, const float* drot_loss, const float* drot_smpl, const float* drot_ext,
+                                     const float* dshape_loss, const float* dbetas_smpl, const float* dshape_ext,
+                                     const float* dcam_loss, const float* dcam_ext, float* d_rot, float* d_state, int B,
+                                     hipStream_t st) {
+  DYB_REQUIRE(drot_loss && drot_smpl && dshape_loss && dbetas_smpl && dcam_loss && d_rot && d_state && B > 0, DYB_ERR_ARG);
+  HeadGradArgs a{g, drot_loss, drot_smpl, drot_ext, dshape_loss, dbetas_smpl, dshape_ext, dcam_loss, dcam_ext, d_rot, d_state, B};
+  hipLaunchKernelGGL(head_grad_kernel, dim3(dyb_cdiv(B * 229, 256)), dim3(256), 0, st, a);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

@@ -163,6 +163,16 @@ int dyb_frame_losses(const float* rotmat, const float* shape, int lds, const flo
                      float wshape, float wpose, float* losses_out, float* drot, float* dshape, int ldds, float* dcam,
                      int lddc, float* djoints49, int B, void* ws, size_t ws_bytes, dyb_stream_t stream);
 
+/* Gradient assembly of the fused HMR + SMPL + frame-loss node (one autograd node per adaptation level instead
+ * of three plus glue): out = g*a (+ ext) with g a device scalar (NULL = 1), and the d_rotmat / d_state inputs of
+ * dyb_hmr_backward from the dyb_frame_losses pieces (scaled by g), the dyb_lbs_bwd pieces and optional external
+ * gradients on rotmat / shape / cam (teacher, motion and label terms attach there). */
+int dyb_scale_add(const float* g, const float* a, const float* ext, float* out, size_t n, dyb_stream_t stream);
+int dyb_head_grad_combine(const float* g, const float* drot_loss, const float* drot_smpl, const float* drot_ext,
+                          const float* dshape_loss, const float* dbetas_smpl, const float* dshape_ext,
+                          const float* dcam_loss, const float* dcam_ext, float* d_rot, float* d_state, int B,
+                          dyb_stream_t stream);
+
 /* ---- flat-arena updates: learn2learn MAML.adapt (call sites dynaboa_benchmark.py:136,140),
  * torch.optim.Adam (base_adaptor.py:126; dynaboa_benchmark.py:149-151), update_teacher
  * (base_adaptor.py:193-201), cal_feature_diff's cosine (:211-219). n = float count, multiple of 4. */
