@@ -288,4 +288,4 @@ def test_fused_level_node_matches_three_module_composition():
     m0, m1 = res[("full", 0)][1], res[("full", 1)][1]
     assert float((m0 - m1).norm() / m0.norm()) < 2e-3          # ReLU-flip noise class, see DESIGN.md 4
     d0 = res[("full", 0)][0] - res[("full", 1)][0]
-    assert float(d0.abs().max()) < 1e-6
+    assert float(d0.abs().max()) < 5e-6                       # three Adam steps of lr 3e-6
