@@ -253,6 +253,8 @@ class BaseAdaptor:
             rot, shape, cam, feats = learner(image, need_feature=True)
             smpl_out = self.decode_smpl_params(rot, shape)
             s3d = smpl_out["s3d"]
+        if not quiet:
+            self._level_pred = (rot.detach(), shape.detach(), cam.detach())     # what inference() with these weights returns
         if getattr(o, f"use_frame_losses_{level}"):
             if not fused:
                 loss, comps = frame_losses(rot, shape, cam, s3d, gt_keypoints_2d, self.gmm_f, o.s2dloss_weight,

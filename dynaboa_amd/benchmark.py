@@ -67,6 +67,10 @@ parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
                     help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
                          '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')
+parser.add_argument('--share_forwards', type=int, default=1, choices=[0, 1],
+                    help='1: forwards the reference schedule repeats with identical weights and input (the un-adapted '
+                         'feature forward, the inference() after each inner step) reuse the level forward of the same '
+                         'weights - identical results, 5 instead of 9 HMR forwards per frame at inner_step 3')
 parser.add_argument('--fused_level', type=int, default=1, choices=[0, 1],
                     help='1: model -> SMPL -> frame-loss head of each adaptation level as one autograd node (same results); '
                          '0: the three-module composition')
@@ -213,6 +217,7 @@ class Adaptor(BaseAdaptor):
             mpjpe_all.append(mpjpe); pampjpe_all.append(pampjpe); pve_all.append(pve)
         if self.options.deferred_metrics:
             final = self.flush_metrics()
+            self.metric_records = final["records"]          # every inference() of the run, incl. the per-inner-step ones
             mpjpe_all, pampjpe_all, pve_all = final["mpjpe"], final["pampjpe"], final["pve"]
         self.results = dict(mpjpe=mpjpe_all, pampjpe=pampjpe_all, pve=pve_all)
         return self.results
@@ -226,22 +231,42 @@ class Adaptor(BaseAdaptor):
             loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, None, self.model)
             self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
             return self.inference(batch, self.model)
-        def _feats():
-            with torch.no_grad():
-                return self.model(image, need_feature=True)[3]
-        init_features = self._on_side(_feats, image)
+        # Forward sharing (share_forwards=1): the reference's schedule evaluates several forwards whose weights AND
+        # input are identical to a level forward of the same frame - the un-adapted feature forward (= lower level 0,
+        # the learner being a fresh clone) and every inference() after an inner step (= the next level's forward with
+        # the same fast weights).  Same kernels, same inputs => same bits, so those results are taken from the level
+        # forwards: 9 HMR forwards per frame become 5 with every output of the reference schedule still produced.
+        share = bool(getattr(o, "share_forwards", 1))
+        if not share:
+            def _feats():
+                with torch.no_grad():
+                    return self.model(image, need_feature=True)[3]
+            init_features = self._on_side(_feats, image)
         h36m_batch = None
         learner = self.model.clone()
+        owed = None                              # (tag, learner) of an inference() waiting for the next level forward
         for i in range(o.inner_step):
-            lower_loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
+            lower_loss, lfeats = self.lower_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
+            if share and i == 0:
+                init_features = [f.detach() for f in lfeats]
+            if owed is not None:
+                m, p, _ = self.inference(batch, learner, tag=owed, _pred=self._level_pred)
+                self.mpjpe_all_lower[owed[1]].append(m); self.pampjpe_all_lower[owed[1]].append(p)
+                owed = None
             if learner.first_order:
                 learner.adapt(lower_loss)           # the reference's call (dynaboa_benchmark.py:140)
             else:
                 learner.adapt(lower_loss, closure=self.level_closure("lower", image, gt_keypoints_2d, h36m_batch))
             if o.eval_lower:
-                m, p, _ = self.inference(batch, learner, tag=('lower', i))
-                self.mpjpe_all_lower[i].append(m); self.pampjpe_all_lower[i].append(p)
+                if share:
+                    owed = ('lower', i)
+                else:
+                    m, p, _ = self.inference(batch, learner, tag=('lower', i))
+                    self.mpjpe_all_lower[i].append(m); self.pampjpe_all_lower[i].append(p)
         upper_loss, _ = self.upper_level_adaptation(image, gt_keypoints_2d, h36m_batch, learner)
+        if owed is not None:
+            m, p, _ = self.inference(batch, learner, tag=owed, _pred=self._level_pred)
+            self.mpjpe_all_lower[owed[1]].append(m); self.pampjpe_all_lower[owed[1]].append(p)
         self.optimizer.zero_grad()
         upper_loss.backward()
         self._join_side()                       # side-stream readers of theta must be done before the in-place step
@@ -297,17 +322,23 @@ class Adaptor(BaseAdaptor):
               "dyb_regress_joints")
         return out.index_select(1, self._j14_idx) - out[:, 0:1, :]
 
-    def inference(self, batch, model, need_feature=False, tag=None, _step=None):
+    def inference(self, batch, model, need_feature=False, tag=None, _step=None, _pred=None):
+        """reference dynaboa_benchmark.py:204-262.  `_pred` = (rotmat, shape, cam) of a forward that already ran with
+        exactly these weights on this image (adaptation() shares the level forwards, see there): the model call is
+        skipped, everything downstream is the same code."""
         step = self.global_step if _step is None else _step
         if self._side is not None and self.options.deferred_metrics and not need_feature \
                 and torch.cuda.current_stream(self.device) != self._side:
-            reads = [self._theta_of(model)] + [v for v in batch.values() if torch.is_tensor(v)]
-            out = self._on_side(lambda: self.inference(batch, model, need_feature, tag, _step=step), *reads)
+            reads = [self._theta_of(model)] + [v for v in batch.values() if torch.is_tensor(v)] + list(_pred or ())
+            out = self._on_side(lambda: self.inference(batch, model, need_feature, tag, _step=step, _pred=_pred), *reads)
             return (None, None, None) if isinstance(out, dict) else out      # deferred: values come from flush_metrics()
         image, gt_pose, gt_betas, gender = batch['image'], batch['pose'], batch['betas'], batch['gender']
         model.eval()
         with torch.no_grad():
-            out = model(image, need_feature)
+            if _pred is not None and not need_feature:
+                out = _pred
+            else:
+                out = model(image, need_feature)
             pred_rotmat, pred_shape, pred_cam = out[0], out[1], out[2]
             smpl_out = self.decode_smpl_params(pred_rotmat, pred_shape)
             pred_vertices = smpl_out['vts']

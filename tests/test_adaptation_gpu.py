@@ -289,3 +289,25 @@ def test_fused_level_node_matches_three_module_composition():
     assert float((m0 - m1).norm() / m0.norm()) < 2e-3          # ReLU-flip noise class, see DESIGN.md 4
     d0 = res[("full", 0)][0] - res[("full", 1)][0]
     assert float(d0.abs().max()) < 5e-6                       # three Adam steps of lr 3e-6
+
+
+def test_shared_forwards_are_bit_identical():
+    """share_forwards=1 takes the un-adapted feature forward and every per-inner-step inference() from the level
+    forward with the same weights instead of recomputing them: weights, Adam state and every metric must be
+    identical to the 9-forward schedule, for the frame-only stream and for the full loss set with the dynamic loop."""
+    from dynaboa_amd import assets
+    frames = [{k: v.to("cuda:0") for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(3)]
+    for opts, ident in (STREAMS["fo_inner3_frameonly"], STREAMS["fo_inner1_full_forced"]):
+        outs = []
+        for share in (0, 1):
+            ad, _ = make_adaptor(dict(opts, share_forwards=share, eval_lower=1), ident, deferred=1)
+            res = ad.excute(frames, nframes=3)
+            recs = sorted(((r["step"], r["tag"], float(np.ravel(r["mpjpe"])[0]), float(np.ravel(r["pampjpe"])[0]), r["pve"])
+                           for r in ad.metric_records), key=lambda t: (t[0], str(t[1])))
+            outs.append((ad.model.module.theta.detach().clone(), res, recs, ad.optim_step_record))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k in ("mpjpe", "pampjpe", "pve"):
+            np.testing.assert_array_equal(np.array(outs[0][1][k], dtype=np.float64).ravel(), np.array(outs[1][1][k], dtype=np.float64).ravel())
+        assert outs[0][3] == outs[1][3]
+        assert len(outs[0][2]) == len(outs[1][2]) and len(outs[0][2]) >= 3 * (1 + opts["inner_step"])
+        assert outs[0][2] == outs[1][2]                      # every inference() record, per-inner-step ones included
