@@ -22,7 +22,7 @@ from . import _lib
 from ._abi import check
 from .base_adaptor import BaseAdaptor
 from .hmr import stream_of
-from .pose_utils import compute_similarity_transform_batch
+from .pose_utils import compute_similarity_transform_batch, pa_mpjpe_device  # noqa: F401  (the NumPy form stays importable from here, as in the reference)
 
 parser = argparse.ArgumentParser()
 parser.add_argument('--expdir', type=str, default='exps')
@@ -362,13 +362,12 @@ class Adaptor(BaseAdaptor):
             self._pending.append(dict(step=step, tag=tag, pred=pred14, gt=gt14, mpjpe=mpjpe_t, pve=pve_t))
             res = (mpjpe_t, None, pve_t)
         else:
-            S1, S2 = pred14.cpu().numpy(), gt14.cpu().numpy()
-            pa = np.sqrt(((compute_similarity_transform_batch(S1, S2) - S2) ** 2).sum(-1)).mean(-1)
+            pa = pa_mpjpe_device(pred14, gt14).cpu().numpy()
             res = (mpjpe_t.cpu().numpy() * 1000, pa * 1000, float(pve_t) * 1000)
         return res + (out[3],) if need_feature else res
 
     def flush_metrics(self):
-        """Resolve deferred records with one device->host transfer (and one batched SVD)."""
+        """Resolve deferred records: one Procrustes launch over every record, one device->host transfer of scalars."""
         if self._side is not None:
             self._join_side()
             self._side.synchronize()
@@ -376,13 +375,14 @@ class Adaptor(BaseAdaptor):
         self._pending = []
         if not rec:
             return dict(mpjpe=[], pampjpe=[], pve=[], records=[])
-        pred = torch.stack([r['pred'] for r in rec]).cpu().numpy()
-        gt = torch.stack([r['gt'] for r in rec]).cpu().numpy()
-        mp = torch.stack([r['mpjpe'] for r in rec]).cpu().numpy() * 1000
-        pve = torch.stack([r['pve'] for r in rec]).cpu().numpy() * 1000
+        pred = torch.stack([r['pred'] for r in rec])
+        gt = torch.stack([r['gt'] for r in rec])
         n, B = pred.shape[0], pred.shape[1]
-        hat = compute_similarity_transform_batch(pred.reshape(n * B, 14, 3), gt.reshape(n * B, 14, 3))
-        pa = np.sqrt(((hat - gt.reshape(n * B, 14, 3)) ** 2).sum(-1)).mean(-1).reshape(n, B) * 1000
+        # Procrustes on the device: only scalars cross PCIe (one transfer for the whole run)
+        pa_t = pa_mpjpe_device(pred.reshape(n * B, 14, 3), gt.reshape(n * B, 14, 3)).view(n, B)
+        allm = torch.cat([torch.stack([r['mpjpe'] for r in rec]).reshape(n, B), pa_t,
+                          torch.stack([r['pve'] for r in rec]).reshape(n, 1)], 1).cpu().numpy() * 1000
+        mp, pa, pve = allm[:, :B], allm[:, B:2 * B], allm[:, 2 * B]
         out = dict(mpjpe=[], pampjpe=[], pve=[], records=[])
         for i, r in enumerate(rec):
             out['records'].append(dict(step=r['step'], tag=r['tag'], mpjpe=mp[i], pampjpe=pa[i], pve=float(pve[i])))

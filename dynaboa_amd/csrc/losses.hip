@@ -416,3 +416,109 @@ extern "C" int dyb_head_grad_combine(const float* g, const float* drot_loss, con
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+
+// ---- PA-MPJPE on the device: reference utils/pose_utils.py:9-57 (compute_similarity_transform) + the error of
+// dynaboa_benchmark.py:236-240, one thread per sample.  Similarity-align pred (J x 3) onto gt: centre both,
+// K = X1^T X2, SVD K = U S V^T, R = V diag(1,1,sign det(U V^T)) U^T, scale = tr(R K)/|X1|^2, t = mu2 - scale R mu1;
+// out = mean_j |scale R p_j + t - g_j|.  The 3x3 SVD is a one-sided Jacobi in double (converges in <= 6 sweeps;
+// tr(R K) = s1 + s2 + z s3 needs no explicit product); the rotation is unique whenever rank(K) >= 2.
+__device__ void pa_svd3(const double K[3][3], double U[3][3], double S[3], double V[3][3]) {
+  double A[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { A[i][j] = K[i][j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double a = 0.0, b = 0.0, c = 0.0;          // |col p|^2, |col q|^2, col p . col q
+        for (int i = 0; i < 3; ++i) { a += A[i][p] * A[i][p]; b += A[i][q] * A[i][q]; c += A[i][p] * A[i][q]; }
+        off += c * c;
+        if (fabs(c) <= 1e-300 || c * c <= 1e-32 * a * b) continue;
+        double zeta = (b - a) / (2.0 * c);
+        double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < 3; ++i) {
+          double x = A[i][p], y = A[i][q];
+          A[i][p] = cs * x - sn * y; A[i][q] = sn * x + cs * y;
+          x = V[i][p]; y = V[i][q];
+          V[i][p] = cs * x - sn * y; V[i][q] = sn * x + cs * y;
+        }
+      }
+    if (off <= 1e-60) break;
+  }
+  for (int j = 0; j < 3; ++j) S[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  // order descending (columns of A and V together)
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (S[b] > S[a]) {
+        double t = S[a]; S[a] = S[b]; S[b] = t;
+        for (int i = 0; i < 3; ++i) {
+          t = A[i][a]; A[i][a] = A[i][b]; A[i][b] = t;
+          t = V[i][a]; V[i][a] = V[i][b]; V[i][b] = t;
+        }
+      }
+  for (int j = 0; j < 2; ++j) {
+    double inv = S[j] > 0.0 ? 1.0 / S[j] : 0.0;
+    for (int i = 0; i < 3; ++i) U[i][j] = A[i][j] * inv;
+  }
+  if (S[2] > 1e-12 * S[0]) {
+    for (int i = 0; i < 3; ++i) U[i][2] = A[i][2] / S[2];
+  } else {             // rank 2: complete U with the cross product (any sign: Z fixes the handedness of R)
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+}
+__device__ double pa_det3(const double M[3][3]) {
+  return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+         M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+__global__ __launch_bounds__(64) void pa_mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      float* __restrict__ out, float* __restrict__ aligned, int n, int J) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n) return;
+  const float* P = pred + (size_t)s * J * 3;
+  const float* Gt = gt + (size_t)s * J * 3;
+  double m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+  for (int j = 0; j < J; ++j)
+    for (int c = 0; c < 3; ++c) { m1[c] += P[j * 3 + c]; m2[c] += Gt[j * 3 + c]; }
+  for (int c = 0; c < 3; ++c) { m1[c] /= J; m2[c] /= J; }
+  double K[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, var1 = 0.0;
+  for (int j = 0; j < J; ++j) {
+    double x[3], y[3];
+    for (int c = 0; c < 3; ++c) { x[c] = P[j * 3 + c] - m1[c]; y[c] = Gt[j * 3 + c] - m2[c]; var1 += x[c] * x[c]; }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) K[a][b] += x[a] * y[b];
+  }
+  double U[3][3], S[3], V[3][3], UVt[3][3];
+  pa_svd3(K, U, S, V);
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) UVt[a][b] = U[a][0] * V[b][0] + U[a][1] * V[b][1] + U[a][2] * V[b][2];
+  const double z = pa_det3(UVt) < 0.0 ? -1.0 : 1.0;
+  double R[3][3];                                    // R = V diag(1,1,z) U^T
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) R[a][b] = V[a][0] * U[b][0] + V[a][1] * U[b][1] + z * V[a][2] * U[b][2];
+  const double scale = (S[0] + S[1] + z * S[2]) / var1;
+  double t[3];
+  for (int a = 0; a < 3; ++a) t[a] = m2[a] - scale * (R[a][0] * m1[0] + R[a][1] * m1[1] + R[a][2] * m1[2]);
+  double err = 0.0;
+  for (int j = 0; j < J; ++j) {
+    double d2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      double h = scale * (R[a][0] * P[j * 3] + R[a][1] * P[j * 3 + 1] + R[a][2] * P[j * 3 + 2]) + t[a];
+      if (aligned) aligned[((size_t)s * J + j) * 3 + a] = (float)h;
+      double d = h - Gt[j * 3 + a];
+      d2 += d * d;
+    }
+    err += sqrt(d2);
+  }
+  out[s] = (float)(err / J);
+}
+// pred, gt: [n][J][3]; out[n] = Procrustes-aligned mean per-joint error (same unit as the inputs);
+// aligned (optional, [n][J][3]) receives the aligned prediction (compute_similarity_transform_batch's return value)
+extern "C" int dyb_pa_mpjpe(const float* pred, const float* gt, float* out, float* aligned, int n, int J, hipStream_t st) {
+  DYB_REQUIRE(pred && gt && out && n > 0 && J >= 3, DYB_ERR_ARG);
+  hipLaunchKernelGGL(pa_mpjpe_kernel, dim3(dyb_cdiv(n, 64)), dim3(64), 0, st, pred, gt, out, aligned, n, J);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

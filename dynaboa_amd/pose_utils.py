@@ -1,8 +1,24 @@
-"""Procrustes alignment for PA-MPJPE (reference utils/pose_utils.py:9-64), batched NumPy.
-Stays on the host like the reference's: 14x3 points per sample, one 3x3 SVD each."""
+"""Procrustes alignment for PA-MPJPE (reference utils/pose_utils.py:9-64).
+
+``pa_mpjpe_device`` is what the adaptation drivers use: the alignment and the error run in libdynaboa_hip.so
+(csrc/losses.hip, one 3x3 SVD per sample) so the metric path ships scalars.  ``compute_similarity_transform_batch``
+keeps the reference's NumPy surface (it is also the checker of the kernel's test)."""
 from __future__ import annotations
 
 import numpy as np
+import torch
+
+
+def pa_mpjpe_device(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """pred, gt: (n, J, 3) device tensors -> (n,) Procrustes-aligned mean per-joint error, same unit."""
+    from . import _lib
+    from ._abi import check
+    from .hmr import stream_of
+    pred, gt = pred.contiguous().float(), gt.contiguous().float()
+    n, J = pred.shape[0], pred.shape[1]
+    out = torch.empty(n, dtype=torch.float32, device=pred.device)
+    check(_lib.load().dyb_pa_mpjpe(pred.data_ptr(), gt.data_ptr(), out.data_ptr(), None, n, J, stream_of(pred)), "dyb_pa_mpjpe")
+    return out
 
 
 def compute_similarity_transform_batch(S1: np.ndarray, S2: np.ndarray) -> np.ndarray:

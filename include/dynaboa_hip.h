@@ -173,6 +173,11 @@ int dyb_head_grad_combine(const float* g, const float* drot_loss, const float* d
                           const float* dcam_loss, const float* dcam_ext, float* d_rot, float* d_state, int B,
                           dyb_stream_t stream);
 
+/* PA-MPJPE on the device: compute_similarity_transform(_batch) of reference utils/pose_utils.py:9-64 (centre, K = X1^T X2,
+ * 3x3 SVD, reflection fix, scale, translation) + the mean per-joint error of dynaboa_benchmark.py:236-240, one sample per
+ * thread, so that the metric path ships scalars instead of joint sets.  aligned (optional) receives the aligned prediction. */
+int dyb_pa_mpjpe(const float* pred, const float* gt, float* out, float* aligned, int n, int J, dyb_stream_t stream);
+
 /* ---- flat-arena updates: learn2learn MAML.adapt (call sites dynaboa_benchmark.py:136,140),
  * torch.optim.Adam (base_adaptor.py:126; dynaboa_benchmark.py:149-151), update_teacher
  * (base_adaptor.py:193-201), cal_feature_diff's cosine (:211-219). n = float count, multiple of 4. */

@@ -655,3 +655,29 @@ def case_bottleneck_fused(be, N, H, W, Cin, planes, stride, downsample, seed=31)
         e["dbd"] = rel_err(be.host(DG["bd"]), grads[12].numpy())
     assert max(e.values()) < 5e-4, e
     return e
+
+
+# ------------------------------------------------------------------- PA-MPJPE / Procrustes on the device
+def case_pa_mpjpe(be, golden, n_random=40, seed=41):
+    """dyb_pa_mpjpe against (a) the reference's compute_similarity_transform_batch outputs (golden g6: random pairs,
+    an exact similarity transform, a reflection) and (b) the NumPy restatement on random + degenerate inputs."""
+    from dynaboa_amd.pose_utils import compute_similarity_transform_batch
+    g = golden("g6_procrustes.npz")
+    rng = _rng(seed)
+    S1 = rng.normal(0, 0.3, (n_random, 14, 3)).astype(np.float32)
+    S2 = (S1 * 1.3 + rng.normal(0, 0.05, S1.shape)).astype(np.float32)
+    S2[0] = S1[0]                                   # identical sets: zero error
+    S1[1, :, 2] = 0.0; S2[1, :, 2] = 0.0            # coplanar points: rank-2 covariance
+    A = np.concatenate([g["S1"].astype(np.float32), S1]); Bm = np.concatenate([g["S2"].astype(np.float32), S2])
+    hat_ref = np.concatenate([g["S1_hat"], compute_similarity_transform_batch(S1, S2)])
+    err_ref = np.sqrt(((hat_ref - Bm) ** 2).sum(-1)).mean(-1)
+    n = A.shape[0]
+    out, hat = be.empty((n,)), be.empty((n, 14, 3))
+    check(be.lib.dyb_pa_mpjpe(be.ptr(be.dev(A)), be.ptr(be.dev(Bm)), be.ptr(out), be.ptr(hat), n, 14, be.stream), "pa_mpjpe")
+    o, h = be.host(out), be.host(hat)
+    keep = np.ones(n, bool)
+    keep[len(g["S1"]) + 1] = False                  # coplanar case: the aligned points may differ by the free reflection ...
+    assert np.abs(h[keep] - hat_ref[keep]).max() < 2e-5 * max(1.0, np.abs(hat_ref).max()), np.abs(h[keep] - hat_ref[keep]).max()
+    assert np.abs(o - err_ref).max() < 2e-5 + 1e-4 * err_ref.max(), (o - err_ref)     # ... the error does not
+    assert o[len(g["S1"])] < 1e-6
+    return dict(max_abs=float(np.abs(o - err_ref).max()))

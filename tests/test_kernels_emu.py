@@ -87,5 +87,9 @@ def test_frame_losses(be):
     K.case_frame_losses(be, golden, assets.load_gmm_prior())
 
 
+def test_pa_mpjpe(be):
+    K.case_pa_mpjpe(be, golden)
+
+
 def test_optim(be):
     K.case_optim(be, n=4096)
