@@ -199,7 +199,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    metrics = ad.flush_metrics()                              # one D2H + batched SVD, outside the clock
+    metrics = ad.flush_metrics()                              # one Procrustes launch + one D2H of scalars, outside the clock
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
