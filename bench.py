@@ -147,7 +147,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        # DYB_BENCH_SMOKE_ONE_GPU=1: functional check of this N>1 control flow on a ONE-GPU box (all ranks on cuda:0 over
+        # gloo, since RCCL refuses two ranks on one device) - never a measurement
+        one_gpu = os.environ.get("DYB_BENCH_SMOKE_ONE_GPU") == "1"
+        if one_gpu:
+            local = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
