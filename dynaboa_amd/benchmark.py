@@ -342,14 +342,19 @@ class Adaptor(BaseAdaptor):
             pred_rotmat, pred_shape, pred_cam = out[0], out[1], out[2]
             smpl_out = self.decode_smpl_params(pred_rotmat, pred_shape)
             pred_vertices = smpl_out['vts']
-            gt_vertices = self.smpl_male(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
-            gt_female = self.smpl_female(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
-            gt_vertices = torch.where((gender == 1).view(-1, 1, 1), gt_female, gt_vertices)
-            gt14 = self._regress14(gt_vertices)
+            # the ground-truth side depends on the batch only: the 2-4 inference() calls of a frame share it
+            key = (step, gt_pose.data_ptr(), gt_betas.data_ptr(), gender.data_ptr())
+            cached = getattr(self, "_gt_cache", None)
+            if cached is None or cached[0] != key:
+                gt_vertices = self.smpl_male(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
+                gt_female = self.smpl_female(global_orient=gt_pose[:, :3], body_pose=gt_pose[:, 3:], betas=gt_betas).vertices
+                gt_vertices = torch.where((gender == 1).view(-1, 1, 1), gt_female, gt_vertices)
+                gt_neutral = self.smpl_neutral(betas=gt_betas, body_pose=gt_pose[:, 3:], global_orient=gt_pose[:, :3],
+                                               pose2rot=True).vertices
+                cached = self._gt_cache = (key, self._regress14(gt_vertices), gt_neutral)
+            gt14, gt_neutral = cached[1], cached[2]
             pred14 = self._regress14(pred_vertices)
             mpjpe_t = (pred14 - gt14).norm(dim=-1).mean(dim=-1)
-            gt_neutral = self.smpl_neutral(betas=gt_betas, body_pose=gt_pose[:, 3:], global_orient=gt_pose[:, :3],
-                                           pose2rot=True).vertices
             pve_t = (gt_neutral - pred_vertices).norm(dim=-1).mean()
         if self.options.dump_predictions:
             import joblib
