@@ -311,3 +311,36 @@ def test_shared_forwards_are_bit_identical():
         assert outs[0][3] == outs[1][3]
         assert len(outs[0][2]) == len(outs[1][2]) and len(outs[0][2]) >= 3 * (1 + opts["inner_step"])
         assert outs[0][2] == outs[1][2]                      # every inference() record, per-inner-step ones included
+
+
+def test_second_order_full_loss_set_vs_oracle(gmm_t, smpl_tabs):
+    """Second order with the reference's full default term set (teacher + labelled exemplars; the motion term needs
+    history and is inactive on frame 0), i.e. the closure path with retrieved exemplars and external gradients on the
+    level node: outer gradient of one frame against the CPU oracle in create_graph=True mode, and against the
+    oracle's first-order gradient to show which of the two it follows."""
+    from dynaboa_amd import assets
+    from oracle import ref_cpu as O
+    opts = dict(inner_step=1, interval=2, optim_steps=2, dynamic_boa=0)
+    frame = assets.make_frame(0, 1, seed=22)
+    grads = {}
+    sd = None
+    for so in (1, 0):
+        if so:
+            ad, bundle = make_adaptor(dict(opts, second_order=1), False)
+            ad.reset_records(1)
+            ad.global_step = 0
+            ad.model.eval()
+            ad.adaptation({k: v.to(ad.device) for k, v in frame.items()})
+            hmr_m = ad.model.module
+            ours = hmr_m._layout1.unpack(ad.optimizer.state[hmr_m.theta]["exp_avg"] / (1 - ad.options.beta1))
+            sd = {k.replace("module.", ""): v for k, v in bundle.checkpoint["model"].items()}
+        ref = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, opts, first_order=not so)
+        ref.exemplar_fn = lambda step: assets.make_exemplars(step, ref.o["sample_num"])
+        torch.set_num_threads(32)
+        grads[so] = ref.adapt_frame(frame)["outer_grad"]
+    names = ["conv1.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight", "layer4.2.conv3.weight", "fc1.weight", "decpose.weight"]
+    e_so = np.array([rel_err(ours[k].cpu().numpy(), grads[1][k].numpy()) for k in names])
+    gap = np.array([rel_err(grads[0][k].numpy(), grads[1][k].numpy()) for k in names])
+    print("SO full-loss: err vs oracle-SO", e_so, " FO-vs-SO gap", gap)
+    assert (e_so < 3e-2).all(), e_so
+    assert (e_so < 0.25 * gap + 5e-3).all(), (e_so, gap)
