@@ -4,8 +4,10 @@ per-frame bilevel schedule (:126-193) and metric path (:204-262) on the HIP kern
 
 Differences that do not change results:
   * per-inference ``joblib.dump`` of 6890x3 vertices (:250-254) is off unless --dump_predictions 1;
-  * with --deferred_metrics 1 the 14-joint sets are kept on the device and PA-MPJPE's per-sample
-    SVD runs once per stream instead of forcing a host sync four times per frame.
+  * with --deferred_metrics 1 the 14-joint sets are kept on the device and the Procrustes kernel runs once over
+    the whole stream instead of forcing a host sync four times per frame;
+  * forwards the schedule repeats with identical weights and input are evaluated once (--share_forwards), and each
+    level's model -> SMPL -> loss head is one autograd node (--fused_level).
 """
 from __future__ import annotations
 

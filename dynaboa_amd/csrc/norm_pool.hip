@@ -2,16 +2,19 @@
 // NCHW->NHWC4 image repack, all NHWC fp32, 16 B per lane.
 //
 // Replaces nn.GroupNorm / nn.ReLU / nn.MaxPool2d / nn.AvgPool2d and the `out += residual` of
-// reference model/hmr.py:14-18,40-60,138-156.  HBM-bound elementwise / reduction work: every
-// kernel streams each tensor once, coalesced along channels.
+// reference model/hmr.py:14-18,40-60,138-156.  Elementwise / reduction work, every tensor streamed
+// once, coalesced along channels; at batch 1 each kernel is a few dependent memory round trips.
 //
 // GroupNorm is split so that no kernel needs a grid-wide barrier:
-//   gn_stats : per (image, chunk-of-rows, group) partial sum / sum-of-squares (one wave per group);
-//              optionally folds the split-K slabs left by the convolution and writes y.
-//   gn_apply : every workgroup re-reduces the (<= few hundred) partials in double, then
-//              out = relu?((y-mean)*rstd*gamma + beta (+ residual)); saves mean/rstd.
-//   backward : gn_bwd_reduce (per-channel sums of dy and dy*xhat + per-group gamma-weighted sums)
-//              -> gn_bwd_apply (coefficients, dx, the residual-edge gradient, dgamma/dbeta).
+//   gn_stats      : per (image, chunk-of-rows, group) partial sum / sum-of-squares (one wave per group);
+//                   folds the split-K slabs left by the convolution and writes y.
+//   gn_apply      : every workgroup re-reduces the (<= 256) partials in double, then
+//                   out = relu?((y-mean)*rstd*gamma + beta (+ residual)); saves mean/rstd.  In the engine it runs
+//                   only for block outputs; inside a bottleneck the consumer conv normalises on load (igemm_conv.hip).
+//   gn_bwd_reduce : folds the incoming gradient (split-K slabs + residual edge), ReLU mask, dm, per-channel and
+//                   per-group partial sums.  In the engine the other half of the backward - dy from (dm, y) and the
+//                   coefficients - happens in the data- / weight-gradient convs' loaders; gn_bwd_apply is the
+//                   stand-alone form behind dyb_groupnorm_bwd.
 #include <hip/hip_ext.h>
 
 #include "dyb_common.h"
