@@ -31,6 +31,7 @@ static inline int dyb_ilog2(int v) {
   while ((1 << l) < v) ++l;
   return l;
 }
+__device__ __forceinline__ int dyb_ilog2_dev(int v) { return 31 - __clz(v); }
 static inline bool dyb_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int dyb_cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -67,8 +68,5 @@ struct GnBwdSrc {
 int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w, float* dx, const float* addend, void* ws,
                           size_t ws_bytes, int* nslabs, hipStream_t st);
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);
-int dyb_conv_fwd_gnin_raw(const ConvDesc& d, const float* y_prev, const float* part_prev, const float* gamma_prev,
-                          const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y, void* ws,
-                          size_t ws_bytes, int* nslabs, hipStream_t st);
 int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, const float* tail,
                          int tail_ld, int tail_cols, int tail_dst_col, hipStream_t st);

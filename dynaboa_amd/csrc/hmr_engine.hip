@@ -23,9 +23,10 @@
 extern "C" {
 size_t dyb_conv2d_workspace_bytes(int, int, int, int, int, int, int, int, int);
 size_t dyb_groupnorm_workspace_bytes(int, int, int);
-int dyb_groupnorm_stats(const float*, int, float*, float*, int, int, int, hipStream_t);
-int dyb_groupnorm_apply(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                        const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+int dyb_conv2d_nhwc_fwd_gnstats(const float*, const float*, int, const float*, const float*, int, float*, const float*, float*,
+                                float*, int*, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+int dyb_groupnorm_apply_n(const float*, const float*, int, const float*, const float*, const float*, const float*, int,
+                          const float*, const float*, float*, float*, float*, int, int, int, int, hipStream_t);
 int dyb_conv2d_nhwc_wgrad_gn_gnin(const float*, const float*, const float*, const float*, int, const float*, const float*,
                                   const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int,
                                   int, int, int, int, void*, size_t, hipStream_t);
@@ -343,18 +344,16 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   return c;
 }
 
-// conv (+ the producer's GroupNorm/ReLU applied in its loader when `prev` is given) -> statistics of
-// its raw output into `part_out`
+// one forward layer: conv (+ the producer's GroupNorm/ReLU applied in its loader when `prev` is given) and the
+// GroupNorm statistics of its raw output into `part_out` (*nch_out partial records)
 static int conv_stats(const HmrPlan& P, const ConvL& c, const float* params, float* acts, const float* x, const ConvL* prev,
-                      const float* part_prev, float* part_out, const WsCarve& w, hipStream_t st) {
-  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
-  int nslabs = 1;
+                      const float* part_prev, int nch_prev, float* part_out, int* nch_out, const WsCarve& w, hipStream_t st) {
   if (prev)
-    RUN(dyb_conv_fwd_gnin_raw(d, acts + prev->y, part_prev, params + prev->gam, params + prev->bet, 1, acts + prev->stats,
-                              params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
-  else
-    RUN(dyb_conv_fwd_raw(d, x, params + c.w, acts + c.y, w.conv, P.ws_conv, &nslabs, st));
-  return dyb_groupnorm_stats(reinterpret_cast<const float*>(w.conv), nslabs, acts + c.y, part_out, P.B, c.Ho * c.Wo, c.K, st);
+    return dyb_conv2d_nhwc_fwd_gnstats(acts + prev->y, part_prev, nch_prev, params + prev->gam, params + prev->bet, 1,
+                                       acts + prev->stats, params + c.w, acts + c.y, part_out, nch_out, P.B, c.H, c.W, c.C, c.K,
+                                       c.R, c.S, c.stride, c.pad, w.conv, P.ws_conv, st);
+  return dyb_conv2d_nhwc_fwd_gnstats(x, nullptr, 0, nullptr, nullptr, 0, nullptr, params + c.w, acts + c.y, part_out, nch_out,
+                                     P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv, P.ws_conv, st);
 }
 
 extern "C" int dyb_hmr_set_graph_mode(void* plan, int on) {
@@ -448,27 +447,30 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
                         const WsCarve& w, hipStream_t st) {
   const int B = P.B;
   const ConvL& stem = P.convs[0];
-  RUN(conv_stats(P, stem, params, acts, acts + P.a_x4, nullptr, nullptr, w.gn[0], w, st));
-  RUN(dyb_groupnorm_apply(acts + stem.y, w.gn[0], params + stem.gam, params + stem.bet, nullptr, nullptr, nullptr, nullptr,
-                          nullptr, acts + stem.out, acts + stem.stats, B, stem.Ho * stem.Wo, stem.K, 1, st));
+  int nA = 0, nB = 0, nD = 0;                 // partial counts behind w.gn[0], [1], [2]
+  RUN(conv_stats(P, stem, params, acts, acts + P.a_x4, nullptr, nullptr, 0, w.gn[0], &nA, w, st));
+  RUN(dyb_groupnorm_apply_n(acts + stem.y, w.gn[0], nA, params + stem.gam, params + stem.bet, nullptr, nullptr, 0, nullptr,
+                            nullptr, nullptr, acts + stem.out, acts + stem.stats, B, stem.Ho * stem.Wo, stem.K, 1, st));
   RUN(dyb_maxpool3x3s2_fwd(acts + stem.out, acts + P.a_pool, reinterpret_cast<uint32_t*>(acts + P.a_poolidx), B, stem.Ho,
                            stem.Wo, stem.K, st));
   const float* x = acts + P.a_pool;
   for (const BlockL& b : P.blocks) {
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
-    // 3 launches per conv become 2: bn1 / bn2 (+ReLU) are applied by conv2 / conv3 while loading
-    RUN(conv_stats(P, c1, params, acts, x, nullptr, nullptr, w.gn[0], w, st));
-    RUN(conv_stats(P, c2, params, acts, nullptr, &c1, w.gn[0], w.gn[1], w, st));
-    if (b.cd >= 0) RUN(conv_stats(P, P.convs[b.cd], params, acts, x, nullptr, nullptr, w.gn[2], w, st));
-    RUN(conv_stats(P, c3, params, acts, nullptr, &c2, w.gn[1], w.gn[0], w, st));
+    // 3 launches per conv become 2 (or 1: the small 1x1 layers write their statistics themselves): bn1 / bn2 (+ReLU)
+    // are applied by conv2 / conv3 while loading
+    RUN(conv_stats(P, c1, params, acts, x, nullptr, nullptr, 0, w.gn[0], &nA, w, st));
+    RUN(conv_stats(P, c2, params, acts, nullptr, &c1, w.gn[0], nA, w.gn[1], &nB, w, st));
+    if (b.cd >= 0) RUN(conv_stats(P, P.convs[b.cd], params, acts, x, nullptr, nullptr, 0, w.gn[2], &nD, w, st));
+    RUN(conv_stats(P, c3, params, acts, nullptr, &c2, w.gn[1], nB, w.gn[0], &nA, w, st));
     // out = relu(bn3(y3) + shortcut), the shortcut being x or downsample.1(yd) normalised on the fly
     if (b.cd >= 0) {
       const ConvL& cd = P.convs[b.cd];
-      RUN(dyb_groupnorm_apply(acts + c3.y, w.gn[0], params + c3.gam, params + c3.bet, acts + cd.y, w.gn[2], params + cd.gam,
-                              params + cd.bet, acts + cd.stats, acts + c3.out, acts + c3.stats, B, c3.Ho * c3.Wo, c3.K, 1, st));
+      RUN(dyb_groupnorm_apply_n(acts + c3.y, w.gn[0], nA, params + c3.gam, params + c3.bet, acts + cd.y, w.gn[2], nD,
+                                params + cd.gam, params + cd.bet, acts + cd.stats, acts + c3.out, acts + c3.stats, B,
+                                c3.Ho * c3.Wo, c3.K, 1, st));
     } else {
-      RUN(dyb_groupnorm_apply(acts + c3.y, w.gn[0], params + c3.gam, params + c3.bet, x, nullptr, nullptr, nullptr, nullptr,
-                              acts + c3.out, acts + c3.stats, B, c3.Ho * c3.Wo, c3.K, 1, st));
+      RUN(dyb_groupnorm_apply_n(acts + c3.y, w.gn[0], nA, params + c3.gam, params + c3.bet, x, nullptr, 0, nullptr, nullptr,
+                                nullptr, acts + c3.out, acts + c3.stats, B, c3.Ho * c3.Wo, c3.K, 1, st));
     }
     x = acts + c3.out;
   }

@@ -270,6 +270,55 @@ __device__ __forceinline__ float4 gnf_apply(float4 y, float4 ga, float4 be, floa
 }
 __device__ __forceinline__ double igemm_shfl_xor_f64(double v, int m) { return __shfl_xor(v, m); }
 
+// (mean, rstd) of the producer per (image, group) into s_nrm, from its per-chunk partials (folded in double, eight
+// loads in flight per lane: this sits on the consumer's critical path) or from the saved statistics; `first`
+// workgroup also saves them for backward.  Ends with a barrier.
+__device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, int tid, bool first, double* s_rawd,
+                                             float* s_nrm) {
+  const int nvals = N * DYB_GN_GROUPS * 2;
+  if (nf.partials) {
+    int L = 32;
+    while (L > 1 && L * nvals > 256) L >>= 1;
+    const int per_pass = 256 / L;
+    for (int base = 0; base < nvals; base += per_pass) {
+      const int v = base + tid / L, sub = tid % L;
+      double s = 0.0;
+      if (v < nvals) {
+        const float* pp = nf.partials + (size_t)(v >> 3) * nf.nchunks * 8 + (v & 7);
+        for (int k0 = sub; k0 < nf.nchunks; k0 += 8 * L) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j * L;
+            t[j] = k < nf.nchunks ? pp[(size_t)k * 8] : 0.f;
+          }
+          s += (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) +
+               (((double)t[4] + (double)t[5]) + ((double)t[6] + (double)t[7]));
+        }
+      }
+      for (int m = L >> 1; m >= 1; m >>= 1) s += igemm_shfl_xor_f64(s, m);
+      if (v < nvals && sub == 0) s_rawd[v] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * DYB_GN_GROUPS; i += 256) {
+      const double cnt = (double)nf.HW * (double)(C / DYB_GN_GROUPS);
+      const double mean = s_rawd[i * 2] / cnt;
+      double var = s_rawd[i * 2 + 1] / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)nf.eps));
+      s_nrm[i * 2] = m;
+      s_nrm[i * 2 + 1] = r;
+      if (nf.stats_out && first) {
+        nf.stats_out[i * 2] = m;
+        nf.stats_out[i * 2 + 1] = r;
+      }
+    }
+  } else {
+    for (int i = tid; i < nvals; i += 256) s_nrm[i] = nf.stats_in[i];
+  }
+  __syncthreads();
+}
+
 template <int MODE, bool GB, bool FA>
 __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f, GnFwdFuse nf) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
@@ -464,50 +513,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     __syncthreads();
   }
 
-  if constexpr (FA) {
-    const int nvals = g.N * DYB_GN_GROUPS * 2;
-    if (nf.partials) {
-      int L = 32;
-      while (L > 1 && L * nvals > 256) L >>= 1;
-      const int per_pass = 256 / L;
-      for (int base = 0; base < nvals; base += per_pass) {
-        const int v = base + tid / L, sub = tid % L;
-        double s = 0.0;
-        if (v < nvals) {
-          const float* pp = nf.partials + (size_t)(v >> 3) * nf.nchunks * 8 + (v & 7);
-          for (int k0 = sub; k0 < nf.nchunks; k0 += 8 * L) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int k = k0 + j * L;
-              t[j] = k < nf.nchunks ? pp[(size_t)k * 8] : 0.f;
-            }
-            s += (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) +
-                 (((double)t[4] + (double)t[5]) + ((double)t[6] + (double)t[7]));
-          }
-        }
-        for (int m = L >> 1; m >= 1; m >>= 1) s += igemm_shfl_xor_f64(s, m);
-        if (v < nvals && sub == 0) s_rawd[v] = s;
-      }
-      __syncthreads();
-      for (int i = tid; i < g.N * DYB_GN_GROUPS; i += 256) {
-        const double cnt = (double)nf.HW * (double)(g.C / DYB_GN_GROUPS);
-        const double mean = s_rawd[i * 2] / cnt;
-        double var = s_rawd[i * 2 + 1] / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)nf.eps));
-        s_nrm[i * 2] = m;
-        s_nrm[i * 2 + 1] = r;
-        if (nf.stats_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-          nf.stats_out[i * 2] = m;
-          nf.stats_out[i * 2 + 1] = r;
-        }
-      }
-    } else {
-      for (int i = tid; i < nvals; i += 256) s_nrm[i] = nf.stats_in[i];
-    }
-    __syncthreads();
-  }
+  if constexpr (FA) gnf_prologue(nf, g.N, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, s_rawd, s_nrm);
 
   if (kt_begin < kt_end) {
     // register prefetch one K-step ahead, two LDS buffers, one barrier per step
@@ -585,6 +591,155 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       if (part == 0 && c < C) {
         f.dbeta[c] = (s_gb[0][cl][0] + s_gb[1][cl][0]) + (s_gb[2][cl][0] + s_gb[3][cl][0]);
         f.dgamma[c] = (s_gb[0][cl][1] + s_gb[1][cl][1]) + (s_gb[2][cl][1] + s_gb[3][cl][1]);
+      }
+    }
+  }
+}
+
+// ---- 1x1 forward conv with the GroupNorm statistics in its epilogue ("K4") -------------------------
+// The small 1x1 layers (layers 2-4: M = Ho*Wo <= 784 pixels at batch 1, Cin <= 1024) are where a forward
+// conv spends its time in launch + the statistics kernel that follows it, not in arithmetic.  Here the
+// four waves of a workgroup split the K range of ONE 32x32 output tile (K-step 128 = 32 per wave), sum
+// their accumulators through LDS, and - because no split-K slabs are left to fold - finish the layer in
+// the same launch: y tile out, plus this tile's (sum, sum of squares) as one GroupNorm partial (a tile's
+// 32 columns lie inside one of the 4 channel groups when Cout/4 >= 32).  The separate gn_stats launch
+// disappears; consumers fold gridDim.x*gridDim.y partials exactly as they fold gn_stats'.
+#define K4_BK 128
+#define K4_LD 36
+struct K4Args {
+  const float* x;        // [H][W][C] input (batch 1), or the producer's raw output when FA
+  const float* w;        // [C][K]
+  float* y;              // [Ho*Wo][K]
+  float* partials;       // [mtiles*ntiles][G][2]
+  int H, W, C, K, stride, Ho, Wo, M;
+};
+template <bool FA>
+__global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse nf) {
+  __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
+  __shared__ float s_nrm[FA ? DYB_GN_GROUPS * 2 : 4];
+  __shared__ double s_rawd[FA ? DYB_GN_GROUPS * 2 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int ktiles = (g.C + K4_BK - 1) / K4_BK;
+  // A pieces: tile row a_row, 4 consecutive k at 32h + a_kq (h = 0..3 -> consumed by wave h); B pieces: k row 32h + b_k, 4 columns
+  const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
+  const int b_k = tid >> 3, b_q = (tid & 7) * 4;
+  const int m = m0 + a_row;
+  const bool row_ok = m < g.M;
+  const int ho = row_ok ? m / g.Wo : 0, wo = row_ok ? m - (m / g.Wo) * g.Wo : 0;
+  const float* arow = g.x + ((size_t)(ho * g.stride) * g.W + (size_t)wo * g.stride) * g.C;
+  const int logCg = dyb_ilog2_dev(g.C) - 2;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_a = [&](int kt, int h, Frag& o) {
+    const int k = kt * K4_BK + 32 * h + a_kq;
+    o.ok = row_ok && k < g.C;
+    o.d = zero4;
+    if (o.ok) {
+      o.d = *reinterpret_cast<const float4*>(arow + k);
+      if constexpr (FA) {
+        o.v = *reinterpret_cast<const float4*>(nf.gamma + k);
+        o.ga = *reinterpret_cast<const float4*>(nf.beta + k);
+      }
+    }
+  };
+  auto load_b = [&](int kt, int h, Frag& o) {
+    const int k = kt * K4_BK + 32 * h + b_k, col = n0 + b_q;
+    o.d = (k < g.C && col < g.K) ? *reinterpret_cast<const float4*>(g.w + (size_t)k * g.K + col) : zero4;
+  };
+  auto store = [&](int buf, int kt, int h, const Frag& a, const Frag& b) {
+    float4 v = a.d;
+    if constexpr (FA) {
+      const int k = kt * K4_BK + 32 * h + a_kq;
+      const float* st = &s_nrm[(k >> logCg) * 2];
+      v = a.ok ? gnf_apply(a.d, a.v, a.ga, st[0], st[1], nf.relu) : zero4;
+    }
+    As[buf][32 * h + a_kq + 0][a_row] = v.x;
+    As[buf][32 * h + a_kq + 1][a_row] = v.y;
+    As[buf][32 * h + a_kq + 2][a_row] = v.z;
+    As[buf][32 * h + a_kq + 3][a_row] = v.w;
+    *reinterpret_cast<float4*>(&Bs[buf][32 * h + b_k][b_q]) = b.d;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  Frag ra[4], rb[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { ra[h].d = ra[h].v = ra[h].ga = zero4; ra[h].ok = false; rb[h] = ra[h]; }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { load_a(0, h, ra[h]); load_b(0, h, rb[h]); }
+  if constexpr (FA) gnf_prologue(nf, 1, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0, s_rawd, s_nrm);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) store(0, 0, h, ra[h], rb[h]);
+  __syncthreads();
+  const int khalf = lane >> 5, l31 = lane & 31;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    if (more) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) { load_a(kt + 1, h, ra[h]); load_b(kt + 1, h, rb[h]); }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 32; k2 += 2) {
+      float a = As[buf][32 * wave + k2 + khalf][l31];
+      float b = Bs[buf][32 * wave + k2 + khalf][l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) store(buf ^ 1, kt + 1, h, ra[h], rb[h]);
+    }
+    __syncthreads();
+  }
+  // ---- sum the four waves' accumulators: red[wave][r][lane] (16 KB, in the A stage) -> fin[32][33] (in the B stage)
+  float* red = &As[0][0][0];
+  float* fin = &Bs[0][0][0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = tid + 256 * j, r = s >> 6, ln = s & 63;
+    const float v = (red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln]) + (red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln]);
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = ln & 31;        // C/D fragment of the 32x32 MFMA
+    fin[row * 33 + col] = v;
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 3, cq = (tid & 7) * 4;
+    if (m0 + row < g.M && n0 + cq < g.K) {
+      float4 v = make_float4(fin[row * 33 + cq], fin[row * 33 + cq + 1], fin[row * 33 + cq + 2], fin[row * 33 + cq + 3]);
+      *reinterpret_cast<float4*>(g.y + (size_t)(m0 + row) * g.K + n0 + cq) = v;
+    }
+  }
+  // ---- GroupNorm partial of this tile: 8 row-parts x 32 columns, then the first wave folds
+  {
+    const int col = tid & 31, part = tid >> 5;
+    float s1 = 0.f, s2 = 0.f;
+    if (n0 + col < g.K) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = part * 4 + i;
+        if (m0 + row < g.M) { const float v = fin[row * 33 + col]; s1 += v; s2 += v * v; }
+      }
+    }
+    float* st = red;                         // [8][32][2], the accumulator stage is free again
+    __syncthreads();
+    st[(part * 32 + col) * 2] = s1;
+    st[(part * 32 + col) * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < 64) {
+      const int c = tid & 31, which = tid >> 5;
+      float t = 0.f;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) t += st[(p8 * 32 + c) * 2 + which];
+      t += __shfl_xor(t, 16); t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+      if (c < DYB_GN_GROUPS) {
+        const int grp = n0 / (g.K / DYB_GN_GROUPS);
+        g.partials[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * DYB_GN_GROUPS + c) * 2 + which] = (c == grp) ? t : 0.f;
       }
     }
   }
@@ -885,6 +1040,33 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
   return DYB_OK;
 }
 
+
+// ---- K4 host side ------------------------------------------------------------------------------------
+bool dyb_conv_k4_ok(const ConvDesc& d) {
+  const int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
+  static const int enabled = getenv("DYB_K4") ? atoi(getenv("DYB_K4")) : 1;
+  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 64 && d.C <= 1024 &&
+         d.K % 128 == 0 && Ho * Wo <= 784;
+}
+// conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count
+int dyb_conv_fwd_k4(const ConvDesc& d, const float* x, const float* w, float* y, float* partials, const GnFwdFuse* nf,
+                    int* nchunks, hipStream_t st) {
+  DYB_REQUIRE(x && w && y && partials && nchunks && dyb_conv_k4_ok(d), DYB_ERR_UNSUPPORTED);
+  K4Args g{x, w, y, partials, d.H, d.W, d.C, d.K, d.stride, conv_out_dim(d.H, 1, d.stride, 0), conv_out_dim(d.W, 1, d.stride, 0), 0};
+  g.M = g.Ho * g.Wo;
+  dim3 grid(dyb_cdiv(g.M, 32), d.K / 32);
+  GnFwdFuse f{};
+  if (nf) {
+    f = *nf;
+    hipLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, g, f);
+  } else {
+    hipLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, g, f);
+  }
+  DYB_CHECK_LAUNCH();
+  *nchunks = (int)(grid.x * grid.y);
+  return DYB_OK;
+}
+
 // ---- producer GroupNorm(+ReLU) applied in the loader (GnFwdFuse) ---------------------------------
 static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, const float* stats_in, const float* gamma,
                        const float* beta, float* stats_out, int relu) {
@@ -894,13 +1076,39 @@ static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, 
   nf.eps = DYB_GN_EPS;
   nf.relu = relu;
 }
-int dyb_conv_fwd_gnin_raw(const ConvDesc& d, const float* y_prev, const float* part_prev, const float* gamma_prev,
-                          const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y, void* ws,
-                          size_t ws_bytes, int* nslabs, hipStream_t st) {
+int dyb_conv_fwd_gnin_raw(const ConvDesc& d, const float* y_prev, const float* part_prev, int nch_prev,
+                          const float* gamma_prev, const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w,
+                          float* y, void* ws, size_t ws_bytes, int* nslabs, hipStream_t st) {
   DYB_REQUIRE(y_prev && part_prev && gamma_prev && beta_prev && d.C % 16 == 0, DYB_ERR_ARG);
   GnFwdFuse nf{};
   make_nfuse(nf, d, part_prev, nullptr, gamma_prev, beta_prev, stats_prev_out, relu_prev);
+  if (nch_prev > 0) nf.nchunks = nch_prev;
   return run_igemm(MODE_FWD, d, y_prev, w, y, nullptr, ws, ws_bytes, nslabs, st, nullptr, &nf);
+}
+// Forward conv of one layer INCLUDING the GroupNorm statistics of its output: y and per-chunk (sum, sum of squares)
+// partials (*nchunks records of [G][2]).  x is a plain activation, or - part_prev != NULL - the producer's raw conv
+// output whose GroupNorm(+ReLU) is applied in the loader from its nch_prev partials.  Small 1x1 layers at batch 1 take
+// the single-launch K4 kernel; everything else is the tiled conv + dyb_groupnorm_stats (which folds the split-K slabs).
+extern "C" int dyb_groupnorm_stats(const float*, int, float*, float*, int, int, int, hipStream_t);
+extern "C" int dyb_conv2d_nhwc_fwd_gnstats(const float* x, const float* part_prev, int nch_prev, const float* gamma_prev,
+                                           const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w,
+                                           float* y, float* partials, int* nchunks, int N, int H, int W, int C, int K, int R,
+                                           int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(x && w && y && partials && nchunks, DYB_ERR_ARG);
+  DYB_REQUIRE(!part_prev || (gamma_prev && beta_prev && nch_prev > 0 && C % 16 == 0), DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  const int Ho = conv_out_dim(H, R, stride, pad), Wo = conv_out_dim(W, S, stride, pad);
+  GnFwdFuse nf{};
+  if (part_prev) {
+    make_nfuse(nf, d, part_prev, nullptr, gamma_prev, beta_prev, stats_prev_out, relu_prev);
+    nf.nchunks = nch_prev;
+  }
+  if (dyb_conv_k4_ok(d)) return dyb_conv_fwd_k4(d, x, w, y, partials, part_prev ? &nf : nullptr, nchunks, st);
+  int nslabs = 1;
+  int rc = run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, &nslabs, st, nullptr, part_prev ? &nf : nullptr);
+  if (rc != DYB_OK) return rc;
+  *nchunks = dyb_gn_fwd_chunks(N, Ho * Wo);
+  return dyb_groupnorm_stats(reinterpret_cast<const float*>(ws), nslabs, y, partials, N, Ho * Wo, K, st);
 }
 // y = conv(relu?(gn(y_prev)), w): y_prev is the producer's raw conv output [N][H][W][C], part_prev its
 // dyb_groupnorm_stats partials; the producer's (mean, rstd) are saved to stats_prev_out.
@@ -909,7 +1117,7 @@ extern "C" int dyb_conv2d_nhwc_fwd_gnin(const float* y_prev, const float* part_p
                                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
                                         size_t ws_bytes, hipStream_t st) {
   ConvDesc d{N, H, W, C, K, R, S, stride, pad};
-  return dyb_conv_fwd_gnin_raw(d, y_prev, part_prev, gamma_prev, beta_prev, relu_prev, stats_prev_out, w, y, ws, ws_bytes,
+  return dyb_conv_fwd_gnin_raw(d, y_prev, part_prev, -1, gamma_prev, beta_prev, relu_prev, stats_prev_out, w, y, ws, ws_bytes,
                                nullptr, st);
 }
 // weight gradient of such a conv: A operand relu?(gn(y_prev)) formed on the fly from the saved

@@ -231,24 +231,34 @@ extern "C" int dyb_groupnorm_stats(const float* slabs, int nslabs, float* y, flo
 // apply half: out = relu?(gn(y) + residual), the residual being absent (NULL), plain, or - when
 // res_partials != NULL - the GroupNorm (no ReLU) of the raw conv output `residual` with its own
 // partials / gamma / beta (its (mean, rstd) are saved to res_stats).
-extern "C" int dyb_groupnorm_apply(const float* y, const float* partials, const float* gamma, const float* beta,
-                                   const float* residual, const float* res_partials, const float* res_gamma,
-                                   const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C,
-                                   int relu, hipStream_t st) {
-  DYB_REQUIRE(y && partials && gamma && beta && out && stats, DYB_ERR_ARG);
-  DYB_REQUIRE(!res_partials || (residual && res_gamma && res_beta && res_stats), DYB_ERR_ARG);
+// explicit partial counts: nch (res_nch) = number of [G][2] partial records per image behind `partials`
+// (`res_partials`) - dyb_gn_fwd_chunks(N, HW) when they come from dyb_groupnorm_stats, the tile count when a conv
+// wrote them in its epilogue (igemm_conv.hip, K4)
+extern "C" int dyb_groupnorm_apply_n(const float* y, const float* partials, int nch, const float* gamma, const float* beta,
+                                     const float* residual, const float* res_partials, int res_nch, const float* res_gamma,
+                                     const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C,
+                                     int relu, hipStream_t st) {
+  DYB_REQUIRE(y && partials && gamma && beta && out && stats && nch > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(!res_partials || (residual && res_gamma && res_beta && res_stats && res_nch > 0), DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
-  int nch = gn_chunks(HW, N);
   size_t total4 = (size_t)HW * (C / 4);
   int bpi = (int)((total4 + 1023) / 1024);
   int cap = 1024 / N > 1 ? 1024 / N : 1;
   if (bpi > cap) bpi = cap;
   if (bpi < 1) bpi = 1;
-  GnResidual rs{residual, res_partials, res_gamma, res_beta, res_stats, nch};
+  GnResidual rs{residual, res_partials, res_gamma, res_beta, res_stats, res_nch};
   hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, st, y, partials, nch, gamma, beta, rs, out, stats, HW, C,
                      relu, DYB_GN_EPS);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+extern "C" int dyb_groupnorm_apply(const float* y, const float* partials, const float* gamma, const float* beta,
+                                   const float* residual, const float* res_partials, const float* res_gamma,
+                                   const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C,
+                                   int relu, hipStream_t st) {
+  const int nch = gn_chunks(HW, N);
+  return dyb_groupnorm_apply_n(y, partials, nch, gamma, beta, residual, res_partials, nch, res_gamma, res_beta, res_stats, out,
+                               stats, N, HW, C, relu, st);
 }
 
 // y: conv output [N][HW][C] (written here when nslabs > 1 from `slabs`), out: normalised result,

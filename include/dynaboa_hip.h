@@ -107,6 +107,20 @@ int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, 
 int dyb_conv_timing_begin(int max_launches);
 int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, double* bytes);
 
+/* One forward layer = conv + the GroupNorm statistics of its output (what the engine issues per layer): y and *nchunks
+ * partial records [G][2] in `partials` (>= dyb_groupnorm_workspace_bytes(N, Ho*Wo, K) and >= 4*(Ho*Wo/32+1)*(K/32)*8
+ * bytes).  part_prev != NULL: x is the producer's raw output, normalised in the loader from its nch_prev partials.
+ * Small 1x1 layers at batch 1 run as ONE launch (statistics in the conv epilogue); dyb_groupnorm_apply_n is
+ * dyb_groupnorm_apply with the partial counts given explicitly. */
+int dyb_conv2d_nhwc_fwd_gnstats(const float* x, const float* part_prev, int nch_prev, const float* gamma_prev,
+                                const float* beta_prev, int relu_prev, float* stats_prev_out, const float* w, float* y,
+                                float* partials, int* nchunks, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_groupnorm_apply_n(const float* y, const float* partials, int nch, const float* gamma, const float* beta,
+                          const float* residual, const float* res_partials, int res_nch, const float* res_gamma,
+                          const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C, int relu,
+                          dyb_stream_t stream);
+
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
 int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);

@@ -681,3 +681,47 @@ def case_pa_mpjpe(be, golden, n_random=40, seed=41):
     assert np.abs(o - err_ref).max() < 2e-5 + 1e-4 * err_ref.max(), (o - err_ref)     # ... the error does not
     assert o[len(g["S1"])] < 1e-6
     return dict(max_abs=float(np.abs(o - err_ref).max()))
+
+
+# ------------------------------------------------------------------- conv + GroupNorm statistics per layer (K4 / tiled)
+def case_layer_gnstats(be, N, H, W, C, Ka, Ra, sa, Kb, Rb, sb, seed=51):
+    """Two chained layers through dyb_conv2d_nhwc_fwd_gnstats (+ dyb_groupnorm_apply_n at the end):
+    out = relu(GN(convB(relu(GN(convA(x)))))) with A's normalised output never materialised.  Shapes pick the
+    single-launch K4 kernel (1x1, batch 1, small maps) or the tiled conv + statistics kernel; both must agree with torch."""
+    rng = _rng(seed)
+    pa, pb = (1 if Ra == 3 else 0), (1 if Rb == 3 else 0)
+    Ha, Wa = (H + 2 * pa - Ra) // sa + 1, (W + 2 * pa - Ra) // sa + 1
+    Hb, Wb = (Ha + 2 * pb - Rb) // sb + 1, (Wa + 2 * pb - Rb) // sb + 1
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    wa = (rng.standard_normal((Ra, Ra, C, Ka)) / np.sqrt(Ra * Ra * C)).astype(np.float32)
+    wb = (rng.standard_normal((Rb, Rb, Ka, Kb)) / np.sqrt(Rb * Rb * Ka)).astype(np.float32)
+    ga, ba = (1 + 0.2 * rng.standard_normal(Ka)).astype(np.float32), (0.2 * rng.standard_normal(Ka)).astype(np.float32)
+    gb, bb = (1 + 0.2 * rng.standard_normal(Kb)).astype(np.float32), (0.2 * rng.standard_normal(Kb)).astype(np.float32)
+    cw = lambda w: torch.from_numpy(w).permute(3, 2, 0, 1).contiguous()
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    ya_t = F.conv2d(xt, cw(wa), stride=sa, padding=pa)
+    a_t = F.relu(F.group_norm(ya_t, 4, torch.from_numpy(ga), torch.from_numpy(ba), 1e-5))
+    yb_t = F.conv2d(a_t, cw(wb), stride=sb, padding=pb)
+    out_t = F.relu(F.group_norm(yb_t, 4, torch.from_numpy(gb), torch.from_numpy(bb), 1e-5))
+    L = be.lib
+    shA, shB = (N, H, W, C, Ka, Ra, Ra, sa, pa), (N, Ha, Wa, Ka, Kb, Rb, Rb, sb, pb)
+    wsb = max(L.dyb_conv2d_workspace_bytes(*shA), L.dyb_conv2d_workspace_bytes(*shB), 16)
+    ws = be.empty((wsb // 4,))
+    pfl = lambda HW, K: max(L.dyb_groupnorm_workspace_bytes(N, HW, K) // 4, (HW // 32 + 1) * (K // 32 + 1) * 8)
+    PA, PB = be.empty((pfl(Ha * Wa, Ka),)), be.empty((pfl(Hb * Wb, Kb),))
+    YA, YB = be.empty((N, Ha * Wa, Ka)), be.empty((N, Hb * Wb, Kb))
+    SA, SB, OUT = be.empty((N, 4, 2)), be.empty((N, 4, 2)), be.empty((N, Hb * Wb, Kb))
+    nA, nB = ctypes.c_int(0), ctypes.c_int(0)
+    X, WA, WB, GA, BA, GB_, BB = [be.dev(a) for a in (x, wa, wb, ga, ba, gb, bb)]
+    check(L.dyb_conv2d_nhwc_fwd_gnstats(be.ptr(X), None, 0, None, None, 0, None, be.ptr(WA), be.ptr(YA), be.ptr(PA),
+                                        ctypes.byref(nA), *shA, be.ptr(ws), wsb, be.stream), "layer A")
+    check(L.dyb_conv2d_nhwc_fwd_gnstats(be.ptr(YA), be.ptr(PA), nA.value, be.ptr(GA), be.ptr(BA), 1, be.ptr(SA), be.ptr(WB),
+                                        be.ptr(YB), be.ptr(PB), ctypes.byref(nB), *shB, be.ptr(ws), wsb, be.stream), "layer B")
+    check(L.dyb_groupnorm_apply_n(be.ptr(YB), be.ptr(PB), nB.value, be.ptr(GB_), be.ptr(BB), None, None, 0, None, None, None,
+                                  be.ptr(OUT), be.ptr(SB), N, Hb * Wb, Kb, 1, be.stream), "apply")
+    nhwc = lambda t, K: t.permute(0, 2, 3, 1).reshape(N, -1, K).numpy()
+    mean_a = ya_t.reshape(N, 4, -1).mean(-1).numpy()
+    e = dict(ya=rel_err(be.host(YA), nhwc(ya_t, Ka)), yb=rel_err(be.host(YB), nhwc(yb_t, Kb)), out=rel_err(be.host(OUT), nhwc(out_t, Kb)),
+             mean_a=float(np.abs(be.host(SA)[:, :, 0] - mean_a).max()))
+    assert max(e.values()) < 5e-4, e
+    return dict(e, nA=nA.value, nB=nB.value)

@@ -60,6 +60,19 @@ def test_bottleneck_fused(be, cfg):
     K.case_bottleneck_fused(be, *cfg, seed=sum(int(v) for v in cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, Ka, Ra, sa, Kb, Rb, sb
+    (1, 6, 6, 64, 128, 1, 1, 128, 1, 1),       # K4 -> K4 (the second with the producer's GroupNorm in its loader)
+    (1, 9, 9, 128, 128, 1, 2, 256, 1, 1),      # K4 with stride 2 (downsample flavour), ragged 25-pixel map
+    (1, 6, 6, 64, 128, 1, 1, 64, 3, 1),        # K4 -> tiled 3x3 (partials of the tile kind consumed by the tiled loader)
+    (1, 6, 6, 64, 64, 3, 1, 128, 1, 1),        # tiled 3x3 -> K4
+    (2, 6, 6, 64, 128, 1, 1, 128, 1, 1),       # batch 2: tiled path for the same shapes
+])
+def test_layer_gnstats(be, cfg):
+    r = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+    assert r["nA"] > 0 and r["nB"] > 0
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)

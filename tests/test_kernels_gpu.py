@@ -67,6 +67,21 @@ def test_bottleneck_fused(be, cfg):
     K.case_bottleneck_fused(be, *cfg, seed=sum(int(v) for v in cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, Ka, Ra, sa, Kb, Rb, sb   (layer pairs of ResNet-50 at 224x224; K4 = the single-launch 1x1 kernel)
+    (1, 28, 28, 512, 128, 1, 1, 128, 3, 1),      # layer2 conv1 (K4) -> conv2 (tiled 3x3)
+    (1, 28, 28, 128, 512, 1, 1, 128, 1, 1),      # layer2 conv3 (K4) -> next conv1 (K4 with loader GroupNorm)
+    (1, 14, 14, 1024, 256, 1, 1, 256, 3, 1),     # layer3 conv1 (K4, 8 K-steps) -> conv2
+    (1, 14, 14, 256, 1024, 1, 1, 256, 1, 1),     # layer3 conv3 -> conv1
+    (1, 7, 7, 512, 2048, 1, 1, 512, 1, 1),       # layer4 conv3 (K4) -> conv1 (Cin 2048: tiled)
+    (1, 56, 56, 256, 512, 1, 2, 128, 1, 1),      # stride-2 downsample (K4, M = 784)
+    (1, 56, 56, 64, 256, 1, 1, 64, 1, 1),        # layer1: M = 3136 -> tiled path
+    (4, 14, 14, 256, 1024, 1, 1, 256, 1, 1),     # batch 4 -> tiled path
+])
+def test_layer_gnstats(be, cfg):
+    K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+
+
 def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 784, 512, 4, True)
     K.case_groupnorm_fold(be, 1, 49, 2048, 36, False)
