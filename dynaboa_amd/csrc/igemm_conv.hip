@@ -286,12 +286,16 @@ __device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, 
       if (v < nvals) {
         const float* pp = nf.partials + (size_t)(v >> 3) * nf.nchunks * 8 + (v & 7);
         for (int k0 = sub; k0 < nf.nchunks; k0 += 8 * L) {
+          // unconditional loads from clamped indices first, masks afterwards: a per-lane `cond ? load : 0` is waited
+          // for load by load (K4 kernel's note) and this fold is on the consumer's critical path
           float t[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int k = k0 + j * L;
-            t[j] = k < nf.nchunks ? pp[(size_t)k * 8] : 0.f;
+            t[j] = pp[(size_t)(k < nf.nchunks ? k : nf.nchunks - 1) * 8];
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = (k0 + j * L < nf.nchunks) ? t[j] : 0.f;
           s += (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) +
                (((double)t[4] + (double)t[5]) + ((double)t[6] + (double)t[7]));
         }
@@ -368,13 +372,13 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     if constexpr (MODE == MODE_FWD) {
       if constexpr (FA) {
         const int k = kt * BK + 16 * h + t_kq;
+        // branch-free (a padding tap reads element 0 and is zeroed when staged): a load under `if (ok)` is waited for
+        // on the spot, which serialises the cold-L2 round trips of a K-step (see the K4 kernel's note)
         long off = fwd_a_off(g, fa, k);
         o.ok = off >= 0;
-        if (o.ok) {
-          o.d = *reinterpret_cast<const float4*>(g.A + off);
-          o.v = *reinterpret_cast<const float4*>(nf.gamma + (k & (g.C - 1)));
-          o.ga = *reinterpret_cast<const float4*>(nf.beta + (k & (g.C - 1)));
-        }
+        o.d = *reinterpret_cast<const float4*>(g.A + (o.ok ? off : 0));
+        o.v = *reinterpret_cast<const float4*>(nf.gamma + (k & (g.C - 1)));
+        o.ga = *reinterpret_cast<const float4*>(nf.beta + (k & (g.C - 1)));
       } else {
         o.d = fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
       }
@@ -382,11 +386,10 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       if constexpr (GB) {
         long off = dg_a_off(g, da, kt * BK + 16 * h + t_kq);
         o.ok = off >= 0;
-        if (o.ok) {
-          o.d = *reinterpret_cast<const float4*>(g.A + off);
-          o.v = *reinterpret_cast<const float4*>(f.y + off);
-          o.ga = *reinterpret_cast<const float4*>(f.gamma + ((kt * BK + 16 * h + t_kq) & (g.K - 1)));
-        }
+        off = o.ok ? off : 0;
+        o.d = *reinterpret_cast<const float4*>(g.A + off);
+        o.v = *reinterpret_cast<const float4*>(f.y + off);
+        o.ga = *reinterpret_cast<const float4*>(f.gamma + ((kt * BK + 16 * h + t_kq) & (g.K - 1)));
       } else {
         o.d = dg_a_load(g, da, kt * BK + 16 * h + t_kq);
       }
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       if constexpr (FA) {
         long off = wg_a_off(g, wa, kt * BK + 16 * h + d_k);
         o.ok = off >= 0;
-        if (o.ok) o.d = *reinterpret_cast<const float4*>(g.A + off);
+        o.d = *reinterpret_cast<const float4*>(g.A + (o.ok ? off : 0));
       } else {
         o.d = wg_a_load(g, wa, kt * BK + 16 * h + d_k);
       }
@@ -407,11 +410,9 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       if constexpr (GB) {
         const int p = kt * BK + 16 * h + d_k, col = n0 + d_q;
         o.ok = p < g.Kdim && col < g.Ncols;
-        if (o.ok) {
-          size_t off = (size_t)p * g.K + col;
-          o.d = *reinterpret_cast<const float4*>(g.B + off);
-          o.v = *reinterpret_cast<const float4*>(f.y + off);
-        }
+        const size_t off = o.ok ? (size_t)p * g.K + col : 0;
+        o.d = *reinterpret_cast<const float4*>(g.B + off);
+        o.v = *reinterpret_cast<const float4*>(f.y + off);
       } else {
         o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
       }
@@ -495,8 +496,10 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int k = k0 + j * L;
-            t[j] = k < f.kparts ? gp[(size_t)k * 8] : 0.f;
+            t[j] = gp[(size_t)(k < f.kparts ? k : f.kparts - 1) * 8];        // clamped, masked below (see gnf_prologue)
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = (k0 + j * L < f.kparts) ? t[j] : 0.f;
           s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         }
       }
@@ -530,12 +533,17 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 #pragma unroll
         for (int h = 0; h < NH; ++h) load_b(kt + 1, h, rb[h]);
       }
+      // keep the three phases apart: nothing that consumes the loads (staging stores, the zero-select of padding taps,
+      // the GroupNorm arithmetic of the fused loaders) may be scheduled above the MFMAs - its wait would expose the
+      // whole memory latency instead of overlapping it with the matrix work
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k2 = 0; k2 < BK; k2 += 2) {
         float a = As[buf][k2 + khalf][arow];
         float b = Bs[buf][k2 + khalf][bcol];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (more) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) { store_a(buf ^ 1, kt + 1, h, ra[h]); store_b(buf ^ 1, kt + 1, h, rb[h]); }
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 }
 
 // ---- 1x1 forward conv with the GroupNorm statistics in its epilogue ("K4") -------------------------
-// The small 1x1 layers (layers 2-4: M = Ho*Wo <= 784 pixels at batch 1, Cin <= 1024) are where a forward
+// The small 1x1 layers (layers 2-4: M = Ho*Wo <= 784 pixels at batch 1, Cin <= 512) are where a forward
 // conv spends its time in launch + the statistics kernel that follows it, not in arithmetic.  Here the
 // four waves of a workgroup split the K range of ONE 32x32 output tile (K-step 128 = 32 per wave), sum
 // their accumulators through LDS, and - because no split-K slabs are left to fold - finish the layer in
@@ -625,35 +633,33 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
   // A pieces: tile row a_row, 4 consecutive k at 32h + a_kq (h = 0..3 -> consumed by wave h); B pieces: k row 32h + b_k, 4 columns
   const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
   const int b_k = tid >> 3, b_q = (tid & 7) * 4;
-  const int m = m0 + a_row;
-  const bool row_ok = m < g.M;
-  const int ho = row_ok ? m / g.Wo : 0, wo = row_ok ? m - (m / g.Wo) * g.Wo : 0;
+  // No bounds logic in the loaders: Cin % 128 == 0 and Cout % 32 == 0 keep every piece in range, and rows past the end
+  // of a ragged last tile re-read row M-1 (their results are never stored or counted).  Any per-piece condition - a
+  // branch, or even a select on the loaded value - makes the compiler wait for that load on the spot, which serialises
+  // the eight cold-L2 round trips of a K-step (seen in the ISA as one s_waitcnt vmcnt per load).
+  const int m = (m0 + a_row < g.M) ? m0 + a_row : g.M - 1;
+  const int ho = m / g.Wo, wo = m - (m / g.Wo) * g.Wo;
   const float* arow = g.x + ((size_t)(ho * g.stride) * g.W + (size_t)wo * g.stride) * g.C;
   const int logCg = dyb_ilog2_dev(g.C) - 2;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  (void)zero4;
 
   auto load_a = [&](int kt, int h, Frag& o) {
     const int k = kt * K4_BK + 32 * h + a_kq;
-    o.ok = row_ok && k < g.C;
-    o.d = zero4;
-    if (o.ok) {
-      o.d = *reinterpret_cast<const float4*>(arow + k);
-      if constexpr (FA) {
-        o.v = *reinterpret_cast<const float4*>(nf.gamma + k);
-        o.ga = *reinterpret_cast<const float4*>(nf.beta + k);
-      }
+    o.d = *reinterpret_cast<const float4*>(arow + k);
+    if constexpr (FA) {
+      o.v = *reinterpret_cast<const float4*>(nf.gamma + k);
+      o.ga = *reinterpret_cast<const float4*>(nf.beta + k);
     }
   };
   auto load_b = [&](int kt, int h, Frag& o) {
-    const int k = kt * K4_BK + 32 * h + b_k, col = n0 + b_q;
-    o.d = (k < g.C && col < g.K) ? *reinterpret_cast<const float4*>(g.w + (size_t)k * g.K + col) : zero4;
+    o.d = *reinterpret_cast<const float4*>(g.w + (size_t)(kt * K4_BK + 32 * h + b_k) * g.K + n0 + b_q);
   };
   auto store = [&](int buf, int kt, int h, const Frag& a, const Frag& b) {
     float4 v = a.d;
     if constexpr (FA) {
-      const int k = kt * K4_BK + 32 * h + a_kq;
-      const float* st = &s_nrm[(k >> logCg) * 2];
-      v = a.ok ? gnf_apply(a.d, a.v, a.ga, st[0], st[1], nf.relu) : zero4;
+      const float* st = &s_nrm[((kt * K4_BK + 32 * h + a_kq) >> logCg) * 2];
+      v = gnf_apply(a.d, a.v, a.ga, st[0], st[1], nf.relu);
     }
     As[buf][32 * h + a_kq + 0][a_row] = v.x;
     As[buf][32 * h + a_kq + 1][a_row] = v.y;
@@ -682,12 +688,17 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
 #pragma unroll
       for (int h = 0; h < 4; ++h) { load_a(kt + 1, h, ra[h]); load_b(kt + 1, h, rb[h]); }
     }
+    // scheduling barriers: the staging stores below target the OTHER LDS buffer, so nothing but these keeps the compiler
+    // from hoisting them (and the wait for the loads they consume) above the MFMAs - which would expose the full
+    // memory latency every step instead of overlapping it with the matrix work
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k2 = 0; k2 < 32; k2 += 2) {
       float a = As[buf][32 * wave + k2 + khalf][l31];
       float b = Bs[buf][32 * wave + k2 + khalf][l31];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
 #pragma unroll
       for (int h = 0; h < 4; ++h) store(buf ^ 1, kt + 1, h, ra[h], rb[h]);
@@ -1045,7 +1056,10 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
 bool dyb_conv_k4_ok(const ConvDesc& d) {
   const int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
   static const int enabled = getenv("DYB_K4") ? atoi(getenv("DYB_K4")) : 1;
-  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 64 && d.C <= 1024 &&
+  static const int max_c = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
+  // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
+  // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
+  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }
 // conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count

@@ -30,11 +30,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     // four weight pieces (+ the matching x pieces) in flight per round trip: the row stream is the
     // latency chain of this kernel at batch 1 (fc1: 9 pieces per lane)
     for (int i0 = lane; i0 < I4; i0 += 256) {
+      // clamped unconditional loads (a per-lane `cond ? load : 0` is waited for load by load); the clamped repeats
+      // are zeroed through the weight piece only
       float4 wv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i4 = i0 + 64 * j;
-        wv[j] = i4 < I4 ? *reinterpret_cast<const float4*>(wr + (size_t)i4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv[j] = *reinterpret_cast<const float4*>(wr + (size_t)(i4 < I4 ? i4 : I4 - 1) * 4);
       }
 #pragma unroll
       for (int t = 0; t < LIN_BT; ++t) {
@@ -43,8 +45,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i4 = i0 + 64 * j;
-            xv[j] = i4 < I4 ? *reinterpret_cast<const float4*>(x + (size_t)(b0 + t) * ldx + (size_t)i4 * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[j] = *reinterpret_cast<const float4*>(x + (size_t)(b0 + t) * ldx + (size_t)(i4 < I4 ? i4 : I4 - 1) * 4);
+          }
+          if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (i0 + 64 * j >= I4) wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -91,13 +97,25 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < LIN_BT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
-      for (int o = o0 + ty; o < o1; o += 4) {
-        float4 wv = *reinterpret_cast<const float4*>(w + (size_t)o * ldw + (size_t)i4 * 4);
+      // four rows per trip, every load issued before the first use (rows past the end re-read the last row with a zero
+      // gradient): the weight rows are cold L2 misses, one round trip per trip instead of one per row
+      for (int ob = o0 + ty; ob < o1; ob += 16) {
+        float4 wv[4];
+        float d[4][LIN_BT];
 #pragma unroll
-        for (int t = 0; t < LIN_BT; ++t) {
-          if (b0 + t < B) {
-            float d = dy[(size_t)(b0 + t) * lddy + o];
-            acc[t].x += d * wv.x; acc[t].y += d * wv.y; acc[t].z += d * wv.z; acc[t].w += d * wv.w;
+        for (int j = 0; j < 4; ++j) {
+          const int o = ob + 4 * j, oc = o < o1 ? o : o1 - 1;
+          wv[j] = *reinterpret_cast<const float4*>(w + (size_t)oc * ldw + (size_t)i4 * 4);
+#pragma unroll
+          for (int t = 0; t < LIN_BT; ++t) d[j][t] = dy[(size_t)(b0 + t < B ? b0 + t : B - 1) * lddy + oc];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool rok = ob + 4 * j < o1;
+#pragma unroll
+          for (int t = 0; t < LIN_BT; ++t) {
+            const float dd = (rok && b0 + t < B) ? d[j][t] : 0.f;
+            acc[t].x += dd * wv[j].x; acc[t].y += dd * wv[j].y; acc[t].z += dd * wv[j].z; acc[t].w += dd * wv[j].w;
           }
         }
       }

@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     for (int c0 = lane; c0 < nch; c0 += 256) {
       float2 t[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {          // clamped unconditional loads, masked below: a per-lane conditional load is waited for on the spot
         const int ch = c0 + 64 * j;
-        t[j] = ch < nch ? *reinterpret_cast<const float2*>(pp + (((size_t)n * nch + ch) * G + wave) * 2) : make_float2(0.f, 0.f);
+        t[j] = *reinterpret_cast<const float2*>(pp + (((size_t)n * nch + (ch < nch ? ch : nch - 1)) * G + wave) * 2);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + 64 * j >= nch) t[j] = make_float2(0.f, 0.f);
       a += ((double)t[0].x + (double)t[1].x) + ((double)t[2].x + (double)t[3].x);
       b += ((double)t[0].y + (double)t[1].y) + ((double)t[2].y + (double)t[3].y);
     }
