@@ -555,16 +555,23 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   // C/D fragment of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* outp = g.out + (g.nsplit > 1 ? (size_t)blockIdx.z * g.M * g.Ncols : 0);
   const int col = n0 + wn * 32 + (lane & 31);
+  if (g.nsplit == 1 && g.addend) {
+    // the 16 addend values are fetched together (clamped addresses), not one conditional load + wait per row
+    float add[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const bool ok = row < g.M && col < g.Ncols;
+      add[r] = g.addend[ok ? (size_t)row * g.Ncols + col : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += add[r];
+  }
   if (col < g.Ncols) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < g.M) {
-        size_t o = (size_t)row * g.Ncols + col;
-        float v = acc[r];
-        if (g.nsplit == 1 && g.addend) v += g.addend[o];
-        outp[o] = v;
-      }
+      if (row < g.M) outp[(size_t)row * g.Ncols + col] = acc[r];
     }
   }
 
