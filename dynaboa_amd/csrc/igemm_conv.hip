@@ -585,20 +585,24 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       const int c = n0 + cl, C = g.K;
       float A = 0.f, B = 0.f;
       if (c < C) {
+        // eight (A, B) pairs in flight per lane and trip: with ~100 chunks the fold was 14 dependent trips, the
+        // longest thing in the launch
         const int total = g.N * f.nchunks;
-        float A1 = 0.f, B1 = 0.f;
-        int k = part;
-        for (; k + 4 < total; k += 8) {
-          const float* p0 = f.partials + (size_t)k * 2 * C + c;
-          const float* p1 = f.partials + (size_t)(k + 4) * 2 * C + c;
-          float a0 = p0[0], b0 = p0[C], a1 = p1[0], b1 = p1[C];
-          A += a0; B += b0; A1 += a1; B1 += b1;
+        for (int k0 = part; k0 < total; k0 += 32) {
+          float a8[8], b8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 4 * j;
+            const float* p0 = f.partials + (size_t)(k < total ? k : total - 1) * 2 * C + c;
+            a8[j] = p0[0];
+            b8[j] = p0[C];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (k0 + 4 * j >= total) { a8[j] = 0.f; b8[j] = 0.f; }
+          A += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+          B += ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7]));
         }
-        if (k < total) {
-          const float* p0 = f.partials + (size_t)k * 2 * C + c;
-          A += p0[0]; B += p0[C];
-        }
-        A += A1; B += B1;
       }
       s_gb[part][cl][0] = A;
       s_gb[part][cl][1] = B;

@@ -348,30 +348,48 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       accumulate(d1, v1, q1, o1);
     }
   }
-  for (; row < row1; row += TY) {
-    size_t off = ((size_t)n * HW + row) * C + (size_t)cq * 4;
-    float4 d = *reinterpret_cast<const float4*>(dout + off);
-    float4 v = *reinterpret_cast<const float4*>(y + off);
-    float4 q = (relu && out) ? *reinterpret_cast<const float4*>(out + off) : zero4;
+  // folded gradient: two rows per trip - every load of both rows (base slab, y, mask source, addend, up to 8 more slabs
+  // each) is issued before the first use; a missing second row re-reads the first and is dropped
+  auto fold_row = [&](float4& d, const float4 (&t)[8]) {
+    d.x += ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
+    d.y += ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
+    d.z += ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
+    d.w += ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
+  };
+  for (; row < row1; row += 2 * TY) {
+    const bool two = row + TY < row1;
+    const size_t off0 = ((size_t)n * HW + row) * C + (size_t)cq * 4;
+    const size_t off1 = two ? off0 + (size_t)TY * C : off0;
+    float4 d0 = *reinterpret_cast<const float4*>(dout + off0), d1 = *reinterpret_cast<const float4*>(dout + off1);
+    float4 v0 = *reinterpret_cast<const float4*>(y + off0), v1 = *reinterpret_cast<const float4*>(y + off1);
+    float4 q0 = (relu && out) ? *reinterpret_cast<const float4*>(out + off0) : zero4;
+    float4 q1 = (relu && out) ? *reinterpret_cast<const float4*>(out + off1) : zero4;
     if (fold) {
-      // eight slab loads in flight per round trip
-      if (addend) {
-        float4 p = *reinterpret_cast<const float4*>(addend + off);
-        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
-      }
+      float4 p0 = addend ? *reinterpret_cast<const float4*>(addend + off0) : zero4;
+      float4 p1 = addend ? *reinterpret_cast<const float4*>(addend + off1) : zero4;
+      d0.x += p0.x; d0.y += p0.y; d0.z += p0.z; d0.w += p0.w;
+      d1.x += p1.x; d1.y += p1.y; d1.z += p1.z; d1.w += p1.w;
       for (int z0 = 1; z0 < nslabs; z0 += 8) {
-        float4 t[8];
+        float4 t0[8], t1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const size_t zo = (size_t)(z0 + j < nslabs ? z0 + j : 0) * slab_stride;      // uniform clamp, zeroed below
+          t0[j] = *reinterpret_cast<const float4*>(dout + zo + off0);
+          t1[j] = *reinterpret_cast<const float4*>(dout + zo + off1);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          t[j] = (z0 + j < nslabs) ? *reinterpret_cast<const float4*>(dout + (size_t)(z0 + j) * slab_stride + off) : zero4;
-        d.x += ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
-        d.y += ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
-        d.z += ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
-        d.w += ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
+          if (z0 + j >= nslabs) { t0[j] = zero4; t1[j] = zero4; }
+        fold_row(d0, t0);
+        fold_row(d1, t1);
       }
-      if (folded) *reinterpret_cast<float4*>(folded + off) = d;
+      if (folded) {
+        *reinterpret_cast<float4*>(folded + off0) = d0;
+        if (two) *reinterpret_cast<float4*>(folded + off1) = d1;
+      }
     }
-    accumulate(d, v, q, off);
+    accumulate(d0, v0, q0, off0);
+    if (two) accumulate(d1, v1, q1, off1);
   }
   float* mine = sm + threadIdx.x * 8;
 #pragma unroll
