@@ -773,21 +773,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n4; i += step) {
-    // four independent accumulators keep four slab loads in flight (the fold is latency-bound)
+    // eight slab loads in flight per trip (uniform bounds: no per-lane condition around a load)
     float4 s = slabs[i];
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
-    int z = 1;
-    for (; z + 2 < nsplit; z += 3) {
-      float4 a = slabs[(size_t)z * n4 + i], b = slabs[(size_t)(z + 1) * n4 + i], c = slabs[(size_t)(z + 2) * n4 + i];
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
-      s3.x += c.x; s3.y += c.y; s3.z += c.z; s3.w += c.w;
+    for (int z0 = 1; z0 < nsplit; z0 += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = slabs[(size_t)(z0 + j < nsplit ? z0 + j : 0) * n4 + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (z0 + j >= nsplit) t[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s.x += ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
+      s.y += ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
+      s.z += ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
+      s.w += ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
     }
-    for (; z < nsplit; ++z) {
-      float4 t = slabs[(size_t)z * n4 + i];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-    }
-    s.x += (s1.x + s2.x) + s3.x; s.y += (s1.y + s2.y) + s3.y; s.z += (s1.z + s2.z) + s3.z; s.w += (s1.w + s2.w) + s3.w;
     if (addend) {
       float4 t = addend[i];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;

@@ -214,9 +214,18 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(SmplTables T, const float
                                                        float* __restrict__ extra_part) {
   __shared__ float sA[NJ * 12], sPf[NPF_PAD], sBe[NB], sPart[4][LBS_VB][3];
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < NJ * 12; i += 256) sA[i] = A[(size_t)b * NJ * 12 + i];
-  for (int i = t; i < NPF_PAD; i += 256) sPf[i] = pf[(size_t)b * NPF_PAD + i];
-  if (t < NB) sBe[t] = betas[(size_t)b * ldb + t];
+  {
+    // the three small tables are fetched in ONE round trip (clamped addresses, all loads before the first LDS store);
+    // three staging loops in a row are three dependent trips in front of the sweep
+    const float a0 = A[(size_t)b * NJ * 12 + t];
+    const float a1 = A[(size_t)b * NJ * 12 + (t + 256 < NJ * 12 ? t + 256 : 0)];
+    const float p0 = pf[(size_t)b * NPF_PAD + (t < NPF_PAD ? t : 0)];
+    const float be = betas[(size_t)b * ldb + (t < NB ? t : 0)];
+    sA[t] = a0;
+    if (t + 256 < NJ * 12) sA[t + 256] = a1;
+    if (t < NPF_PAD) sPf[t] = p0;
+    if (t < NB) sBe[t] = be;
+  }
   __syncthreads();
   const int v = blockIdx.x * LBS_VB + lane;
   const bool live = v < NV;
