@@ -910,6 +910,21 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   return DYB_OK;
 }
 
+static int conv_out_dim(int in, int k, int stride, int pad);
+// a (start, stop) event pair + the launch's algorithmic flop / bytes booked, when a timing scope is open
+static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1) {
+  if (!g_timing) return;                      // unlocked fast path when no scope is open
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  if (!g_timing || g_timing->used + 2 > g_timing->ev.size()) return;
+  *ev0 = g_timing->ev[g_timing->used];
+  *ev1 = g_timing->ev[g_timing->used + 1];
+  g_timing->used += 2;
+  const double creal = d.C == 4 ? 3.0 : (double)d.C;        // the stem's 4th input channel is padding
+  const double px = (double)d.N * conv_out_dim(d.H, d.R, d.stride, d.pad) * conv_out_dim(d.W, d.S, d.stride, d.pad);
+  g_timing->flop += 2.0 * px * d.K * d.R * d.S * creal;
+  g_timing->bytes += 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
+}
+
 // Runs one mode.  If `raw_slabs_out` is non-null and the policy picks nsplit>1 the slabs are left
 // in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
@@ -936,17 +951,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   DYB_REQUIRE(!(fuse || nfuse) || d.N <= 64, DYB_ERR_UNSUPPORTED);
   const dim3 blk(256);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::unique_lock<std::mutex> tlock(g_timing_mu, std::defer_lock);
-  if (g_timing) tlock.lock();                 // unlocked fast path when no scope is open
-  if (g_timing && g_timing->used + 2 <= g_timing->ev.size()) {
-    ev0 = g_timing->ev[g_timing->used];
-    ev1 = g_timing->ev[g_timing->used + 1];
-    g_timing->used += 2;
-    const double creal = d.C == 4 ? 3.0 : (double)d.C;        // the stem's 4th input channel is padding
-    const double px = (double)d.N * conv_out_dim(d.H, d.R, d.stride, d.pad) * conv_out_dim(d.W, d.S, d.stride, d.pad);
-    g_timing->flop += 2.0 * px * d.K * d.R * d.S * creal;
-    g_timing->bytes += 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
-  }
+  timing_acquire(d, &ev0, &ev1);
 #define DYB_IGEMM_LAUNCH(M_, GB_, FA_)                                                                          \
   do {                                                                                                          \
     if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf); \
@@ -967,7 +972,6 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     else DYB_IGEMM_LAUNCH(MODE_WGRAD, false, false);
   }
 #undef DYB_IGEMM_LAUNCH
-  if (tlock.owns_lock()) tlock.unlock();
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
@@ -1080,12 +1084,13 @@ int dyb_conv_fwd_k4(const ConvDesc& d, const float* x, const float* w, float* y,
   g.M = g.Ho * g.Wo;
   dim3 grid(dyb_cdiv(g.M, 32), d.K / 32);
   GnFwdFuse f{};
-  if (nf) {
-    f = *nf;
-    hipLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, g, f);
-  } else {
-    hipLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, g, f);
-  }
+  if (nf) f = *nf;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  timing_acquire(d, &ev0, &ev1);
+  if (nf && ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);
+  else if (nf) hipLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, g, f);
+  else if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);
+  else hipLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, g, f);
   DYB_CHECK_LAUNCH();
   *nchunks = (int)(grid.x * grid.y);
   return DYB_OK;
