@@ -6,8 +6,8 @@
 //     block outputs; the GroupNorm+ReLU outputs INSIDE a bottleneck (bn1, bn2, downsample.1) have a
 //     single consumer and are never written - that consumer normalises y on the fly in its loader,
 //   * a workspace (split-K slabs, norm partials, three gradient buffers, per-layer masked gradients).
-// One C call = one whole forward (138 launches: conv -> statistics per layer, one apply per block
-// output) or backward (~210: GroupNorm-backward reduce -> data gradient per layer on the critical
+// One C call = one whole forward (112 launches: conv -> statistics per layer - one launch for the small 1x1
+// layers -, one apply per block output) or backward (~210: GroupNorm-backward reduce -> data gradient per layer on the critical
 // chain, weight gradients on an auxiliary stream), no host syncs, no allocation, capturable in a
 // hipGraph.  PyTorch only owns the memory and the stream.
 #include <stdlib.h>

@@ -910,7 +910,6 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   return DYB_OK;
 }
 
-static int conv_out_dim(int in, int k, int stride, int pad);
 // a (start, stop) event pair + the launch's algorithmic flop / bytes booked, when a timing scope is open
 static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1) {
   if (!g_timing) return;                      // unlocked fast path when no scope is open
