@@ -658,14 +658,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     int n = (int)(t / Ho);
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     uint32_t bi[4] = {255u, 255u, 255u, 255u};
-    for (int r = 0; r < 3; ++r) {
-      int hi = ho * 2 - 1 + r;
-      if (hi < 0 || hi >= H) continue;
+    // the nine taps are fetched together (out-of-range taps re-read the clamped pixel and are skipped below), then
+    // compared in the reference's scan order: a load inside the `continue` structure is one dependent round trip per tap
+    float4 tapv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
       for (int s = 0; s < 3; ++s) {
-        int wi = wo * 2 - 1 + s;
-        if (wi < 0 || wi >= W) continue;
-        float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + hi) * W + wi) * C + (size_t)cq * 4);
-        uint32_t tap = r * 3 + s;
+        int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+        hi = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+        wi = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+        tapv[r * 3 + s] = *reinterpret_cast<const float4*>(x + (((size_t)n * H + hi) * W + wi) * C + (size_t)cq * 4);
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = wo * 2 - 1 + s;
+        if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+        const float4 v = tapv[r * 3 + s];
+        const uint32_t tap = r * 3 + s;
         if (v.x > best.x || bi[0] == 255u) { best.x = v.x; bi[0] = tap; }
         if (v.y > best.y || bi[1] == 255u) { best.y = v.y; bi[1] = tap; }
         if (v.z > best.z || bi[2] == 255u) { best.z = v.z; bi[2] = tap; }

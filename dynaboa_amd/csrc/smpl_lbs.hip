@@ -444,13 +444,16 @@ __device__ __forceinline__ void fill_dpf(float (&vals)[64], const float* __restr
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
     const int q = BASE + i;
+    // unconditional loads (dead lanes read vertex 0 and are masked through `lv`): a load under `if (live)` is waited
+    // for on the spot, which made this sweep ~200 dependent round trips (tools/isa_scan.py)
+    const float lv = live ? 1.f : 0.f;
     float x = 0.f;
     if (q < NPF) {
       const float* row = pd + (size_t)q * (NV * 3);
-      if (live) x = row[0] * dvp[0] + row[1] * dvp[1] + row[2] * dvp[2];
+      x = (row[0] * dvp[0] + row[1] * dvp[1] + row[2] * dvp[2]) * lv;
     } else if (q < NPF + NB) {
       const int l = q - NPF;
-      if (live) x = sd[l] * dvp[0] + sd[NB + l] * dvp[1] + sd[2 * NB + l] * dvp[2];
+      x = (sd[l] * dvp[0] + sd[NB + l] * dvp[1] + sd[2 * NB + l] * dvp[2]) * lv;
     }
     vals[i] = x;
   }
@@ -465,24 +468,50 @@ __global__ __launch_bounds__(64) void lbs_bwd_skin_kernel(SmplTables T, const fl
   __shared__ float sA[NJ * 12], sDj[NJ54 * 3];
   __shared__ int sVj[NVJ];
   const int b = blockIdx.y, lane = threadIdx.x;
-  for (int i = lane; i < NJ * 12; i += 64) sA[i] = A[(size_t)b * NJ * 12 + i];
-  for (int i = lane; i < NJ54 * 3; i += 64) sDj[i] = dj54[(size_t)b * NJ54 * 3 + i];
-  if (lane < NVJ) sVj[lane] = T.vertex_joint_ids[lane];
+  {
+    // 288 + 162 + 21 staged values: all loads first (clamped), then the LDS stores - one round trip, not eight
+    float a5[5], d3[3];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) a5[u] = A[(size_t)b * NJ * 12 + (lane + 64 * u < NJ * 12 ? lane + 64 * u : 0)];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) d3[u] = dj54[(size_t)b * NJ54 * 3 + (lane + 64 * u < NJ54 * 3 ? lane + 64 * u : 0)];
+    const int vj = T.vertex_joint_ids[lane < NVJ ? lane : 0];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if (lane + 64 * u < NJ * 12) sA[lane + 64 * u] = a5[u];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (lane + 64 * u < NJ54 * 3) sDj[lane + 64 * u] = d3[u];
+    if (lane < NVJ) sVj[lane] = vj;
+  }
   __syncthreads();
   const int v = blockIdx.x * LBS_VB + lane;
   const bool live = v < NV;
   const int vv = live ? v : 0;
-  float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
+  // every global load of this prologue is unconditional and issued before the first use (dead lanes read vertex 0
+  // and are masked): skin weights, the extra-joint regressor column, vposed / dverts
+  const float lv = live ? 1.f : 0.f;
+  float w[NJ], xe[NEXTRA];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) w[j] = T.weights_t[(size_t)j * NV + vv];
+#pragma unroll
+  for (int e = 0; e < NEXTRA; ++e) xe[e] = T.j_extra[(size_t)e * NV + vv];
+  const size_t ov = ((size_t)b * NV + vv) * 3;
+  float dv[3] = {0.f, 0.f, 0.f}, vp[3];
+  if (dverts) { dv[0] = dverts[ov]; dv[1] = dverts[ov + 1]; dv[2] = dverts[ov + 2]; }     // uniform condition
+  vp[0] = vposed[ov]; vp[1] = vposed[ov + 1]; vp[2] = vposed[ov + 2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) w[j] *= lv;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { dv[c] *= lv; vp[c] *= lv; }
+#pragma unroll
+  for (int e = 0; e < NEXTRA; ++e) {
+    const float x = xe[e] * lv;
+    dv[0] += x * sDj[(NJ + NVJ + e) * 3 + 0];
+    dv[1] += x * sDj[(NJ + NVJ + e) * 3 + 1];
+    dv[2] += x * sDj[(NJ + NVJ + e) * 3 + 2];
+  }
   if (live) {
-    size_t o = ((size_t)b * NV + v) * 3;
-    if (dverts) { dv[0] = dverts[o]; dv[1] = dverts[o + 1]; dv[2] = dverts[o + 2]; }
-    vp[0] = vposed[o]; vp[1] = vposed[o + 1]; vp[2] = vposed[o + 2];
-    for (int e = 0; e < NEXTRA; ++e) {
-      float x = T.j_extra[(size_t)e * NV + v];
-      dv[0] += x * sDj[(NJ + NVJ + e) * 3 + 0];
-      dv[1] += x * sDj[(NJ + NVJ + e) * 3 + 1];
-      dv[2] += x * sDj[(NJ + NVJ + e) * 3 + 2];
-    }
     for (int k = 0; k < NVJ; ++k) {
       if (sVj[k] == v) {
         dv[0] += sDj[(NJ + k) * 3 + 0];
@@ -491,9 +520,6 @@ __global__ __launch_bounds__(64) void lbs_bwd_skin_kernel(SmplTables T, const fl
       }
     }
   }
-  float w[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) w[j] = live ? T.weights_t[(size_t)j * NV + vv] : 0.f;
   float TR[9];
 #pragma unroll
   for (int e = 0; e < 9; ++e) TR[e] = 0.f;
