@@ -24,9 +24,19 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   const float* wr = w + (size_t)o * ldw;
   const int I4 = I >> 2;
   for (int b0 = 0; b0 < B; b0 += LIN_BT) {
-    float acc[LIN_BT];
+    float acc[LIN_BT], addv[LIN_BT];
 #pragma unroll
     for (int t = 0; t < LIN_BT; ++t) acc[t] = 0.f;
+    // bias (+ residual) fetched up front by every lane (same address: one broadcast line), not by lane 0 after the
+    // reduction - there it would be two more dependent round trips at the end of a 5 us kernel
+    {
+      const float bo = bias[o];
+#pragma unroll
+      for (int t = 0; t < LIN_BT; ++t) {
+        const int bb = b0 + t < B ? b0 + t : B - 1;
+        addv[t] = bo + (res ? res[(size_t)bb * ldres + o] : 0.f);
+      }
+    }
     // four weight pieces (+ the matching x pieces) in flight per round trip: the row stream is the
     // latency chain of this kernel at batch 1 (fc1: 9 pieces per lane)
     for (int i0 = lane; i0 < I4; i0 += 256) {
@@ -61,11 +71,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < LIN_BT; ++t) {
       float s = dyb_wave_sum(acc[t]);
-      if (lane == 0 && b0 + t < B) {
-        float v = s + bias[o];
-        if (res) v += res[(size_t)(b0 + t) * ldres + o];
-        y[(size_t)(b0 + t) * ldy + o] = v;
-      }
+      if (lane == 0 && b0 + t < B) y[(size_t)(b0 + t) * ldy + o] = s + addv[t];
     }
   }
 }
