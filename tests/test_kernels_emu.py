@@ -73,6 +73,48 @@ def test_layer_gnstats(be, cfg):
     assert r["nA"] > 0 and r["nB"] > 0
 
 
+def _random_conv_cfgs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        R = int(rng.choice([1, 3]))
+        st = int(rng.choice([1, 2]))
+        pad = 1 if R == 3 else 0
+        H, W = int(rng.integers(3, 12)), int(rng.integers(3, 12))
+        if (H + 2 * pad - R) // st + 1 < 1 or (W + 2 * pad - R) // st + 1 < 1:
+            continue
+        out.append((int(rng.integers(1, 4)), H, W, int(rng.choice([16, 32, 64, 128])), int(rng.choice([16, 32, 64, 128])), R, st, pad))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_conv_cfgs(8, 123))
+def test_conv_random_shapes(be, cfg):
+    """Seeded random geometry (non-square maps, batch 1-3, ragged tiles in every dimension, K tails): the three plain
+    gather flavours and the GroupNorm-fused gradients against torch autograd."""
+    N, H, W, C, Kc, R, st, pad = cfg
+    K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg))
+    K.case_conv_gn_bwd_fused(be, N, H, W, C, Kc, R, st, pad, relu=1, seed=sum(cfg) + 1)
+
+
+def test_conv_is_linear_in_both_operands(be):
+    """Size-independent property: conv(a*x1 + x2, w) == a*conv(x1, w) + conv(x2, w), same in w (split-K included)."""
+    rng = np.random.default_rng(9)
+    N, H, W, C, Kc, R, st, pad = 1, 9, 7, 64, 64, 3, 1, 1
+    x1, x2 = (rng.standard_normal((N, H, W, C)).astype(np.float32) for _ in range(2))
+    w1, w2 = ((rng.standard_normal((R, R, C, Kc)) / 24).astype(np.float32) for _ in range(2))
+    wsb = max(be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, Kc, R, R, st, pad), 16)
+    ws = be.empty((wsb // 4,))
+
+    def conv(x, w):
+        y = be.empty((N, H, W, Kc))
+        K.check(be.lib.dyb_conv2d_nhwc_fwd(be.ptr(be.dev(x)), be.ptr(be.dev(w)), be.ptr(y), N, H, W, C, Kc, R, R, st, pad,
+                                           be.ptr(ws), wsb, be.stream), "conv")
+        return be.host(y).copy()
+    a = 1.75
+    assert K.rel_err(conv(a * x1 + x2, w1), a * conv(x1, w1) + conv(x2, w1)) < 2e-6
+    assert K.rel_err(conv(x1, a * w1 + w2), a * conv(x1, w1) + conv(x1, w2)) < 2e-6
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)
