@@ -64,7 +64,12 @@ int dyb_gn_fwd_chunks(int N, int HW);
 // split-K slabs in `ws` (addend NOT applied then) for the next GroupNorm-backward reduce to fold
 struct GnBwdSrc {
   const float *dm, *y, *stats, *part, *gamma;
+  int nch, ncolb;          // partial-block layout; 0 = the one dyb_groupnorm_bwd_reduce uses
 };
+bool dyb_conv_dgrad_k4_ok(const ConvDesc& d);
+int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, const float* addend, const float* y_p,
+                      const float* out_p, const float* stats_p, const float* gamma_p, const float* beta_p, float* dm_p,
+                      float* part_p, int* nch, int* ncolb, hipStream_t st, hipEvent_t done);
 int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w, float* dx, const float* addend, void* ws,
                           size_t ws_bytes, int* nslabs, hipStream_t st);
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);

@@ -27,9 +27,9 @@ int dyb_conv2d_nhwc_fwd_gnstats(const float*, const float*, int, const float*, c
                                 float*, int*, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 int dyb_groupnorm_apply_n(const float*, const float*, int, const float*, const float*, const float*, const float*, int,
                           const float*, const float*, float*, float*, float*, int, int, int, int, hipStream_t);
-int dyb_conv2d_nhwc_wgrad_gn_gnin(const float*, const float*, const float*, const float*, int, const float*, const float*,
-                                  const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int,
-                                  int, int, int, int, void*, size_t, hipStream_t);
+int dyb_conv2d_nhwc_wgrad_gn_n(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                               const float*, const float*, int, int, const float*, float*, float*, float*, int, int, int, int,
+                               int, int, int, int, int, void*, size_t, hipStream_t);
 size_t dyb_groupnorm_bwd_partial_floats(int, int, int);
 int dyb_groupnorm_bwd_reduce(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int,
                              int, int, hipStream_t);
@@ -515,18 +515,23 @@ struct WgradJob {
   const float* conv_in;
   const ConvL* in_prev;
   const float* dm;
+  int nch, ncolb;              // layout of the layer's partial block (0 = gn_bwd_reduce's)
+};
+// per-call bookkeeping of the backward chain: which layers' partial blocks have a non-default layout (written by a K4
+// data-gradient epilogue) and which layers' reduce has already happened there
+struct BwdState {
+  std::vector<int> nch, ncolb;
+  std::vector<char> reduced;
 };
 static int run_wgrad(HmrPlan& P, const WgradJob& j, const float* params, const float* acts, float* grads, const WsCarve& w,
                      void* slabs, hipStream_t st) {
   const ConvL& c = P.convs[j.ci];
   const float* part = w.gnb + c.gnb;
-  if (j.in_prev)     // the conv's input was relu(gn(y_prev)), never materialised
-    return dyb_conv2d_nhwc_wgrad_gn_gnin(acts + j.in_prev->y, acts + j.in_prev->stats, params + j.in_prev->gam,
-                                         params + j.in_prev->bet, 1, j.dm, acts + c.y, acts + c.stats, part, params + c.gam,
-                                         grads + c.w, grads + c.gam, grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride,
-                                         c.pad, slabs, P.ws_conv, st);
-  return dyb_conv2d_nhwc_wgrad_gn(j.conv_in, j.dm, acts + c.y, acts + c.stats, part, params + c.gam, grads + c.w, grads + c.gam,
-                                  grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, st);
+  const ConvL* ip = j.in_prev;       // non-null: the conv's input was relu(gn(y_prev)), never materialised
+  return dyb_conv2d_nhwc_wgrad_gn_n(ip ? nullptr : j.conv_in, ip ? acts + ip->y : nullptr, ip ? acts + ip->stats : nullptr,
+                                    ip ? params + ip->gam : nullptr, ip ? params + ip->bet : nullptr, j.dm, acts + c.y,
+                                    acts + c.stats, part, j.nch, j.ncolb, params + c.gam, grads + c.w, grads + c.gam,
+                                    grads + c.bet, P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, slabs, P.ws_conv, st);
 }
 // `jobs`: weight gradients whose inputs are ready once the reduce carrying `done` has run; the caller
 // flushes them to the auxiliary stream once per bottleneck (one cross-stream edge per block instead of
@@ -541,7 +546,7 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
                               acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st, done));
-  WgradJob j{ci, conv_in, in_prev, dm};
+  WgradJob j{ci, conv_in, in_prev, dm, 0, 0};
   if (jobs) jobs->push_back(j);
   else RUN(run_wgrad(P, j, params, acts, grads, w, w.conv, st));
   *dm_out = dm;
@@ -557,10 +562,10 @@ static int flush_wgrads(HmrPlan& P, std::vector<WgradJob>& jobs, hipEvent_t done
 // data gradient of layer ci from its dm: conv_transpose(dy, w) (+ addend), materialised in dx_buf or -
 // when `out` is given and the policy splits K - left as slabs (+ the addend) for the next reduce
 static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* acts, const float* dm, float* dx_buf,
-                       const float* addend, Pending* out, const WsCarve& w, hipStream_t st) {
+                       const float* addend, Pending* out, const WsCarve& w, hipStream_t st, const BwdState& bs) {
   const ConvL& c = P.convs[ci];
   ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
-  GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam};
+  GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, bs.nch[ci], bs.ncolb[ci]};
   int ns = 1;
   RUN(dyb_conv_dgrad_gn_raw(d, src, params + c.w, dx_buf, addend, w.conv, P.ws_conv, (out && P.fold_in_reduce) ? &ns : nullptr,
                             st));
@@ -568,6 +573,25 @@ static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* act
     if (ns > 1) *out = Pending{reinterpret_cast<const float*>(w.conv), ns, (size_t)P.B * c.H * c.W * c.C, addend};
     else *out = plain(dx_buf);
   }
+  return DYB_OK;
+}
+
+// K4 data gradient of the 1x1 layer ci whose epilogue performs the GroupNorm-backward reduce of the producer layer pi
+// (the layer whose normalised output is ci's input): dm_pi + partial block of pi come out, no dx buffer exists.
+// Returns false in *done when the shape does not qualify (caller takes the two-launch route).
+static int layer_dgrad_k4(HmrPlan& P, int ci, int pi, const float* params, const float* acts, const float* dm, const float* addend,
+                          const WsCarve& w, hipStream_t st, BwdState& bs, const float** dm_p, bool* done) {
+  const ConvL &c = P.convs[ci], &p = P.convs[pi];
+  ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
+  *done = false;
+  if (!dyb_conv_dgrad_k4_ok(d)) return DYB_OK;
+  GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, bs.nch[ci], bs.ncolb[ci]};
+  int nch = 0, ncolb = 0;
+  RUN(dyb_conv_dgrad_k4(d, src, params + c.w, addend, acts + p.y, p.has_out ? acts + p.out : nullptr, acts + p.stats,
+                        params + p.gam, params + p.bet, w.dy + p.dy, w.gnb + p.gnb, &nch, &ncolb, st, nullptr));
+  bs.nch[pi] = nch; bs.ncolb[pi] = ncolb; bs.reduced[pi] = 1;
+  *dm_p = w.dy + p.dy;
+  *done = true;
   return DYB_OK;
 }
 
@@ -639,33 +663,60 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   float* free_buf = D1;          // the D buffer `cur` does not occupy (a pending `cur` lives in the slab region)
   std::vector<WgradJob> jobs_store;
   std::vector<WgradJob>* jobs = aux ? &jobs_store : nullptr;
+  BwdState bs;
+  bs.nch.assign(P.convs.size(), 0); bs.ncolb.assign(P.convs.size(), 0); bs.reduced.assign(P.convs.size(), 0);
+  // weight-gradient job of a layer whose reduce happened inside a K4 data gradient
+  auto push_wgrad = [&](int ci, const float* conv_in, const ConvL* in_prev, const float* dm) -> int {
+    WgradJob j{ci, conv_in, in_prev, dm, bs.nch[ci], bs.ncolb[ci]};
+    if (jobs) { jobs->push_back(j); return DYB_OK; }
+    return run_wgrad(P, j, params, acts, grads, w, w.conv, st);
+  };
   for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2];
     const float* xin = (bi == 0) ? acts + P.a_pool : acts + P.convs[P.blocks[bi - 1].c3].out;
     float* other = (free_buf == D0) ? D1 : D0;
-    const float *dm3, *dm2, *dm1, *dmd;
+    const float *dm3 = nullptr, *dm2 = nullptr, *dm1 = nullptr, *dmd = nullptr;
     Pending p3, p2, pout;
+    bool k4 = false;
     hipEvent_t ev = aux ? P.ev_dy[b.c1] : nullptr;      // rides on the block's last reduce
     // out = relu(gn3(conv3(a2)) + res)
-    RUN(layer_gn_bwd(P, b.c3, params, acts, grads, nullptr, &c2, cur, 1, &dm3, w, st, jobs, nullptr));
-    RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st));
-    RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, jobs, nullptr));
-    RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st));      // `cur` was consumed by the c3 reduce
+    if (bs.reduced[b.c3]) {            // done by the K4 data gradient of the next block's conv1
+      dm3 = w.dy + P.convs[b.c3].dy;
+      RUN(push_wgrad(b.c3, nullptr, &c2, dm3));
+    } else {
+      RUN(layer_gn_bwd(P, b.c3, params, acts, grads, nullptr, &c2, cur, 1, &dm3, w, st, jobs, nullptr));
+    }
+    RUN(layer_dgrad_k4(P, b.c3, b.c2, params, acts, dm3, nullptr, w, st, bs, &dm2, &k4));
+    if (k4) {
+      RUN(push_wgrad(b.c2, nullptr, &c1, dm2));
+    } else {
+      RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st, bs));
+      RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, jobs, nullptr));
+    }
+    RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st, bs));      // `cur` was consumed by the c3 reduce
+    const float* edge = dm3;           // residual-edge gradient of this block
     if (b.cd >= 0) {
       RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, nullptr));
       // shortcut branch: GroupNorm without ReLU on the residual-edge gradient; its data gradient is materialised
       RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, jobs, ev));
       if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
-      RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st));
-      RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, Rb, &pout, w, st));
+      RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st, bs));
+      edge = Rb;
     } else {
       RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, ev));
       if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
-      RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, dm3, &pout, w, st));
     }
-    cur = pout;
-    if (cur.nslabs == 1) free_buf = other;       // cur sits in the old free buffer
+    k4 = false;
+    if (bi > 0) {
+      const float* dmp = nullptr;
+      RUN(layer_dgrad_k4(P, b.c1, P.blocks[bi - 1].c3, params, acts, dm1, edge, w, st, bs, &dmp, &k4));
+    }
+    if (!k4) {
+      RUN(layer_dgrad(P, b.c1, params, acts, dm1, free_buf, edge, &pout, w, st, bs));
+      cur = pout;
+      if (cur.nslabs == 1) free_buf = other;       // cur sits in the old free buffer
+    }
   }
   // ---- stem: maxpool backward needs the gradient materialised -> GN/ReLU -> conv1 (no data gradient for the image)
   const ConvL& stem = P.convs[0];

@@ -270,6 +270,43 @@ __device__ __forceinline__ float4 gnf_apply(float4 y, float4 ga, float4 be, floa
 }
 __device__ __forceinline__ double igemm_shfl_xor_f64(double v, int m) { return __shfl_xor(v, m); }
 
+// (mean, rstd, c1, c2) per (image, group) into s_coef for the GroupNorm-backward loaders: the per-chunk group sums the
+// reduce left behind are folded here (eight loads in flight per lane, clamped + masked).  Ends with a barrier.
+__device__ __forceinline__ void gnb_prologue(const GnBwdFuse& f, int N, int tid, float* s_raw, float* s_coef) {
+  const int nvals = N * DYB_GN_GROUPS * 2;
+  int L = 32;
+  while (L > 1 && L * nvals > 256) L >>= 1;
+  const int per_pass = 256 / L;
+  for (int base = 0; base < nvals; base += per_pass) {
+    const int v = base + tid / L, sub = tid % L;
+    float s = 0.f;
+    if (v < nvals) {
+      const float* gp = f.gpart + (size_t)(v >> 3) * f.kparts * 8 + (v & 7);
+      for (int k0 = sub; k0 < f.kparts; k0 += 8 * L) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j * L;
+          t[j] = gp[(size_t)(k < f.kparts ? k : f.kparts - 1) * 8];        // clamped, masked below (see gnf_prologue)
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (k0 + j * L < f.kparts) ? t[j] : 0.f;
+        s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      }
+    }
+    for (int m = L >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (v < nvals && sub == 0) s_raw[v] = s * f.inv_m;
+  }
+  __syncthreads();
+  for (int i = tid; i < N * DYB_GN_GROUPS; i += 256) {
+    s_coef[i * 4 + 0] = f.stats[i * 2];
+    s_coef[i * 4 + 1] = f.stats[i * 2 + 1];
+    s_coef[i * 4 + 2] = s_raw[i * 2];
+    s_coef[i * 4 + 3] = s_raw[i * 2 + 1];
+  }
+  __syncthreads();
+}
+
 // (mean, rstd) of the producer per (image, group) into s_nrm, from its per-chunk partials (folded in double, eight
 // loads in flight per lane: this sits on the consumer's critical path) or from the saved statistics; `first`
 // workgroup also saves them for backward.  Ends with a barrier.
@@ -478,43 +515,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 #pragma unroll
     for (int h = 0; h < NH; ++h) load_b(kt_begin, h, rb[h]);
   }
-  if constexpr (GB) {
-    // fold the per-chunk group sums into (c1, c2) for every image: 8 values per image, L lanes each
-    const int nvals = g.N * DYB_GN_GROUPS * 2;
-    int L = 32;
-    while (L > 1 && L * nvals > 256) L >>= 1;
-    const int per_pass = 256 / L;
-    for (int base = 0; base < nvals; base += per_pass) {
-      const int v = base + tid / L, sub = tid % L;
-      float s = 0.f;
-      if (v < nvals) {
-        // the fold sits on the kernel's critical path: eight independent loads in flight per lane,
-        // not a dependent chain (up to 8*L = 256 partials per value in one round trip at batch 1)
-        const float* gp = f.gpart + (size_t)(v >> 3) * f.kparts * 8 + (v & 7);
-        for (int k0 = sub; k0 < f.kparts; k0 += 8 * L) {
-          float t[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j * L;
-            t[j] = gp[(size_t)(k < f.kparts ? k : f.kparts - 1) * 8];        // clamped, masked below (see gnf_prologue)
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) t[j] = (k0 + j * L < f.kparts) ? t[j] : 0.f;
-          s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-        }
-      }
-      for (int m = L >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-      if (v < nvals && sub == 0) s_raw[v] = s * f.inv_m;
-    }
-    __syncthreads();
-    for (int i = tid; i < g.N * DYB_GN_GROUPS; i += 256) {
-      s_coef[i * 4 + 0] = f.stats[i * 2];
-      s_coef[i * 4 + 1] = f.stats[i * 2 + 1];
-      s_coef[i * 4 + 2] = s_raw[i * 2];
-      s_coef[i * 4 + 3] = s_raw[i * 2 + 1];
-    }
-    __syncthreads();
-  }
+  if constexpr (GB) gnb_prologue(f, g.N, tid, s_raw, s_coef);
 
   if constexpr (FA) gnf_prologue(nf, g.N, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, s_rawd, s_nrm);
 
@@ -767,6 +768,163 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
   }
 }
 
+// ---- 1x1 data gradient with the NEXT GroupNorm-backward reduce in its epilogue ("K4 dgrad") --------------
+// Mirror image of the K4 forward kernel on the backward chain (reduce -> dgrad per layer): for a small 1x1 conv L the
+// four waves split the K (= Cout) range of one 32-pixel x 32-channel dx tile, dy being formed on the fly from (dm, y)
+// of L as in the tiled kernel.  The finished tile IS the gradient of the producer P's GroupNorm output (P = the layer
+// whose normalised output feeds L), so the epilogue does P's reduce right there: add the residual-edge gradient, apply
+// P's ReLU mask (from the stored activation, or recomputed from y_P where it was never stored), write dm_P, and leave
+// this tile's per-channel (sum dm, sum dm*xhat) and per-group gamma-weighted sums as one row chunk / column block of
+// P's partial block.  P's own gn_bwd_reduce launch disappears from the chain.
+struct K4DgradArgs {
+  // conv L
+  const float* dm;        // [M][K]   masked GroupNorm-output gradient of L
+  const float* w;         // [C][K]
+  const float* addend;    // [M][C] or NULL: residual-edge gradient added to dx
+  // producer P (GroupNorm over [M][C])
+  const float* y_p;       // [M][C] raw conv output of P
+  const float* out_p;     // [M][C] stored activation (mask source) or NULL: recompute from y_p
+  const float* stats_p;   // [G][2]
+  const float* gamma_p;
+  const float* beta_p;
+  float* dm_p;            // [M][C]
+  float* partials_p;      // [mtiles][2][C]
+  float* gpart_p;         // [mtiles*ntiles][G][2]
+  int M, C, K;
+};
+__global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBwdFuse f) {
+  __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
+  __shared__ float s_coef[DYB_GN_GROUPS * 4], s_raw[DYB_GN_GROUPS * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int ktiles = g.K / K4_BK;
+  const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
+  const int m = (m0 + a_row < g.M) ? m0 + a_row : g.M - 1;              // ragged last tile re-reads the last pixel
+  const float* dmrow = g.dm + (size_t)m * g.K;
+  const float* yrow = f.y + (size_t)m * g.K;
+  const float* wrow = g.w + (size_t)(n0 + a_row) * g.K;                  // B piece: channel n0 + a_row, 4 consecutive k
+  const int logKg = dyb_ilog2_dev(g.K) - 2;
+
+  auto load_a = [&](int kt, int h, Frag& o) {
+    const int k = kt * K4_BK + 32 * h + a_kq;
+    o.d = *reinterpret_cast<const float4*>(dmrow + k);
+    o.v = *reinterpret_cast<const float4*>(yrow + k);
+    o.ga = *reinterpret_cast<const float4*>(f.gamma + k);
+  };
+  auto load_b = [&](int kt, int h, Frag& o) { o.d = *reinterpret_cast<const float4*>(wrow + kt * K4_BK + 32 * h + a_kq); };
+  auto store = [&](int buf, int kt, int h, const Frag& a, const Frag& b) {
+    const int k = kt * K4_BK + 32 * h + a_kq;
+    Frag t = a;
+    t.ok = true;
+    const float4 v = gnb_apply(t, &s_coef[(k >> logKg) * 4]);
+    As[buf][32 * h + a_kq + 0][a_row] = v.x;
+    As[buf][32 * h + a_kq + 1][a_row] = v.y;
+    As[buf][32 * h + a_kq + 2][a_row] = v.z;
+    As[buf][32 * h + a_kq + 3][a_row] = v.w;
+    Bs[buf][32 * h + a_kq + 0][a_row] = b.d.x;
+    Bs[buf][32 * h + a_kq + 1][a_row] = b.d.y;
+    Bs[buf][32 * h + a_kq + 2][a_row] = b.d.z;
+    Bs[buf][32 * h + a_kq + 3][a_row] = b.d.w;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  Frag ra[4], rb[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { load_a(0, h, ra[h]); load_b(0, h, rb[h]); }
+  // epilogue operands that do not depend on the matrix product go out now as well
+  const int e_row = tid >> 3, e_cq = (tid & 7) * 4;
+  const bool e_ok = m0 + e_row < g.M;
+  const size_t e_off = (size_t)(e_ok ? m0 + e_row : g.M - 1) * g.C + n0 + e_cq;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 e_y = *reinterpret_cast<const float4*>(g.y_p + e_off);
+  const float4 e_add = g.addend ? *reinterpret_cast<const float4*>(g.addend + e_off) : zero4;
+  const float4 e_out = g.out_p ? *reinterpret_cast<const float4*>(g.out_p + e_off) : zero4;
+  const float4 e_ga = *reinterpret_cast<const float4*>(g.gamma_p + n0 + e_cq);
+  const float4 e_be = *reinterpret_cast<const float4*>(g.beta_p + n0 + e_cq);
+  const int grp_p = n0 / (g.C / DYB_GN_GROUPS);
+  const float mean_p = g.stats_p[grp_p * 2], rstd_p = g.stats_p[grp_p * 2 + 1];
+  gnb_prologue(f, 1, tid, s_raw, s_coef);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) store(0, 0, h, ra[h], rb[h]);
+  __syncthreads();
+  const int khalf = lane >> 5, l31 = lane & 31;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    if (more) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) { load_a(kt + 1, h, ra[h]); load_b(kt + 1, h, rb[h]); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k2 = 0; k2 < 32; k2 += 2) {
+      float a = As[buf][32 * wave + k2 + khalf][l31];
+      float b = Bs[buf][32 * wave + k2 + khalf][l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) store(buf ^ 1, kt + 1, h, ra[h], rb[h]);
+    }
+    __syncthreads();
+  }
+  // ---- four partial accumulators -> dx tile fin[32][33]
+  float* red = &As[0][0][0];
+  float* fin = &Bs[0][0][0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = tid + 256 * j, r = s >> 6, ln = s & 63;
+    const float v = (red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln]) + (red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln]);
+    fin[((r & 3) + 8 * (r >> 2) + 4 * (ln >> 5)) * 33 + (ln & 31)] = v;
+  }
+  __syncthreads();
+  // ---- GroupNorm-backward reduce of the producer on this tile
+  float dmv[4], xh[4];
+  {
+    const float yv[4] = {e_y.x, e_y.y, e_y.z, e_y.w}, av[4] = {e_add.x, e_add.y, e_add.z, e_add.w};
+    const float ov[4] = {e_out.x, e_out.y, e_out.z, e_out.w}, gv[4] = {e_ga.x, e_ga.y, e_ga.z, e_ga.w};
+    const float bv[4] = {e_be.x, e_be.y, e_be.z, e_be.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = (yv[j] - mean_p) * rstd_p;
+      const float act = g.out_p ? ov[j] : fmaf(xh[j], gv[j], bv[j]);          // the consumer's expression when not stored
+      const float d = fin[e_row * 33 + e_cq + j] + av[j];
+      dmv[j] = (e_ok && act > 0.f) ? d : 0.f;
+    }
+    if (e_ok) *reinterpret_cast<float4*>(g.dm_p + e_off) = make_float4(dmv[0], dmv[1], dmv[2], dmv[3]);
+  }
+  __syncthreads();                                   // fin consumed: reuse the B stage for the column sums
+  float* sa = fin;                                   // [32 rows][33] A contributions, then [32][33] B contributions
+  float* sb = fin + 32 * 33;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sa[e_row * 33 + e_cq + j] = dmv[j];
+    sb[e_row * 33 + e_cq + j] = dmv[j] * xh[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int c = tid & 31, which = tid >> 5;
+    const float* src = which ? sb : sa;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += src[r * 33 + c];
+    g.partials_p[((size_t)blockIdx.x * 2 + which) * g.C + n0 + c] = t;          // [mtile][2][C]
+    // per-group gamma-weighted sums of this column block (its 32 channels lie in one group)
+    float wsum = t * g.gamma_p[n0 + c];
+    wsum += __shfl_xor(wsum, 16); wsum += __shfl_xor(wsum, 8); wsum += __shfl_xor(wsum, 4);
+    wsum += __shfl_xor(wsum, 2); wsum += __shfl_xor(wsum, 1);
+    if (c < DYB_GN_GROUPS)
+      g.gpart_p[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * DYB_GN_GROUPS + c) * 2 + which] = (c == grp_p) ? wsum : 0.f;
+  }
+}
+
 // out[i] = sum_z slab[z][i] (+ addend[i]);  n4 = element count / 4
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ slabs, const float4* __restrict__ addend,
                                                              float4* __restrict__ out, int nsplit, size_t n4) {
@@ -1010,13 +1168,14 @@ extern "C" int dyb_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
 // ---- data / weight gradient with the GroupNorm backward of the conv's output formed in the loader ----
 // dm: masked gradient of the GroupNorm output, y_gn/stats: saved conv output and (mean, rstd), part: the
 // partial-sum block dyb_groupnorm_bwd_reduce wrote for this layer (N images, Ho*Wo pixels, K channels).
+// nch / ncolb: row-chunk and column-block counts of the partial block (0: the layout dyb_groupnorm_bwd_reduce uses;
+// a producer that wrote the partials from a conv epilogue passes its tile counts)
 static int make_fuse(GnBwdFuse& f, const ConvDesc& d, const float* y_gn, const float* stats, const float* part,
-                     const float* gamma, float* dgamma, float* dbeta) {
+                     const float* gamma, float* dgamma, float* dbeta, int nch = 0, int ncolb = 0) {
   DYB_REQUIRE(y_gn && stats && part && gamma, DYB_ERR_ARG);
   DYB_REQUIRE(d.K % 16 == 0, DYB_ERR_UNSUPPORTED);
   int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
-  int nch = 0, ncolb = 0;
-  dyb_gn_bwd_layout(d.N, Ho * Wo, d.K, &nch, &ncolb);
+  if (nch <= 0 || ncolb <= 0) dyb_gn_bwd_layout(d.N, Ho * Wo, d.K, &nch, &ncolb);
   f.y = y_gn; f.stats = stats; f.gamma = gamma;
   f.partials = part;
   f.gpart = part + (size_t)d.N * nch * 2 * d.K;
@@ -1046,10 +1205,37 @@ extern "C" int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const f
   if (rc != DYB_OK) return rc;
   return run_igemm(MODE_WGRAD, d, x, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f);
 }
+bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
+  const char* e = getenv("DYB_K4_BWD");                 // read per call: tests toggle it; off by default (unmeasured)
+  const int enabled = e ? atoi(e) : 0;
+  static const int max_k = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
+  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
+         d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
+}
+// dx of the 1x1 conv `d` (never materialised as such) -> dm / partials of the producer's GroupNorm; *nch, *ncolb = the
+// partial block's row-chunk / column-block counts (tile counts) for the producer's own fused gradients.
+int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, const float* addend, const float* y_p,
+                      const float* out_p, const float* stats_p, const float* gamma_p, const float* beta_p, float* dm_p,
+                      float* part_p, int* nch, int* ncolb, hipStream_t st, hipEvent_t done) {
+  DYB_REQUIRE(dyb_conv_dgrad_k4_ok(d) && w && y_p && stats_p && gamma_p && beta_p && dm_p && part_p && nch && ncolb,
+              DYB_ERR_UNSUPPORTED);
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr, src.nch, src.ncolb);
+  if (rc != DYB_OK) return rc;
+  const int M = d.H * d.W;
+  dim3 grid(dyb_cdiv(M, 32), d.C / 32);
+  K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K};
+  if (done) hipExtLaunchKernelGGL(igemm_k4_dgrad_kernel, grid, dim3(256), 0, st, nullptr, done, 0, g, f);
+  else hipLaunchKernelGGL(igemm_k4_dgrad_kernel, grid, dim3(256), 0, st, g, f);
+  DYB_CHECK_LAUNCH();
+  *nch = (int)grid.x;
+  *ncolb = (int)grid.y;
+  return DYB_OK;
+}
 int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w, float* dx, const float* addend, void* ws,
                           size_t ws_bytes, int* nslabs, hipStream_t st) {
   GnBwdFuse f{};
-  int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr);
+  int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr, src.nch, src.ncolb);
   if (rc != DYB_OK) return rc;
   return run_igemm(MODE_DGRAD, d, src.dm, w, dx, addend, ws, ws_bytes, nslabs, st, &f);
 }
@@ -1162,5 +1348,54 @@ extern "C" int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* s
   if (rc != DYB_OK) return rc;
   GnFwdFuse nf{};
   make_nfuse(nf, d, nullptr, stats_prev, gamma_prev, beta_prev, nullptr, relu_prev);
+  return run_igemm(MODE_WGRAD, d, y_prev, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f, &nf);
+}
+
+// Data gradient of conv (N,H,W,C,K,...) fused with the GroupNorm-backward reduce of the PRODUCER of its input (the
+// layer whose normalised output feeds this conv; its GroupNorm is over [N][H*W][C]): dm_p / part_p come out, dx itself
+// is scratch.  Small 1x1 layers at batch 1 with DYB_K4_BWD=1 run as one launch (K4 dgrad); otherwise this is
+// dyb_conv2d_nhwc_dgrad_gn into dx_scratch followed by dyb_groupnorm_bwd_reduce.  *nch_p / *ncolb_p: layout of part_p
+// for the producer's own fused gradients (pass them on as nch / ncolb there).
+extern "C" int dyb_groupnorm_bwd_reduce(const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                                        float*, int, int, int, int, hipStream_t);
+extern "C" int dyb_conv2d_nhwc_dgrad_gn_reduce(const float* dm, const float* y_gn, const float* stats, const float* part, int nch,
+                                               int ncolb, const float* gamma, const float* w, const float* addend,
+                                               const float* y_p, const float* out_p, const float* stats_p,
+                                               const float* gamma_p, const float* beta_p, float* dm_p, float* part_p,
+                                               int* nch_p, int* ncolb_p, float* dx_scratch, int N, int H, int W, int C, int K,
+                                               int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(nch_p && ncolb_p && dm_p && part_p && y_p && stats_p && gamma_p && beta_p, DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdSrc src{dm, y_gn, stats, part, gamma, nch, ncolb};
+  if (dyb_conv_dgrad_k4_ok(d))
+    return dyb_conv_dgrad_k4(d, src, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, nch_p, ncolb_p, st, nullptr);
+  DYB_REQUIRE(dx_scratch, DYB_ERR_ARG);
+  int rc = dyb_conv_dgrad_gn_raw(d, src, w, dx_scratch, addend, ws, ws_bytes, nullptr, st);
+  if (rc != DYB_OK) return rc;
+  dyb_gn_bwd_layout(N, H * W, C, nch_p, ncolb_p);
+  return dyb_groupnorm_bwd_reduce(dx_scratch, out_p, y_p, stats_p, gamma_p, beta_p, dm_p, part_p, N, H * W, C, 1, st);
+}
+// the fused gradients with an explicit partial-block layout (what a K4 dgrad producer hands on)
+extern "C" int dyb_conv2d_nhwc_dgrad_gn_n(const float* dm, const float* y_gn, const float* stats, const float* part, int nch,
+                                          int ncolb, const float* gamma, const float* w, float* dx, const float* addend, int N,
+                                          int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                                          size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdSrc src{dm, y_gn, stats, part, gamma, nch, ncolb};
+  return dyb_conv_dgrad_gn_raw(d, src, w, dx, addend, ws, ws_bytes, nullptr, st);
+}
+extern "C" int dyb_conv2d_nhwc_wgrad_gn_n(const float* x, const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                                          const float* beta_prev, const float* dm, const float* y_gn, const float* stats,
+                                          const float* part, int nch, int ncolb, const float* gamma, float* dw, float* dgamma,
+                                          float* dbeta, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                          void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(dgamma && dbeta && (x || (y_prev && stats_prev && gamma_prev && beta_prev)), DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  GnBwdFuse f{};
+  int rc = make_fuse(f, d, y_gn, stats, part, gamma, dgamma, dbeta, nch, ncolb);
+  if (rc != DYB_OK) return rc;
+  if (!y_prev) return run_igemm(MODE_WGRAD, d, x, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f);
+  GnFwdFuse nf{};
+  make_nfuse(nf, d, nullptr, stats_prev, gamma_prev, beta_prev, nullptr, 1);
   return run_igemm(MODE_WGRAD, d, y_prev, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f, &nf);
 }

@@ -121,6 +121,28 @@ int dyb_groupnorm_apply_n(const float* y, const float* partials, int nch, const 
                           const float* res_beta, float* res_stats, float* out, float* stats, int N, int HW, int C, int relu,
                           dyb_stream_t stream);
 
+/* Backward mirror of dyb_conv2d_nhwc_fwd_gnstats: the data gradient of a conv fused with the GroupNorm-backward reduce
+ * of the PRODUCER of its input (GroupNorm over [N][H*W][C]): dm_p and the partial block part_p
+ * (dyb_groupnorm_bwd_partial_floats(N, H*W, C) floats) come out, *nch_p / *ncolb_p give part_p's layout; dx itself only
+ * exists in dx_scratch (or not at all).  With DYB_K4_BWD=1 small 1x1 layers at batch 1 are ONE launch; otherwise it is
+ * dyb_conv2d_nhwc_dgrad_gn + dyb_groupnorm_bwd_reduce.  (nch, ncolb) describe `part` of THIS conv's GroupNorm (0, 0 = the
+ * dyb_groupnorm_bwd_reduce layout).  The _n gradients take such an explicit layout; in dyb_conv2d_nhwc_wgrad_gn_n the
+ * conv input is x, or - x == NULL - relu(gn(y_prev)) formed in the loader. */
+int dyb_conv2d_nhwc_dgrad_gn_reduce(const float* dm, const float* y_gn, const float* stats, const float* part, int nch,
+                                    int ncolb, const float* gamma, const float* w, const float* addend, const float* y_p,
+                                    const float* out_p, const float* stats_p, const float* gamma_p, const float* beta_p,
+                                    float* dm_p, float* part_p, int* nch_p, int* ncolb_p, float* dx_scratch, int N, int H,
+                                    int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
+                                    dyb_stream_t stream);
+int dyb_conv2d_nhwc_dgrad_gn_n(const float* dm, const float* y_gn, const float* stats, const float* part, int nch, int ncolb,
+                               const float* gamma, const float* w, float* dx, const float* addend, int N, int H, int W, int C,
+                               int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+int dyb_conv2d_nhwc_wgrad_gn_n(const float* x, const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                               const float* beta_prev, const float* dm, const float* y_gn, const float* stats,
+                               const float* part, int nch, int ncolb, const float* gamma, float* dw, float* dgamma,
+                               float* dbeta, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                               size_t ws_bytes, dyb_stream_t stream);
+
 /* ---- pooling / layout: nn.MaxPool2d(3,2,1), nn.AvgPool2d(7) (reference model/hmr.py:73,78,142,155)
  * and the NCHW(3) -> NHWC(4) repack of the dataloader image (boa_dataset/pw3d.py:115). */
 int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, dyb_stream_t stream);

@@ -725,3 +725,89 @@ def case_layer_gnstats(be, N, H, W, C, Ka, Ra, sa, Kb, Rb, sb, seed=51):
              mean_a=float(np.abs(be.host(SA)[:, :, 0] - mean_a).max()))
     assert max(e.values()) < 5e-4, e
     return dict(e, nA=nA.value, nB=nB.value)
+
+
+# ------------------------------------------------------------------- data gradient + producer's reduce (K4 backward)
+def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61):
+    """Two chained layers P -> L at batch 1:  a = relu(GN_P(y_p)) [+ residual];  y = conv1x1_L(a);  out = relu(GN_L(y)).
+    Given d(out), dyb_conv2d_nhwc_dgrad_gn_reduce must produce P's masked gradient dm_p and a partial block from which P's
+    own fused gradients come out right: checked through the folded per-channel sums (= dbeta_P / dgamma_P) and through
+    the data gradient of a 1x1 conv placed in front of P.  Runs with DYB_K4_BWD=1 (one launch) and =0 (two launches)."""
+    import os
+    rng = _rng(seed)
+    N, M = 1, H * W
+    y_p = (rng.standard_normal((N, M, C)) * 1.2).astype(np.float32)
+    gp, bp = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+    res = rng.standard_normal((N, M, C)).astype(np.float32)           # residual operand of P's activation (bn3 flavour)
+    wl = (rng.standard_normal((1, 1, C, Kc)) / np.sqrt(C)).astype(np.float32)
+    gl, bl = (1 + 0.2 * rng.standard_normal(Kc)).astype(np.float32), (0.2 * rng.standard_normal(Kc)).astype(np.float32)
+    dout = rng.standard_normal((N, M, Kc)).astype(np.float32)
+    add = rng.standard_normal((N, M, C)).astype(np.float32) if with_addend else None
+    # ---- torch reference
+    T = lambda a: torch.from_numpy(a)
+    ypt = T(y_p).permute(0, 2, 1).reshape(N, C, H, W).requires_grad_(True)
+    gpt, bpt = T(gp).requires_grad_(True), T(bp).requires_grad_(True)
+    pre = F.group_norm(ypt, 4, gpt, bpt, 1e-5)
+    if not mask_from_y:
+        pre = pre + T(res).permute(0, 2, 1).reshape(N, C, H, W)
+    a = F.relu(pre)
+    yl = F.conv2d(a, T(wl).permute(3, 2, 0, 1))
+    ol = F.relu(F.group_norm(yl, 4, T(gl), T(bl), 1e-5))
+    extra = (a * T(add).permute(0, 2, 1).reshape(N, C, H, W)).sum() if with_addend else 0.0     # a second consumer of `a`
+    loss = (ol * T(dout).permute(0, 2, 1).reshape(N, Kc, H, W)).sum() + extra
+    gy, gg, gb = torch.autograd.grad(loss, [ypt, gpt, bpt])
+    dyp_ref = gy.reshape(N, C, M).permute(0, 2, 1).numpy()
+    L = be.lib
+    res_out = {}
+    for mode in (1, 0):
+        os.environ["DYB_K4_BWD"] = str(mode)
+        try:
+            shL = (N, H, W, C, Kc, 1, 1, 1, 0)
+            wsb = max(L.dyb_conv2d_workspace_bytes(*shL), 16)
+            ws = be.empty((wsb // 4,))
+            gws = be.empty((max(L.dyb_groupnorm_workspace_bytes(N, M, C), L.dyb_groupnorm_workspace_bytes(N, M, Kc)) // 4,))
+            gwsb = gws.numel() * 4 if hasattr(gws, "numel") else gws.size * 4
+            YP, GP, BP = be.dev(y_p), be.dev(gp), be.dev(bp)
+            OUTP, SP = be.empty((N, M, C)), be.empty((N, 4, 2))
+            check(L.dyb_groupnorm_fwd(None, 1, be.ptr(YP), be.ptr(GP), be.ptr(BP), None if mask_from_y else be.ptr(be.dev(res)),
+                                      be.ptr(OUTP), be.ptr(SP), N, M, C, 1, be.ptr(gws), gwsb, be.stream), "gn P")
+            WL, GL, BL = be.dev(wl), be.dev(gl), be.dev(bl)
+            YL, OUTL, SL = be.empty((N, M, Kc)), be.empty((N, M, Kc)), be.empty((N, 4, 2))
+            check(L.dyb_conv2d_nhwc_fwd(be.ptr(OUTP), be.ptr(WL), be.ptr(YL), *shL, be.ptr(ws), wsb, be.stream), "conv L")
+            check(L.dyb_groupnorm_fwd(None, 1, be.ptr(YL), be.ptr(GL), be.ptr(BL), None, be.ptr(OUTL), be.ptr(SL), N, M, Kc, 1,
+                                      be.ptr(gws), gwsb, be.stream), "gn L")
+            partL = be.empty((L.dyb_groupnorm_bwd_partial_floats(N, M, Kc),))
+            DML = be.empty((N, M, Kc))
+            check(L.dyb_groupnorm_bwd_reduce(be.ptr(be.dev(dout)), be.ptr(OUTL), be.ptr(YL), be.ptr(SL), be.ptr(GL), be.ptr(BL),
+                                             be.ptr(DML), be.ptr(partL), N, M, Kc, 1, be.stream), "reduce L")
+            partP = be.empty((L.dyb_groupnorm_bwd_partial_floats(N, M, C) + 64 * C,))
+            DMP, DX = be.empty((N, M, C)), be.empty((N, M, C))
+            nch, ncolb = ctypes.c_int(0), ctypes.c_int(0)
+            check(L.dyb_conv2d_nhwc_dgrad_gn_reduce(be.ptr(DML), be.ptr(YL), be.ptr(SL), be.ptr(partL), 0, 0, be.ptr(GL), be.ptr(WL),
+                                                    be.ptr(be.dev(add)) if with_addend else None, be.ptr(YP),
+                                                    None if mask_from_y else be.ptr(OUTP), be.ptr(SP), be.ptr(GP), be.ptr(BP),
+                                                    be.ptr(DMP), be.ptr(partP), ctypes.byref(nch), ctypes.byref(ncolb), be.ptr(DX),
+                                                    *shL, be.ptr(ws), wsb, be.stream), "dgrad+reduce")
+            # P's gradients from (dm_p, partials): a 1x1 identity-sized conv "in front of" P gives dy_P as its data gradient
+            eye = np.eye(C, dtype=np.float32).reshape(1, 1, C, C)
+            DYP, DWI, DGP, DBP = be.empty((N, M, C)), be.empty((1, 1, C, C)), be.empty((C,)), be.empty((C,))
+            shI = (N, H, W, C, C, 1, 1, 1, 0)
+            wsb2 = max(L.dyb_conv2d_workspace_bytes(*shI), 16)
+            ws2 = be.empty((wsb2 // 4,))
+            check(L.dyb_conv2d_nhwc_dgrad_gn_n(be.ptr(DMP), be.ptr(YP), be.ptr(SP), be.ptr(partP), nch.value, ncolb.value, be.ptr(GP),
+                                               be.ptr(be.dev(eye)), be.ptr(DYP), None, *shI, be.ptr(ws2), wsb2, be.stream), "dgrad P")
+            check(L.dyb_conv2d_nhwc_wgrad_gn_n(be.ptr(YP), None, None, None, None, be.ptr(DMP), be.ptr(YP), be.ptr(SP), be.ptr(partP),
+                                               nch.value, ncolb.value, be.ptr(GP), be.ptr(DWI), be.ptr(DGP), be.ptr(DBP), *shI,
+                                               be.ptr(ws2), wsb2, be.stream), "wgrad P")
+            res_out[mode] = dict(dyp=be.host(DYP).copy(), dg=be.host(DGP).copy(), db=be.host(DBP).copy(), dm=be.host(DMP).copy(),
+                                 layout=(nch.value, ncolb.value))
+        finally:
+            os.environ.pop("DYB_K4_BWD", None)
+    e = {}
+    for mode, r in res_out.items():
+        e[f"dy_p[{mode}]"] = rel_err(r["dyp"], dyp_ref)
+        e[f"dgamma_p[{mode}]"] = rel_err(r["dg"], gg.numpy())
+        e[f"dbeta_p[{mode}]"] = rel_err(r["db"], gb.numpy())
+    e["dm one-vs-two launches"] = rel_err(res_out[1]["dm"], res_out[0]["dm"])
+    assert max(e.values()) < 5e-4, e
+    return dict(e, layouts=(res_out[1]["layout"], res_out[0]["layout"]))

@@ -346,3 +346,35 @@ def test_second_order_full_loss_set_vs_oracle(gmm_t, smpl_tabs):
     # down 50 layers), 1e-5 from layer4 up - against first-vs-second-order gaps of 14-30 %
     assert (e_so < 6e-2).all(), e_so
     assert (e_so < 0.3 * gap + 5e-3).all(), (e_so, gap)
+
+
+def test_k4_backward_path_matches_reference_stream(monkeypatch):
+    """DYB_K4_BWD=1 (data gradients of the small 1x1 layers carry the producer's GroupNorm-backward reduce in their
+    epilogue; off by default) on the 3-inner-step golden stream: same losses / predictions / Adam moments as the
+    reference within the usual tolerances."""
+    monkeypatch.setenv("DYB_K4_BWD", "1")
+    from dynaboa_amd import assets
+    g = golden("g5_fo_inner3_frameonly.npz")
+    opts, ident = STREAMS["fo_inner3_frameonly"]
+    ad, _ = make_adaptor(opts, ident)
+    n = int(g["nframes"])
+    ad.reset_records(n)
+    hmr = ad.model.module
+    for step in range(n):
+        ad.global_step = step
+        ad.fit_losses = {}
+        batch = {k: v.to(ad.device) for k, v in assets.make_frame(step, 1, seed=22).items()}
+        ad.model.eval()
+        ad.adaptation(batch)
+        up = float(ad.fit_losses["ul/total"])
+        assert abs(up - g["upper_loss"][step]) < 1e-4 * abs(g["upper_loss"][step]), (step, up)
+        with torch.no_grad():
+            r, s, c = ad.model(batch["image"])
+        for k, v in dict(rotmat=r, shape=s, cam=c).items():
+            assert rel_err(v.cpu().numpy(), g[f"pred{step}_{k}"]) < 1e-3, (step, k)
+    st = ad.optimizer.state[hmr.theta]
+    L = hmr._layout1
+    m, v = L.unpack(st["exp_avg"]), L.unpack(st["exp_avg_sq"])
+    names = [str(x) for x in g["names"]]
+    np.testing.assert_allclose(np.array([float(m[k].double().norm()) for k in names]), g["m_norms"], rtol=2e-2)
+    np.testing.assert_allclose(np.array([float(v[k].double().norm()) for k in names]), g["v_norms"], rtol=2e-2)

@@ -115,6 +115,17 @@ def test_conv_is_linear_in_both_operands(be):
     assert K.rel_err(conv(x1, a * w1 + w2), a * conv(x1, w1) + conv(x1, w2)) < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [
+    # H, W, C (producer / conv input channels), K (conv output channels), mask_from_y, with_addend
+    (6, 6, 128, 128, True, False),      # conv3-flavour: producer bn2, mask recomputed from y, no residual
+    (5, 7, 256, 128, False, True),      # conv1-flavour: producer bn3 (stored activation + residual), residual-edge addend, ragged 35-pixel map
+    (4, 4, 128, 256, True, True),
+])
+def test_dgrad_gn_reduce(be, cfg):
+    r = K.case_dgrad_gn_reduce(be, *cfg, seed=sum(int(v) for v in cfg))
+    assert r["layouts"][0] != r["layouts"][1]            # the one-launch path really ran (tile-count layout)
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)

@@ -82,6 +82,19 @@ def test_layer_gnstats(be, cfg):
     K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    # H, W, C (producer channels), K (conv output channels), mask_from_y, with_addend
+    (28, 28, 128, 512, True, False),       # layer2 conv3 data gradient + bn2 reduce
+    (28, 28, 512, 128, False, True),       # layer2 conv1 data gradient + previous block's bn3 reduce (+ residual edge)
+    (14, 14, 256, 1024, True, False),      # layer3 conv3 (8 K-steps)
+    (14, 14, 1024, 256, False, True),      # layer3 conv1
+    (7, 7, 2048, 512, False, True),        # layer4 conv1
+])
+def test_dgrad_gn_reduce(be, cfg):
+    r = K.case_dgrad_gn_reduce(be, *cfg, seed=sum(int(v) for v in cfg))
+    assert r["layouts"][0] != r["layouts"][1]
+
+
 def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 784, 512, 4, True)
     K.case_groupnorm_fold(be, 1, 49, 2048, 36, False)
