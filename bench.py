@@ -263,7 +263,7 @@ def main():
                                "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],
                                "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3,
                                "whole_frame_frac": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
         print(json.dumps(out))
     if dist is not None:
