@@ -631,16 +631,23 @@ struct K4Args {
   const float* w;        // [C][K]
   float* y;              // [Ho*Wo][K]
   float* partials;       // [mtiles*ntiles][G][2]
-  int H, W, C, K, stride, Ho, Wo, M;
+  int H, W, C, K, stride, Ho, Wo, M;      // M = Ho*Wo: pixels of ONE image
+  int N, tpi;                             // batch, 32-row tiles per image (MULTI: tiles never straddle images)
 };
-template <bool FA>
+// MULTI (batch > 1, experimental behind DYB_K4_BATCH=1): blockIdx.x = image * tpi + tile; partials are per image.
+template <bool FA, bool MULTI>
 __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse nf) {
   __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
-  __shared__ float s_nrm[FA ? DYB_GN_GROUPS * 2 : 4];
-  __shared__ double s_rawd[FA ? DYB_GN_GROUPS * 2 : 1];
+  __shared__ float s_nrm[FA ? (MULTI ? 64 : 1) * DYB_GN_GROUPS * 2 : 4];
+  __shared__ double s_rawd[FA ? (MULTI ? 64 : 1) * DYB_GN_GROUPS * 2 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int img = MULTI ? blockIdx.x / g.tpi : 0, mtile = MULTI ? blockIdx.x - img * g.tpi : blockIdx.x;
+  if constexpr (MULTI) {
+    g.x += (size_t)img * g.H * g.W * g.C;
+    g.y += (size_t)img * g.M * g.K;
+  }
+  const int m0 = mtile * 32, n0 = blockIdx.y * 32;
   const int ktiles = (g.C + K4_BK - 1) / K4_BK;
   // A pieces: tile row a_row, 4 consecutive k at 32h + a_kq (h = 0..3 -> consumed by wave h); B pieces: k row 32h + b_k, 4 columns
   const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
   auto store = [&](int buf, int kt, int h, const Frag& a, const Frag& b) {
     float4 v = a.d;
     if constexpr (FA) {
-      const float* st = &s_nrm[((kt * K4_BK + 32 * h + a_kq) >> logCg) * 2];
+      const float* st = &s_nrm[(img * DYB_GN_GROUPS + ((kt * K4_BK + 32 * h + a_kq) >> logCg)) * 2];
       v = gnf_apply(a.d, a.v, a.ga, st[0], st[1], nf.relu);
     }
     As[buf][32 * h + a_kq + 0][a_row] = v.x;
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
   for (int h = 0; h < 4; ++h) { ra[h].d = ra[h].v = ra[h].ga = zero4; ra[h].ok = false; rb[h] = ra[h]; }
 #pragma unroll
   for (int h = 0; h < 4; ++h) { load_a(0, h, ra[h]); load_b(0, h, rb[h]); }
-  if constexpr (FA) gnf_prologue(nf, 1, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0, s_rawd, s_nrm);
+  if constexpr (FA) gnf_prologue(nf, MULTI ? g.N : 1, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0, s_rawd, s_nrm);
 #pragma unroll
   for (int h = 0; h < 4; ++h) store(0, 0, h, ra[h], rb[h]);
   __syncthreads();
@@ -762,6 +769,7 @@ __global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse n
       t += __shfl_xor(t, 16); t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
       if (c < DYB_GN_GROUPS) {
         const int grp = n0 / (g.K / DYB_GN_GROUPS);
+        // record index: [image][tile * ntiles + ntile]; blockIdx.x = image * tpi + tile, so the flat form covers both cases
         g.partials[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * DYB_GN_GROUPS + c) * 2 + which] = (c == grp) ? t : 0.f;
       }
     }
@@ -790,14 +798,26 @@ struct K4DgradArgs {
   float* dm_p;            // [M][C]
   float* partials_p;      // [mtiles][2][C]
   float* gpart_p;         // [mtiles*ntiles][G][2]
-  int M, C, K;
+  int M, C, K;            // M = pixels of ONE image
+  int N, tpi;             // batch, 32-row tiles per image
 };
+// MULTI (batch > 1, experimental behind DYB_K4_BATCH=1): blockIdx.x = image * tpi + tile, per-image coefficients / statistics
+template <bool MULTI>
 __global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBwdFuse f) {
   __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
-  __shared__ float s_coef[DYB_GN_GROUPS * 4], s_raw[DYB_GN_GROUPS * 2];
+  __shared__ float s_coef[(MULTI ? 64 : 1) * DYB_GN_GROUPS * 4], s_raw[(MULTI ? 64 : 1) * DYB_GN_GROUPS * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int img = MULTI ? blockIdx.x / g.tpi : 0, mtile = MULTI ? blockIdx.x - img * g.tpi : blockIdx.x;
+  if constexpr (MULTI) {
+    const size_t ok = (size_t)img * g.M * g.K, oc = (size_t)img * g.M * g.C;
+    g.dm += ok; f.y += ok;
+    g.y_p += oc; g.dm_p += oc;
+    if (g.addend) g.addend += oc;
+    if (g.out_p) g.out_p += oc;
+    g.stats_p += img * DYB_GN_GROUPS * 2;
+  }
+  const int m0 = mtile * 32, n0 = blockIdx.y * 32;
   const int ktiles = g.K / K4_BK;
   const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
   const int m = (m0 + a_row < g.M) ? m0 + a_row : g.M - 1;              // ragged last tile re-reads the last pixel
@@ -817,7 +837,7 @@ __global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBw
     const int k = kt * K4_BK + 32 * h + a_kq;
     Frag t = a;
     t.ok = true;
-    const float4 v = gnb_apply(t, &s_coef[(k >> logKg) * 4]);
+    const float4 v = gnb_apply(t, &s_coef[(img * DYB_GN_GROUPS + (k >> logKg)) * 4]);
     As[buf][32 * h + a_kq + 0][a_row] = v.x;
     As[buf][32 * h + a_kq + 1][a_row] = v.y;
     As[buf][32 * h + a_kq + 2][a_row] = v.z;
@@ -846,7 +866,7 @@ __global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBw
   const float4 e_be = *reinterpret_cast<const float4*>(g.beta_p + n0 + e_cq);
   const int grp_p = n0 / (g.C / DYB_GN_GROUPS);
   const float mean_p = g.stats_p[grp_p * 2], rstd_p = g.stats_p[grp_p * 2 + 1];
-  gnb_prologue(f, 1, tid, s_raw, s_coef);
+  gnb_prologue(f, MULTI ? g.N : 1, tid, s_raw, s_coef);
 #pragma unroll
   for (int h = 0; h < 4; ++h) store(0, 0, h, ra[h], rb[h]);
   __syncthreads();
@@ -1209,7 +1229,9 @@ bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
   const char* e = getenv("DYB_K4_BWD");                 // read per call (tests toggle it); on: 1.40 -> 1.31 ms per backward
   const int enabled = e ? atoi(e) : 1;
   static const int max_k = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
-  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
+  const char* eb = getenv("DYB_K4_BATCH");
+  const bool batch_ok = d.N == 1 || (eb && atoi(eb) && d.N <= 64);
+  return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
          d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
 }
 // dx of the 1x1 conv `d` (never materialised as such) -> dm / partials of the producer's GroupNorm; *nch, *ncolb = the
@@ -1222,16 +1244,23 @@ int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, co
   GnBwdFuse f{};
   int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr, src.nch, src.ncolb);
   if (rc != DYB_OK) return rc;
-  const int M = d.H * d.W;
-  dim3 grid(dyb_cdiv(M, 32), d.C / 32);
-  K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K};
+  const int M = d.H * d.W, tpi = dyb_cdiv(M, 32);
+  dim3 grid(d.N * tpi, d.C / 32);
+  K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K,
+                d.N, tpi};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (!done) timing_acquire(d, &ev0, &ev1);           // bench.py's conv timing scope
-  if (done) hipExtLaunchKernelGGL(igemm_k4_dgrad_kernel, grid, dim3(256), 0, st, nullptr, done, 0, g, f);
-  else if (ev0) hipExtLaunchKernelGGL(igemm_k4_dgrad_kernel, grid, dim3(256), 0, st, ev0, ev1, 0, g, f);
-  else hipLaunchKernelGGL(igemm_k4_dgrad_kernel, grid, dim3(256), 0, st, g, f);
+#define DYB_K4D_LAUNCH(MU_)                                                                                          \
+  do {                                                                                                               \
+    if (done) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, nullptr, done, 0, g, f);   \
+    else if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);    \
+    else hipLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, g, f);                             \
+  } while (0)
+  if (d.N == 1) DYB_K4D_LAUNCH(false);
+  else DYB_K4D_LAUNCH(true);
+#undef DYB_K4D_LAUNCH
   DYB_CHECK_LAUNCH();
-  *nch = (int)grid.x;
+  *nch = tpi;                                  // row chunks per image
   *ncolb = (int)grid.y;
   return DYB_OK;
 }
@@ -1261,26 +1290,39 @@ bool dyb_conv_k4_ok(const ConvDesc& d) {
   static const int max_c = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
   // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
   // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
-  return enabled && d.N == 1 && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
+  const char* eb = getenv("DYB_K4_BATCH");            // batch > 1 through K4: experimental, off by default (unmeasured)
+  const bool batch_ok = d.N == 1 || (eb && atoi(eb) && d.N <= 64);
+  return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }
 // conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count
 int dyb_conv_fwd_k4(const ConvDesc& d, const float* x, const float* w, float* y, float* partials, const GnFwdFuse* nf,
                     int* nchunks, hipStream_t st) {
   DYB_REQUIRE(x && w && y && partials && nchunks && dyb_conv_k4_ok(d), DYB_ERR_UNSUPPORTED);
-  K4Args g{x, w, y, partials, d.H, d.W, d.C, d.K, d.stride, conv_out_dim(d.H, 1, d.stride, 0), conv_out_dim(d.W, 1, d.stride, 0), 0};
+  K4Args g{x, w, y, partials, d.H, d.W, d.C, d.K, d.stride, conv_out_dim(d.H, 1, d.stride, 0), conv_out_dim(d.W, 1, d.stride, 0), 0,
+           d.N, 0};
   g.M = g.Ho * g.Wo;
-  dim3 grid(dyb_cdiv(g.M, 32), d.K / 32);
+  g.tpi = dyb_cdiv(g.M, 32);
+  dim3 grid(d.N * g.tpi, d.K / 32);
   GnFwdFuse f{};
   if (nf) f = *nf;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1);
-  if (nf && ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);
-  else if (nf) hipLaunchKernelGGL((igemm_k4_fwd_kernel<true>), grid, dim3(256), 0, st, g, f);
-  else if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);
-  else hipLaunchKernelGGL((igemm_k4_fwd_kernel<false>), grid, dim3(256), 0, st, g, f);
+#define DYB_K4_LAUNCH(FA_, MU_)                                                                                       \
+  do {                                                                                                                \
+    if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);       \
+    else hipLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, g, f);                           \
+  } while (0)
+  if (d.N == 1) {
+    if (nf) DYB_K4_LAUNCH(true, false);
+    else DYB_K4_LAUNCH(false, false);
+  } else {
+    if (nf) DYB_K4_LAUNCH(true, true);
+    else DYB_K4_LAUNCH(false, true);
+  }
+#undef DYB_K4_LAUNCH
   DYB_CHECK_LAUNCH();
-  *nchunks = (int)(grid.x * grid.y);
+  *nchunks = (int)(g.tpi * grid.y);             // partial records per image
   return DYB_OK;
 }
 

@@ -728,14 +728,14 @@ def case_layer_gnstats(be, N, H, W, C, Ka, Ra, sa, Kb, Rb, sb, seed=51):
 
 
 # ------------------------------------------------------------------- data gradient + producer's reduce (K4 backward)
-def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61):
+def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61, N=1):
     """Two chained layers P -> L at batch 1:  a = relu(GN_P(y_p)) [+ residual];  y = conv1x1_L(a);  out = relu(GN_L(y)).
     Given d(out), dyb_conv2d_nhwc_dgrad_gn_reduce must produce P's masked gradient dm_p and a partial block from which P's
     own fused gradients come out right: checked through the folded per-channel sums (= dbeta_P / dgamma_P) and through
     the data gradient of a 1x1 conv placed in front of P.  Runs with DYB_K4_BWD=1 (one launch) and =0 (two launches)."""
     import os
     rng = _rng(seed)
-    N, M = 1, H * W
+    M = H * W
     y_p = (rng.standard_normal((N, M, C)) * 1.2).astype(np.float32)
     gp, bp = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
     res = rng.standard_normal((N, M, C)).astype(np.float32)           # residual operand of P's activation (bn3 flavour)

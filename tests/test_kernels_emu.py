@@ -126,6 +126,17 @@ def test_dgrad_gn_reduce(be, cfg):
     assert r["layouts"][0] != r["layouts"][1]            # the one-launch path really ran (tile-count layout)
 
 
+def test_k4_batched_paths(be, monkeypatch):
+    """DYB_K4_BATCH=1 (experimental): the single-launch 1x1 kernels at batch > 1 - tiles never straddle images, per-image
+    partial records / coefficients - forward pair and backward pair against torch."""
+    monkeypatch.setenv("DYB_K4_BATCH", "1")
+    r = K.case_layer_gnstats(be, 3, 5, 5, 128, 128, 1, 1, 256, 1, 1, seed=77)            # ragged 25-pixel maps, 3 images
+    assert r["nA"] == 1 * 4 and r["nB"] == 1 * 8                                          # tiles per image x column tiles
+    r = K.case_dgrad_gn_reduce(be, 5, 7, 256, 128, False, True, seed=78, N=2)
+    assert r["layouts"][0] == (2, 8)                                                      # 35 pixels -> 2 row tiles per image
+    K.case_dgrad_gn_reduce(be, 4, 4, 128, 256, True, False, seed=79, N=3)
+
+
 def test_pools(be):
     K.case_pools(be, 2, 12, 12, 64)
     K.case_avgpool(be, 2, 49, 128)
