@@ -170,3 +170,12 @@ def test_pa_mpjpe(be):
 
 def test_optim(be):
     K.case_optim(be, n=4096)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")
+@pytest.mark.parametrize("k4_batch", ["0", "1"])
+def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, monkeypatch, k4_batch):
+    """The whole engine (forward + backward, batch 2) against the reference module's golden g3 on the emulator; with
+    DYB_K4_BATCH=1 the single-launch 1x1 kernels run with per-image tiles / partial records (experimental path)."""
+    monkeypatch.setenv("DYB_K4_BATCH", k4_batch)
+    K.case_hmr_engine(be, golden, ckpt_rand)
