@@ -244,6 +244,10 @@ class Adaptor(BaseAdaptor):
                 with torch.no_grad():
                     return self.model(image, need_feature=True)[3]
             init_features = self._on_side(_feats, image)
+        elif o.inner_step == 0:
+            # no lower level to share a forward with (the reference handles inner_step=0: dynaboa_benchmark.py:132-136)
+            with torch.no_grad():
+                init_features = [f.detach() for f in self.model(image, need_feature=True)[3]]
         h36m_batch = None
         learner = self.model.clone()
         owed = None                              # (tag, learner) of an inference() waiting for the next level forward
@@ -306,6 +310,11 @@ class Adaptor(BaseAdaptor):
                     feat_12 = float(sims[12]['cos'])
                     self.feat_sims[self.global_step].append(sims)
                 mpjpe, pampjpe, pve = self.inference(batch, self.model, tag=('final', self.optimized_step))
+                # the reference appends the metrics of every extra step (dynaboa_benchmark.py:188-189: what it dumps to
+                # steps_statistic_res.pt); in deferred mode the values live in metric_records under tag ('final', k)
+                if mpjpe is not None and pampjpe is not None and self.global_step < len(self.mpjpe_statistics):
+                    self.mpjpe_statistics[self.global_step].append(mpjpe)
+                    self.pampjpe_statistics[self.global_step].append(pampjpe)
             self.optim_step_record.append(self.optimized_step)
         return mpjpe, pampjpe, pve
 

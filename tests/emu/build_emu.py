@@ -24,7 +24,7 @@ def build(force=False):
         return LIB
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
     objs = []
-    flags = ["-std=c++17", "-O2", "-fPIC", "-g0", "-I", os.path.join(HERE, "include"), "-I", CSRC,
+    flags = ["-std=c++17", "-O2", "-fPIC", "-g0", "-pthread", "-I", os.path.join(HERE, "include"), "-I", CSRC,
              "-Wno-unused-value", "-Wno-vla-cxx-extension"]
     procs = []
     for s in sources() + [os.path.join(HERE, "emu_runtime.cpp")]:
@@ -34,7 +34,7 @@ def build(force=False):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"emu build failed for {s}")
-    subprocess.check_call([cxx, "-shared", "-o", LIB, *objs])
+    subprocess.check_call([cxx, "-shared", "-pthread", "-o", LIB, *objs])
     return LIB
 
 

@@ -1,15 +1,23 @@
 // TEST INFRASTRUCTURE ONLY - cooperative-fiber executor behind tests/emu/include/hip/hip_runtime.h.
 // One fiber per work-item; a workgroup's fibers run round-robin on the calling OS thread and
 // yield at __syncthreads() / cross-lane operations, which gives exactly the barrier semantics the
-// kernels rely on.  Workgroups of a grid run one after another.  x86-64 SysV only.
+// kernels rely on.  The workgroups of a grid are spread over a few OS threads (DYB_EMU_THREADS, default = the CPU
+// count, max 16): every piece of executor state, the built-in index variables and the kernels' __shared__ arrays are
+// thread_local, and no kernel here communicates between workgroups.  x86-64 SysV only.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace emu {
-dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -54,14 +62,14 @@ struct Wave {
   float a[2][64], b[2][64];
 };
 
-static char* g_stacks = nullptr;
-static Fiber g_f[kMaxThreads];
-static Wave g_w[kMaxThreads / 64];
-static void* g_sched_sp;
-static int g_cur, g_n, g_alive, g_arrived;
-static unsigned long long g_gen;
-static void (*g_call)(void*);
-static void* g_ctx;
+static thread_local char* g_stacks = nullptr;
+static thread_local Fiber g_f[kMaxThreads];
+static thread_local Wave g_w[kMaxThreads / 64];
+static thread_local void* g_sched_sp;
+static thread_local int g_cur, g_n, g_alive, g_arrived;
+static thread_local unsigned long long g_gen;
+static thread_local void (*g_call)(void*);
+static thread_local void* g_ctx;
 
 static void yield_to_sched() { emu_ctx_switch(&g_f[g_cur].sp, g_sched_sp); }
 
@@ -162,12 +170,8 @@ static void init_fiber(int idx) {
   g_f[idx].sp = sp;
 }
 
-void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
-  int n = (int)(block.x * block.y * block.z);
-  if (n <= 0 || n > kMaxThreads) {
-    fprintf(stderr, "emu: bad block size %d\n", n);
-    abort();
-  }
+static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, void (*call)(void*), void* ctx) {
+  const int n = (int)(block.x * block.y * block.z);
   if (!g_stacks) {
     g_stacks = static_cast<char*>(mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE,
                                        MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
@@ -177,52 +181,131 @@ void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
   g_ctx = ctx;
   g_blockDim = block;
   g_gridDim = grid;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        g_blockIdx = dim3(bx, by, bz);
-        g_n = g_alive = n;
-        g_arrived = 0;
-        g_gen = 0;
-        int nw = (n + 63) / 64;
-        for (int w = 0; w < nw; ++w) {
-          int cnt = n - w * 64;
-          g_w[w].alive = cnt > 64 ? 64 : cnt;
-          g_w[w].arrived = 0;
-          g_w[w].gen = 0;
-          memset(g_w[w].dep_gen, 0, sizeof(g_w[w].dep_gen));
-        }
-        for (int i = 0; i < n; ++i) {
-          init_fiber(i);
-          g_f[i].state = READY;
-          g_f[i].lane = i & 63;
-          g_f[i].wave = i >> 6;
-          g_f[i].tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-        }
-        int done = 0;
-        while (done < n) {
-          int progressed = 0;
-          for (int i = 0; i < n; ++i) {
-            Fiber& f = g_f[i];
-            if (f.state == DONE) continue;
-            if (f.state == WAIT_BLOCK) {
-              if (g_gen == f.wait_gen) continue;
-              f.state = READY;
-            } else if (f.state == WAIT_WAVE) {
-              if (g_w[f.wave].gen == f.wait_gen) continue;
-              f.state = READY;
-            }
-            g_cur = i;
-            g_threadIdx = f.tid;
-            emu_ctx_switch(&g_sched_sp, f.sp);
-            ++progressed;
-            if (f.state == DONE) ++done;
-          }
-          if (!progressed) {
-            fprintf(stderr, "emu: deadlock in block (%u,%u,%u): %d of %d work-items finished\n", bx, by, bz, done, n);
-            abort();
-          }
-        }
+  g_blockIdx = dim3(bx, by, bz);
+  g_n = g_alive = n;
+  g_arrived = 0;
+  g_gen = 0;
+  int nw = (n + 63) / 64;
+  for (int w = 0; w < nw; ++w) {
+    int cnt = n - w * 64;
+    g_w[w].alive = cnt > 64 ? 64 : cnt;
+    g_w[w].arrived = 0;
+    g_w[w].gen = 0;
+    memset(g_w[w].dep_gen, 0, sizeof(g_w[w].dep_gen));
+  }
+  for (int i = 0; i < n; ++i) {
+    init_fiber(i);
+    g_f[i].state = READY;
+    g_f[i].lane = i & 63;
+    g_f[i].wave = i >> 6;
+    g_f[i].tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+  }
+  int done = 0;
+  while (done < n) {
+    int progressed = 0;
+    for (int i = 0; i < n; ++i) {
+      Fiber& f = g_f[i];
+      if (f.state == DONE) continue;
+      if (f.state == WAIT_BLOCK) {
+        if (g_gen == f.wait_gen) continue;
+        f.state = READY;
+      } else if (f.state == WAIT_WAVE) {
+        if (g_w[f.wave].gen == f.wait_gen) continue;
+        f.state = READY;
       }
+      g_cur = i;
+      g_threadIdx = f.tid;
+      emu_ctx_switch(&g_sched_sp, f.sp);
+      ++progressed;
+      if (f.state == DONE) ++done;
+    }
+    if (!progressed) {
+      fprintf(stderr, "emu: deadlock in block (%u,%u,%u): %d of %d work-items finished\n", bx, by, bz, done, n);
+      abort();
+    }
+  }
+}
+
+// ---- a small persistent pool: the launching thread publishes one grid at a time and takes part itself ----
+struct Job {
+  dim3 grid, block;
+  void (*call)(void*);
+  void* ctx;
+  unsigned long long total;
+};
+// heap objects that are never destroyed: the pool threads are detached and still wait on them when the process exits
+// (destroying a condition variable with waiters blocks forever)
+static std::mutex& g_mu = *new std::mutex();                    // serialises launches (several host threads may drive the library)
+static std::mutex& g_pool_mu = *new std::mutex();
+static std::condition_variable &g_cv_work = *new std::condition_variable(), &g_cv_done = *new std::condition_variable();
+static std::vector<std::thread>& g_pool = *new std::vector<std::thread>();
+static Job g_job;
+static unsigned long long g_job_id = 0;
+static std::atomic<unsigned long long> g_next{0};
+static int g_active = 0;
+
+static void work_on(const Job& j) {
+  for (;;) {
+    unsigned long long b = g_next.fetch_add(1, std::memory_order_relaxed);
+    if (b >= j.total) return;
+    unsigned bx = (unsigned)(b % j.grid.x), by = (unsigned)((b / j.grid.x) % j.grid.y), bz = (unsigned)(b / ((unsigned long long)j.grid.x * j.grid.y));
+    run_block(j.grid, j.block, bx, by, bz, j.call, j.ctx);
+  }
+}
+static void pool_main() {
+  unsigned long long seen = 0;
+  for (;;) {
+    Job j;
+    {
+      std::unique_lock<std::mutex> lk(g_pool_mu);
+      g_cv_work.wait(lk, [&] { return g_job_id != seen; });
+      seen = g_job_id;
+      j = g_job;
+    }
+    work_on(j);
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if (--g_active == 0) g_cv_done.notify_all();
+    }
+  }
+}
+static int pool_size() {
+  static int n = [] {
+    const char* e = getenv("DYB_EMU_THREADS");
+    long v = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (v < 1) v = 1;
+    if (v > 16) v = 16;
+    return (int)v;
+  }();
+  return n;
+}
+
+void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
+  int n = (int)(block.x * block.y * block.z);
+  if (n <= 0 || n > kMaxThreads) {
+    fprintf(stderr, "emu: bad block size %d\n", n);
+    abort();
+  }
+  std::lock_guard<std::mutex> launch_lock(g_mu);
+  Job j{grid, block, call, ctx, (unsigned long long)grid.x * grid.y * grid.z};
+  const int helpers = pool_size() - 1;
+  if (helpers <= 0 || j.total < 2) {
+    g_next.store(0);
+    work_on(j);
+    return;
+  }
+  if (g_pool.empty())
+    for (int i = 0; i < helpers; ++i) { g_pool.emplace_back(pool_main); g_pool.back().detach(); }
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_next.store(0);
+    g_job = j;
+    g_active = helpers;
+    ++g_job_id;
+  }
+  g_cv_work.notify_all();
+  work_on(j);
+  std::unique_lock<std::mutex> lk(g_pool_mu);
+  g_cv_done.wait(lk, [&] { return g_active == 0; });
 }
 }  // namespace emu

@@ -4,7 +4,8 @@
 // conditional compilation.  To check their indexing / synchronisation logic in the build
 // container (which has no GPU) the `-m "not gpu"` tests compile those same files with the host
 // clang++ and `-I tests/emu/include`, so that this header is found instead of the real one.
-// Every workgroup is executed by cooperative fibers (one per work-item, see emu_runtime.cpp):
+// Every workgroup is executed by cooperative fibers (one per work-item, see emu_runtime.cpp), workgroups of a
+// grid on a few OS threads (hence __shared__ = static thread_local):
 // __syncthreads(), wave-64 shuffles and the 32x32x2 fp32 MFMA are emulated with the hardware's
 // lane -> element maps.  The resulting library (tests/emu/_build/libdynaboa_emu.so) is loaded
 // only by tests; dynaboa_amd/_lib.py never looks for it.
@@ -18,7 +19,7 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+#define __shared__ static thread_local
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
@@ -77,7 +78,7 @@ static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 
 namespace emu {
-extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void syncthreads();
 void wave_exchange(const void* mine, void* theirs, int src_lane, int bytes);
 void mfma_32x32x2(float a, float b, float* c16);

@@ -378,6 +378,14 @@ def g5so(out):
     run_stream("fo_inner2_frameonly", out, dict(frame_only, inner_step=2), 2, first_order=True)
 
 
+def g5so3(out):
+    """Second order at the BENCHMARKED depth (inner_step=3, BASELINE configs[1]); its first-order twin is
+    g5_fo_inner3_frameonly (same stream, same seeds)."""
+    frame_only = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0,
+                      use_motion=0, dynamic_boa=0, use_temporal_losses_upper=0)
+    run_stream("so_inner3_frameonly", out, dict(frame_only, inner_step=3), 2, first_order=False)
+
+
 def g5_forced(out):
     # lr=3e-6 moves features[12] by <1e-7 in cosine, so the dynamic loop of
     # dynaboa_benchmark.py:161-192 never fires above; a negative threshold forces the branch
