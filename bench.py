@@ -42,13 +42,18 @@ RESNET_CONVS = [
 
 
 def pmc_traffic():
-    """HBM bytes per launch (read + write) of the conv kernel family from the committed PMC passes
-    (profiles/r01_pmc_igemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, each in its own run;
-    reads x2 = the gfx950 correction, calibrated there on the 216 / 432 MB streaming kernels; writes
-    calibrate exact); None if the file is absent."""
+    """HBM bytes per launch (read + write) of the conv kernel family from the newest committed PMC summary
+    (profiles/r*_pmc_igemm_traffic.json, written by tools/pmc_summarize.py from two rocprofv3 runs of THIS command:
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE, each in its own pass; reads x2 = the gfx950 correction, calibrated there on
+    the 216 / 432 MB streaming kernels; writes calibrate exact).  A PMC pass cannot run inside the bench process, so the
+    figure is the one of the commit named in the note; None if no summary is committed."""
+    import glob
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")))
-        return float(d["hbm_bytes_per_launch"])
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_igemm_traffic.json")))[-1]
+        d = json.load(open(path))
+        return dict(bytes=float(d["hbm_bytes_per_launch"]),
+                    note="HBM read (FETCH_SIZE x2) + write (WRITE_SIZE) bytes per conv launch from %s, measured at commit %s" %
+                         (os.path.relpath(path, ROOT), d.get("commit", "unknown (round 1, before the K4 data gradient)")))
     except Exception:      # noqa: BLE001
         return None
 
@@ -117,6 +122,98 @@ def cpu_baseline(inner_step=3, timeout_s=240):
         return dict(value=None, unit="adapted frames/s", cores=None, kind="port", sample=f"cpu baseline did not finish: {type(e).__name__}")
 
 
+def self_spawn(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+def build_adaptor(device, batch, inner_step, full_losses=0, second_order=0, share_forwards=1, overlap=2, schedule="faithful",
+                  **over):
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    if full_losses:
+        o = DB.parser.parse_args([])
+        o.inner_step = inner_step
+    else:
+        o = DB.frame_only_options(inner_step=inner_step)
+    o.batch_size = batch
+    o.second_order = second_order
+    o.share_forwards = share_forwards
+    o.deferred_metrics = 1
+    o.overlap_metrics = overlap
+    o.eval_lower = 1 if schedule == "faithful" else 0
+    for k, v in over.items():
+        setattr(o, k, v)
+    return DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
+
+
+def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
+    """warmup untimed frames, then `steps` frames between barrier + device synchronise on both sides; the metric tail of
+    the last frames (side-stream worker) and flush_metrics() - the Procrustes launch + the device-to-host transfer of the
+    per-frame errors the reference performs inside every inference() - are INSIDE the clock.  per_frame: a HIP event after
+    every frame on the issuing stream gives the per-frame completion intervals (p50 / p99)."""
+    def run(lo, hi, evs=None):
+        for s in range(lo, hi):
+            ad.global_step = s
+            ad.fit_losses = {}
+            ad.model.eval()
+            ad.adaptation(frames[s])
+            if evs is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                evs.append(e)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        run(0, warmup)
+        ad.flush_metrics()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [] if per_frame else None
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        if evs is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            evs.append(e0)
+        run(warmup, warmup + steps, evs)
+        t_issue = time.perf_counter() - t0          # host finished issuing; GPU may still be draining
+        metrics = ad.flush_metrics()                # joins the side worker / stream, Procrustes launch, D2H of the scalars
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = dict(dt=dt, t_issue=t_issue, metrics=metrics, run=run)
+    if evs is not None:
+        ft = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
+        out["frame_ms"] = ft
+    return out
+
+
+def sub_record(device, name, steps, warmup, batch, inner_step, note, **kw):
+    """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each."""
+    from dynaboa_amd import assets
+    try:
+        ad = build_adaptor(device, batch, inner_step, **kw)
+        frames = [{k: v.to(device) for k, v in assets.make_frame(500_000 + s, batch, seed=22).items()} for s in range(warmup + steps)]
+        ad.reset_records(warmup + steps)
+        st = torch.cuda.Stream(device=device)
+        r = timed_stream(ad, frames, warmup, steps, st)
+        return dict(value=steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
+                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps, config=note)
+    except Exception as e:      # noqa: BLE001
+        return dict(value=None, error=f"{type(e).__name__}: {e}", config=note)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,15 +231,22 @@ def main():
                     help="1: second-order MAML (BASELINE config 5's ablation arm); the reference and the default run are first-order")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
+    ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--cpu_baseline_only", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args.inner_step)))
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -158,55 +262,23 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
-    from dynaboa_amd import assets, benchmark as DB
-    from dynaboa_amd.base_adaptor import synthetic_bundle
-    if args.full_losses:
-        o = DB.parser.parse_args([])
-        o.inner_step = args.inner_step
-    else:
-        o = DB.frame_only_options(inner_step=args.inner_step)
-    o.batch_size = args.batch
-    o.second_order = args.second_order
-    o.share_forwards = args.share_forwards
-    o.deferred_metrics = 1
-    o.overlap_metrics = args.overlap
-    o.eval_lower = 1 if args.schedule == "faithful" else 0
-    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
+    from dynaboa_amd import assets
+    ad = build_adaptor(device, args.batch, args.inner_step, args.full_losses, args.second_order, args.share_forwards,
+                       args.overlap, args.schedule)
     total = args.warmup + args.steps
     n_roof = 0 if args.no_roofline else 4           # extra frames for the instrumented roofline pass (outside the clock)
+    n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
     # this rank's shard of the synthetic stream, resident in HBM before the clock starts
+    nfr = total + n_roof + n_pct
     frames = [{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + s, args.batch, seed=22).items()}
-              for s in range(total + n_roof)]
-    ad.reset_records(total + n_roof)
-
-    def run(lo, hi):
-        for s in range(lo, hi):
-            ad.global_step = s
-            ad.fit_losses = {}
-            ad.model.eval()
-            ad.adaptation(frames[s])
+              for s in range(nfr)]
+    ad.reset_records(nfr)
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream
     main_stream = torch.cuda.Stream(device=device)
-    torch.cuda.synchronize()
-    with torch.cuda.stream(main_stream):
-        run(0, args.warmup)
-        ad.flush_metrics()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(main_stream):
-        run(args.warmup, total)
-    t_issue = time.perf_counter() - t0          # host finished issuing; GPU may still be draining
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    metrics = ad.flush_metrics()                              # one Procrustes launch + one D2H of scalars, outside the clock
+    res = timed_stream(ad, frames, args.warmup, args.steps, main_stream, dist, per_frame=(args.steps >= 200))
+    dt, t_issue, metrics, run = res["dt"], res["t_issue"], res["metrics"], res["run"]
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,7 +297,9 @@ def main():
         fwd_ref = (1 + 2 * args.inner_step + 2) if args.schedule == "faithful" else (args.inner_step + 3)
         # with forward sharing the identical-weight repeats (feature forward, per-inner-step inference) reuse a level forward
         fwd_pf = (args.inner_step + 2) if (args.share_forwards and not args.full_losses) else fwd_ref
-        out = {"metric": "adapted frames/sec/GPU (3 inner + 1 outer step, bs=1) + PA-MPJPE on 3DPW",
+        order = "second-order" if args.second_order else "first-order"
+        out = {"metric": "adapted frames/sec, whole job (%d inner + 1 outer step, bs=%d, %s; synthetic 224x224 stream, no 3DPW "
+                         "assets in the image: PA-MPJPE on 3DPW not measured)" % (args.inner_step, args.batch, order),
                "value": value, "unit": "adapted frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt * 1e3 / args.steps, "host_issue_ms_per_step": t_issue * 1e3 / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -233,7 +307,8 @@ def main():
                "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
                                       "inner_step=%d + 1 outer, %s, %s; schedule=%s: every output of the reference's "
                                       "%d-forward schedule is produced (metrics after each inner step when faithful), "
-                                      "%d HMR forwards + %d backwards executed per frame%s; metric tails / remaining no-grad forwards %s" %
+                                      "%d HMR forwards + %d backwards executed per frame%s; metric tails / remaining no-grad forwards %s; "
+                                      "metric flush (Procrustes + D2H) inside the clock" %
                                       (args.batch, args.inner_step,
                                        "second-order (finite-difference Hessian-vector products: +2 forward+backward per inner step)"
                                        if args.second_order else "first-order (reference parity mode)",
@@ -249,20 +324,54 @@ def main():
                           "gathered_frames": int(gathered.numel()) if gathered is not None else None,
                           "engine_graphs": __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(args.batch).graph_stats()}}
         if not args.no_roofline:
-            r = conv_roofline(run, total, total + n_roof, main_stream)
+            lo = total
+            torch.cuda.synchronize()
+            r = conv_roofline(run, lo, lo + n_roof, main_stream)
             ad.flush_metrics()
         if not args.no_roofline and r is not None:
+            tr = pmc_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),
-                               "traffic_note": "HBM read (FETCH_SIZE x2) + write (WRITE_SIZE) bytes per launch, "
-                                               "profiles/r01_pmc_igemm_traffic.json", "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad, +/- GroupNorm loaders>: every conv launch of the "
-                                         "adaptation chain (main + weight-gradient streams), timed on its own dispatch inside the path",
+                               "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": tr["bytes"] if tr else None,
+                               "traffic_note": tr["note"] if tr else "no PMC summary under profiles/",
+                               "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad, +/- GroupNorm loaders> + igemm_k4_{fwd,dgrad}_kernel: every conv "
+                                         "launch of the adaptation chain (main + weight-gradient streams), timed on its own dispatch inside the path",
                                "sample_frames": r["sample_frames"],
                                "avg_launch_us": r["avg_launch_us"], "launches_per_frame": r["launches_per_frame"],
                                "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],
                                "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3,
                                "whole_frame_frac": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS}
+        # per-frame completion intervals (HIP events on the issuing stream): from the timed run itself when it has >= 200
+        # frames, else from an extra pass of `percentile_frames` frames of the same loop
+        ft = res.get("frame_ms")
+        if ft is None and n_pct:
+            evs = []
+            torch.cuda.synchronize()
+            with torch.cuda.stream(main_stream):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(main_stream)
+                evs.append(e0)
+                run(total + n_roof, total + n_roof + n_pct, evs)
+                ad.flush_metrics()
+            torch.cuda.synchronize()
+            ft = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
+        if ft is not None and len(ft):
+            out["frame_time_ms"] = {"frames": int(len(ft)), "mean": float(ft.mean()), "p50": float(np.percentile(ft, 50)),
+                                    "p99": float(np.percentile(ft, 99)), "max": float(ft.max()),
+                                    "how": "HIP event after every frame on the issuing stream; intervals between consecutive events"}
+        if world == 1 and not args.no_sub_records and not (args.second_order or args.full_losses or args.batch != 1):
+            del ad, frames
+            torch.cuda.empty_cache()
+            out["second_order"] = sub_record(device, "second_order", 24, 4, 1, args.inner_step,
+                                             "configs[1] second-order arm: same stream, second_order=1 (finite-difference Hessian-vector "
+                                             "products, +2 forward+backward per inner step)", second_order=1)
+            out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 16, 4, 8, args.inner_step,
+                                                 "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
+                                                 "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
+                                                 upper_level_mixtrain=1, sample_num=8)
+            out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
+                                                    "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
+                                                    "dynamic-BOA gate)", full_losses=1)
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
         print(json.dumps(out))

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -125,6 +126,9 @@ struct HmrPlan {
   hipEvent_t ev_join;
   bool events_ready;
   std::unordered_map<GKey, GEntry, GKeyHash> gfwd, gbwd;
+  // one plan serves every stream / host thread of the process (metric worker, replica threads): the lazily created
+  // events and the graph cache are the only mutable state and sit behind this lock (the eager path never takes it)
+  std::mutex mu;
 };
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -269,6 +273,7 @@ extern "C" void dyb_hmr_plan_destroy(void* plan) {
   delete P;
 }
 static int ensure_events(HmrPlan& P) {
+  std::lock_guard<std::mutex> lock(P.mu);
   if (P.events_ready) return DYB_OK;
   P.ev_dy.resize(P.convs.size());
   for (size_t i = 0; i < P.convs.size(); ++i)
@@ -382,6 +387,11 @@ template <class Body>
 static int run_cached(HmrPlan& P, std::unordered_map<GKey, GEntry, GKeyHash>& cache, const GKey& key, hipStream_t st,
                       Body body) {
   if (!P.graph_mode) return body();
+  // graph mode: lookups, insertions (which may rehash) and the counters are serialised; a capture is thread-local, so
+  // holding the lock across it only delays other graph-mode callers of the same plan.  The cache stops growing at
+  // DYB_MAX_GRAPHS keys: later keys run eagerly.
+  std::lock_guard<std::mutex> lock(P.mu);
+  if (cache.find(key) == cache.end() && cache.size() >= DYB_MAX_GRAPHS) { ++P.g_eager; return body(); }
   GEntry& e = cache[key];
   if (e.exec) {
     if (hipGraphLaunch(e.exec, st) == hipSuccess) { ++P.g_hits; return DYB_OK; }

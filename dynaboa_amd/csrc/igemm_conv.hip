@@ -26,6 +26,9 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
+#include <string.h>
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -1006,6 +1009,46 @@ static float env_float(const char* name, float dflt) {
   const char* v = getenv(name);
   return v ? (float)atof(v) : dflt;
 }
+
+// ---- run-time switches ------------------------------------------------------------------------------------
+// Read from the environment ONCE (first use), never on the dispatch path; dyb_set_option changes one afterwards
+// (tests / A-B runs).  Names: "k4" (single-launch 1x1 forward + statistics), "k4_bwd" (1x1 data gradient carries the
+// producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit).
+struct DybSwitches {
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc;
+  DybSwitches() {
+    auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+    k4 = env("DYB_K4", 1);
+    k4_bwd = env("DYB_K4_BWD", 1);
+    k4_batch = env("DYB_K4_BATCH", 1);
+    k4_maxc = env("DYB_K4_MAXC", 1024);
+  }
+};
+static DybSwitches& switches() {
+  static DybSwitches* s = new DybSwitches();
+  return *s;
+}
+static std::atomic<int>* find_switch(const char* name) {
+  if (!name) return nullptr;
+  DybSwitches& s = switches();
+  if (!strcmp(name, "k4")) return &s.k4;
+  if (!strcmp(name, "k4_bwd")) return &s.k4_bwd;
+  if (!strcmp(name, "k4_batch")) return &s.k4_batch;
+  if (!strcmp(name, "k4_maxc")) return &s.k4_maxc;
+  return nullptr;
+}
+extern "C" int dyb_set_option(const char* name, int value) {
+  std::atomic<int>* p = find_switch(name);
+  DYB_REQUIRE(p, DYB_ERR_ARG);
+  p->store(value);
+  return DYB_OK;
+}
+extern "C" int dyb_get_option(const char* name, int* value) {
+  std::atomic<int>* p = find_switch(name);
+  DYB_REQUIRE(p && value, DYB_ERR_ARG);
+  *value = p->load();
+  return DYB_OK;
+}
 // `raw`: the consumer folds the slabs itself (forward: GroupNorm statistics; backward: the next
 // GroupNorm-backward reduce), so a split costs per-slab read time there instead of a launch.
 static int choose_split(const IgemmArgs& g, size_t ws_floats, int mode, bool raw = false) {
@@ -1226,11 +1269,9 @@ extern "C" int dyb_conv2d_nhwc_wgrad_gn(const float* x, const float* dm, const f
   return run_igemm(MODE_WGRAD, d, x, dm, dw, nullptr, ws, ws_bytes, nullptr, st, &f);
 }
 bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
-  const char* e = getenv("DYB_K4_BWD");                 // read per call (tests toggle it); on: 1.40 -> 1.31 ms per backward
-  const int enabled = e ? atoi(e) : 1;
-  static const int max_k = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
-  const char* eb = getenv("DYB_K4_BATCH");
-  const bool batch_ok = d.N == 1 || (eb && atoi(eb) && d.N <= 64);
+  const DybSwitches& sw = switches();                   // k4_bwd on: 1.40 -> 1.31 ms per backward
+  const int enabled = sw.k4_bwd.load(std::memory_order_relaxed), max_k = sw.k4_maxc.load(std::memory_order_relaxed);
+  const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
   return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
          d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
 }
@@ -1249,17 +1290,19 @@ int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, co
   K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K,
                 d.N, tpi};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (!done) timing_acquire(d, &ev0, &ev1);           // bench.py's conv timing scope
+  timing_acquire(d, &ev0, &ev1);                      // bench.py's conv timing scope
 #define DYB_K4D_LAUNCH(MU_)                                                                                          \
   do {                                                                                                               \
-    if (done) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, nullptr, done, 0, g, f);   \
-    else if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);    \
+    if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);         \
+    else if (done) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, nullptr, done, 0, g, f); \
     else hipLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, g, f);                             \
   } while (0)
   if (d.N == 1) DYB_K4D_LAUNCH(false);
   else DYB_K4D_LAUNCH(true);
 #undef DYB_K4D_LAUNCH
   DYB_CHECK_LAUNCH();
+  // inside a timing scope the launch carries the timing pair, so the caller's completion event is a record of its own
+  if (ev0 && done && hipEventRecord(done, st) != hipSuccess) return DYB_ERR_LAUNCH;
   *nch = tpi;                                  // row chunks per image
   *ncolb = (int)grid.y;
   return DYB_OK;
@@ -1286,12 +1329,11 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
 // ---- K4 host side ------------------------------------------------------------------------------------
 bool dyb_conv_k4_ok(const ConvDesc& d) {
   const int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
-  static const int enabled = getenv("DYB_K4") ? atoi(getenv("DYB_K4")) : 1;
-  static const int max_c = getenv("DYB_K4_MAXC") ? atoi(getenv("DYB_K4_MAXC")) : 1024;
+  const DybSwitches& sw = switches();
+  const int enabled = sw.k4.load(std::memory_order_relaxed), max_c = sw.k4_maxc.load(std::memory_order_relaxed);
   // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
   // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
-  const char* eb = getenv("DYB_K4_BATCH");            // batch > 1 through K4: experimental, off by default (unmeasured)
-  const bool batch_ok = d.N == 1 || (eb && atoi(eb) && d.N <= 64);
+  const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
   return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }

@@ -224,6 +224,13 @@ int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, dyb_st
 int dyb_axpby(const float* x, float* y, float a, float b, size_t n, dyb_stream_t stream);
 int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* out, dyb_stream_t stream);
 
+/* run-time switches of the dispatch policy (A/B runs, tests).  Read from the environment (DYB_K4, DYB_K4_BWD,
+ * DYB_K4_BATCH, DYB_K4_MAXC) once at first use - never on the dispatch path - and changed here afterwards.
+ * names: "k4" single-launch 1x1 forward conv + statistics; "k4_bwd" 1x1 data gradient carrying the producer's
+ * GroupNorm-backward reduce; "k4_batch" both at batch > 1; "k4_maxc" their channel limit. */
+int dyb_set_option(const char* name, int value);
+int dyb_get_option(const char* name, int* value);
+
 /* diagnostic: n dependent launches of a trivial kernel (per-launch floor of a kernel chain) */
 int dyb_debug_launch_chain(float* scratch, int n, int blocks, dyb_stream_t stream);
 

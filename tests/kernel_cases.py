@@ -760,7 +760,7 @@ def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61, N=1
     L = be.lib
     res_out = {}
     for mode in (1, 0):
-        os.environ["DYB_K4_BWD"] = str(mode)
+        L.dyb_set_option(b"k4_bwd", mode)
         try:
             shL = (N, H, W, C, Kc, 1, 1, 1, 0)
             wsb = max(L.dyb_conv2d_workspace_bytes(*shL), 16)
@@ -802,7 +802,7 @@ def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61, N=1
             res_out[mode] = dict(dyp=be.host(DYP).copy(), dg=be.host(DGP).copy(), db=be.host(DBP).copy(), dm=be.host(DMP).copy(),
                                  layout=(nch.value, ncolb.value))
         finally:
-            os.environ.pop("DYB_K4_BWD", None)
+            L.dyb_set_option(b"k4_bwd", 1)
     e = {}
     for mode, r in res_out.items():
         e[f"dy_p[{mode}]"] = rel_err(r["dyp"], dyp_ref)

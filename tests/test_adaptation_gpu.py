@@ -348,12 +348,23 @@ def test_second_order_full_loss_set_vs_oracle(gmm_t, smpl_tabs):
     assert (e_so < 0.3 * gap + 5e-3).all(), (e_so, gap)
 
 
-def test_k4_backward_path_matches_reference_stream(monkeypatch):
-    """DYB_K4_BWD=1 (data gradients of the small 1x1 layers carry the producer's GroupNorm-backward reduce in their
-    epilogue; off by default) on the 3-inner-step golden stream: same losses / predictions / Adam moments as the
-    reference within the usual tolerances."""
-    monkeypatch.setenv("DYB_K4_BWD", "1")
-    from dynaboa_amd import assets
+@pytest.fixture
+def restore_switches():
+    """Library switches changed by a test (dyb_set_option) go back to their defaults afterwards."""
+    from dynaboa_amd import _lib
+    yield
+    lib = _lib.load()
+    for name, dflt in ((b"k4", 1), (b"k4_bwd", 1), (b"k4_batch", 1)):
+        lib.dyb_set_option(name, dflt)
+
+
+@pytest.mark.parametrize("k4_bwd", [1, 0])
+def test_k4_backward_path_matches_reference_stream(k4_bwd, restore_switches):
+    """k4_bwd=1 (default: data gradients of the small 1x1 layers carry the producer's GroupNorm-backward reduce in their
+    epilogue) and k4_bwd=0 (two launches) on the 3-inner-step golden stream: same losses / predictions / Adam moments
+    as the reference within the usual tolerances."""
+    from dynaboa_amd import _lib, assets
+    _lib.load().dyb_set_option(b"k4_bwd", k4_bwd)
     g = golden("g5_fo_inner3_frameonly.npz")
     opts, ident = STREAMS["fo_inner3_frameonly"]
     ad, _ = make_adaptor(opts, ident)
@@ -378,3 +389,74 @@ def test_k4_backward_path_matches_reference_stream(monkeypatch):
     names = [str(x) for x in g["names"]]
     np.testing.assert_allclose(np.array([float(m[k].double().norm()) for k in names]), g["m_norms"], rtol=2e-2)
     np.testing.assert_allclose(np.array([float(v[k].double().norm()) for k in names]), g["v_norms"], rtol=2e-2)
+
+
+def test_batch8_mixtrain_matches_oracle(gmm_t, smpl_tabs):
+    """BASELINE configs[2]: batch 8, lower- and upper-level labelled exemplars mixed in (S = 8 synthetic exemplars per
+    level, reference base_adaptor.py:346-376 through dynaboa_benchmark.py:138-151) - one full bilevel step (2 inner +
+    1 outer) against the CPU oracle: predictions after the step and the outer gradient.  Runs with the default dispatch
+    (single-launch 1x1 kernels at batch > 1, k4_batch=1)."""
+    from dynaboa_amd import assets
+    from oracle import ref_cpu as O
+    opts = dict(inner_step=2, batch_size=8, sample_num=8, retrieval=1, lower_level_mixtrain=1, upper_level_mixtrain=1,
+                use_meanteacher=0, use_motion=0, dynamic_boa=0, use_temporal_losses_upper=0)
+    ad, bundle = make_adaptor(opts, False)
+    ad.reset_records(1)
+    ad.global_step = 0
+    frame = assets.make_frame(5, 8, seed=22)
+    ad.model.eval()
+    ad.adaptation({k: v.to(ad.device) for k, v in frame.items()})
+    with torch.no_grad():
+        r, s, c = ad.model(frame["image"].to(ad.device))
+        j = ad.decode_smpl_params(r, s)["s3d"]
+    sd = {k.replace("module.", ""): v for k, v in bundle.checkpoint["model"].items()}
+    ref = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, opts)
+    ref.exemplar_fn = lambda step: assets.make_exemplars(step, 8)
+    torch.set_num_threads(max(1, min(64, (__import__("os").cpu_count() or 8) // 2)))
+    rec = ref.adapt_frame(frame)
+    assert abs(float(ad.fit_losses["ul/total"]) - rec["upper_loss"][0]) < 1e-4 * abs(rec["upper_loss"][0])
+    for name, a, b in (("rotmat", r, rec["pred"]["rotmat"]), ("shape", s, rec["pred"]["shape"]), ("cam", c, rec["pred"]["cam"]),
+                       ("joints", j, rec["pred"]["joints"])):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-3, name
+    hmr_m = ad.model.module
+    m1 = hmr_m._layout1.unpack(ad.optimizer.state[hmr_m.theta]["exp_avg"])
+    for k in ("conv1.weight", "layer1.0.conv2.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight", "layer4.2.conv3.weight",
+              "fc1.weight", "decpose.bias"):
+        a, b = m1[k].double().flatten() * 2, rec["outer_grad"][k].double().flatten()
+        assert cosine(a, b) > 0.999, k
+        assert abs(float(a.norm() / b.norm()) - 1) < 2e-2, k
+
+
+def test_second_order_inner3_matches_reference_second_order():
+    """Second order at the BENCHMARKED depth (inner_step=3, BASELINE configs[1]) against the reference run with
+    learn2learn first_order=False (golden g5_so_inner3_frameonly); the first-order golden of the same stream
+    (g5_fo_inner3_frameonly) shows which of the two gradients the implementation follows."""
+    from dynaboa_amd import assets
+    gso, gfo = golden("g5_so_inner3_frameonly.npz"), golden("g5_fo_inner3_frameonly.npz")
+    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=3, second_order=1), False)
+    n = int(gso["nframes"])
+    ad.reset_records(n)
+    hmr = ad.model.module
+    L = hmr._layout1
+    names = [str(x) for x in gso["names"]]
+    for step in range(n):
+        ad.global_step = step
+        ad.fit_losses = {}
+        batch = {k: v.to(ad.device) for k, v in assets.make_frame(step, 1, seed=22).items()}
+        ad.model.eval()
+        ad.adaptation(batch)
+        up = float(ad.fit_losses["ul/total"])
+        assert abs(up - gso["upper_loss"][step]) < 1e-4 * abs(gso["upper_loss"][step]), (step, up)
+        with torch.no_grad():
+            r, s, c = ad.model(batch["image"])
+        for k, v in dict(rotmat=r, shape=s, cam=c).items():
+            assert rel_err(v.cpu().numpy(), gso[f"pred{step}_{k}"]) < 1e-3, (step, k)
+        if step == 0:
+            st = ad.optimizer.state[hmr.theta]
+            g1 = L.unpack(st["exp_avg"] / (1 - ad.options.beta1))
+            gn = np.array([float(g1[k].double().norm()) for k in names])
+            err_so = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
+            gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
+            print("SO inner3 grad-norm error: median %.2e max %.2e; FO-vs-SO gap: median %.2e" % (np.median(err_so), err_so.max(), np.median(gap)))
+            assert np.median(err_so) < 1e-2 and err_so.max() < 5e-2
+            assert np.median(err_so) < 0.1 * np.median(gap)

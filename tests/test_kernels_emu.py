@@ -126,10 +126,10 @@ def test_dgrad_gn_reduce(be, cfg):
     assert r["layouts"][0] != r["layouts"][1]            # the one-launch path really ran (tile-count layout)
 
 
-def test_k4_batched_paths(be, monkeypatch):
-    """DYB_K4_BATCH=1 (experimental): the single-launch 1x1 kernels at batch > 1 - tiles never straddle images, per-image
+def test_k4_batched_paths(be):
+    """k4_batch=1 (default): the single-launch 1x1 kernels at batch > 1 - tiles never straddle images, per-image
     partial records / coefficients - forward pair and backward pair against torch."""
-    monkeypatch.setenv("DYB_K4_BATCH", "1")
+    be.lib.dyb_set_option(b"k4_batch", 1)
     r = K.case_layer_gnstats(be, 3, 5, 5, 128, 128, 1, 1, 256, 1, 1, seed=77)            # ragged 25-pixel maps, 3 images
     assert r["nA"] == 1 * 4 and r["nB"] == 1 * 8                                          # tiles per image x column tiles
     r = K.case_dgrad_gn_reduce(be, 5, 7, 256, 128, False, True, seed=78, N=2)
@@ -173,9 +173,12 @@ def test_optim(be):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")
-@pytest.mark.parametrize("k4_batch", ["0", "1"])
-def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, monkeypatch, k4_batch):
+@pytest.mark.parametrize("k4_batch", [0, 1])
+def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, k4_batch):
     """The whole engine (forward + backward, batch 2) against the reference module's golden g3 on the emulator; with
-    DYB_K4_BATCH=1 the single-launch 1x1 kernels run with per-image tiles / partial records (experimental path)."""
-    monkeypatch.setenv("DYB_K4_BATCH", k4_batch)
-    K.case_hmr_engine(be, golden, ckpt_rand)
+    k4_batch=1 the single-launch 1x1 kernels run with per-image tiles / partial records (experimental path)."""
+    be.lib.dyb_set_option(b"k4_batch", k4_batch)
+    try:
+        K.case_hmr_engine(be, golden, ckpt_rand)
+    finally:
+        be.lib.dyb_set_option(b"k4_batch", 1)

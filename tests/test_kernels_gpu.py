@@ -174,6 +174,31 @@ def test_conv_linearity_full_size(be):
     assert np.abs(outs[2] - (2.5 * outs[0] + outs[1])).max() < 1e-4 * np.abs(outs[2]).max()
 
 
-def test_hmr_engine_vs_reference_module(be, ckpt_rand):
-    e = K.case_hmr_engine(be, golden, ckpt_rand)
+@pytest.mark.parametrize("k4_batch", [1, 0])
+def test_hmr_engine_vs_reference_module(be, ckpt_rand, k4_batch):
+    """Whole engine at batch 2 against the reference module's golden: with the single-launch 1x1 kernels at batch > 1
+    (k4_batch=1, the default) and with the tiled kernels only."""
+    be.lib.dyb_set_option(b"k4_batch", k4_batch)
+    try:
+        e = K.case_hmr_engine(be, golden, ckpt_rand)
+    finally:
+        be.lib.dyb_set_option(b"k4_batch", 1)
     print(e)
+
+
+@pytest.mark.parametrize("k4_batch", [1, 0])
+def test_batched_pairs_both_dispatches(be, k4_batch):
+    """The batch > 1 layer pairs / data-gradient + reduce pairs / bottlenecks through both dispatches (single-launch 1x1
+    kernels with per-image tiles, or tiled conv + statistics)."""
+    be.lib.dyb_set_option(b"k4_batch", k4_batch)
+    try:
+        r = K.case_layer_gnstats(be, 4, 14, 14, 256, 1024, 1, 1, 256, 1, 1, seed=11)
+        assert (r["nA"] == 7 * 32) == bool(k4_batch)             # 196 pixels -> 7 row tiles per image x 32 column tiles
+        K.case_layer_gnstats(be, 8, 28, 28, 512, 128, 1, 1, 128, 3, 1, seed=12)
+        K.case_layer_gnstats(be, 3, 7, 7, 512, 2048, 1, 1, 512, 1, 1, seed=13)
+        K.case_dgrad_gn_reduce(be, 14, 14, 1024, 256, False, True, seed=14, N=8)
+        K.case_dgrad_gn_reduce(be, 28, 28, 128, 512, True, False, seed=15, N=3)
+        K.case_bottleneck_fused(be, 8, 14, 14, 1024, 256, 1, False, seed=16)
+        K.case_bottleneck_fused(be, 2, 28, 28, 512, 256, 2, True, seed=17)
+    finally:
+        be.lib.dyb_set_option(b"k4_batch", 1)

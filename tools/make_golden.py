@@ -386,6 +386,13 @@ def g5so3(out):
     run_stream("so_inner3_frameonly", out, dict(frame_only, inner_step=3), 2, first_order=False)
 
 
+def g5fo3(out):
+    """The first-order twin of g5so3 alone (same call as in g5; regenerates g5_fo_inner3_frameonly incl. its g1_* keys)."""
+    frame_only = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0,
+                      use_motion=0, dynamic_boa=0, use_temporal_losses_upper=0)
+    run_stream("fo_inner3_frameonly", out, dict(frame_only, inner_step=3), 4)
+
+
 def g5_forced(out):
     # lr=3e-6 moves features[12] by <1e-7 in cosine, so the dynamic loop of
     # dynaboa_benchmark.py:161-192 never fires above; a negative threshold forces the branch
