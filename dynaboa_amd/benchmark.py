@@ -81,6 +81,10 @@ parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
                          'concurrently with the next adaptation step (same arithmetic, same results); 2 = also issue '
                          'them from a second host thread')
+parser.add_argument('--native_step', type=int, default=1, choices=[0, 1],
+                    help='1: configurations the native frame stepper covers (first order, frame-loss set; csrc/adapt_step.hip) '
+                         'run as ONE C call per frame - same kernels, same order, identical weights; 0: always the '
+                         'torch.autograd composition')
 parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
                     help='run inference() after every inner step like the reference (:142)')
 
@@ -140,10 +144,11 @@ class Adaptor(BaseAdaptor):
         self.pampjpe_all_lower = [[] for _ in range(self.options.inner_step)]
         self.history, self.kp2dlosses_lower, self.kp2dlosses_upper = {}, [], {}
         self._pending = []            # deferred metric records
+        self._native, self._native_why, self._nframes = None, None, nframes
         self._side, self._side_done, self._worker, self._last_fut = None, None, None, None
         if getattr(self.options, "overlap_metrics", 0) and self.options.deferred_metrics and self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)
-            if getattr(self.options, "overlap_metrics", 0) >= 2:
+            if getattr(self.options, "overlap_metrics", 0) >= 2 and not self._native_ok():
                 self._worker = _SideWorker(self.device, self._side)
 
     # ------------------------------------------------------------------ side-stream plumbing
@@ -224,11 +229,60 @@ class Adaptor(BaseAdaptor):
         self.results = dict(mpjpe=mpjpe_all, pampjpe=pampjpe_all, pve=pve_all)
         return self.results
 
+    # ------------------------------------------------------------------ native frame stepper (csrc/adapt_step.hip)
+    def _native_ok(self):
+        """Whether frames of this run go through the native stepper (decided once per reset_records)."""
+        if self._native_why is None:
+            from . import native_step as NS
+            why = NS.supported(self.options) if getattr(self.options, "native_step", 1) else "native_step=0"
+            self._native_why = why or ""
+        return self._native_why == ""
+
+    def _adapt_native(self, batch):
+        from . import native_step as NS
+        o = self.options
+        if self._native is None:
+            self._native = NS.NativeStepper(self, self._nframes)
+        ns = self._native
+        K = o.inner_step
+        f, slot = ns.adapt_frame(batch, side_stream=self._side)
+        for i in range(K):
+            self.kp2dlosses_lower.append(ns.losses(f, i)[0])
+        log = self.fit_losses
+        for tag, lv in ((("ll", K - 1),) if K > 0 else ()) + (("ul", K),):
+            l4 = ns.losses(f, lv)
+            log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"] = l4[0], l4[1], l4[2]
+            log[f"{tag}/unlabelloss"] = log[f"{tag}/total"] = l4[3]
+        self.kp2dlosses_upper[self.global_step] = ns.losses(f, K)[0]
+        out = (None, None, None)
+        tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', 0)]
+        if not o.deferred_metrics:
+            ns.join()
+        for tag in tags:
+            v = ns.record_views(slot)
+            slot += 1
+            if o.deferred_metrics:
+                self._pending.append(dict(step=self.global_step, tag=tag, **v))
+                res = (v["mpjpe"], None, v["pve"])
+            else:
+                pa = pa_mpjpe_device(v["pred"], v["gt"]).cpu().numpy()
+                res = (v["mpjpe"].cpu().numpy() * 1000, pa * 1000, float(v["pve"]) * 1000)
+            if tag[0] == 'lower':
+                self.mpjpe_all_lower[tag[1]].append(res[0]); self.pampjpe_all_lower[tag[1]].append(res[1])
+            else:
+                out = res
+        if self.global_step < len(self.mpjpe_statistics):
+            self.mpjpe_statistics[self.global_step] = [out[0]]
+            self.pampjpe_statistics[self.global_step] = [out[1]]
+        return out
+
     # ------------------------------------------------------------------ the per-frame bilevel step
     def adaptation(self, batch):
         o = self.options
         image, gt_keypoints_2d = batch['image'], batch['smpl_j2d']
         self.save_hist(image, gt_keypoints_2d)
+        if self._native_ok():
+            return self._adapt_native(batch)
         if not o.use_boa:
             loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, None, self.model)
             self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
@@ -384,6 +438,8 @@ class Adaptor(BaseAdaptor):
 
     def flush_metrics(self):
         """Resolve deferred records: one Procrustes launch over every record, one device->host transfer of scalars."""
+        if self._native is not None:
+            self._native.join()
         if self._side is not None:
             self._join_side()
             self._side.synchronize()

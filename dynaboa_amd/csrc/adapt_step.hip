@@ -1,0 +1,475 @@
+// Native frame stepper: ONE C call per adapted frame.
+//
+// The per-frame bilevel schedule of reference dynaboa_benchmark.py:126-193 (Adaptor.adaptation) - clone, inner_step x
+// [lower-level loss -> learner.adapt -> inference], upper-level loss through the fast weights, zero_grad / backward /
+// Adam.step, inference - issued from C++ over the engine (hmr_engine.hip), the SMPL kernels (smpl_lbs.hip), the loss
+// head (losses.hip) and the flat-arena updates (optim.hip).  The Python Adaptor (dynaboa_amd/benchmark.py) stays the
+// surface; in the configurations this file covers it forwards a frame here instead of walking the same ~1700 launches
+// through torch.autograd + ctypes (9 ms of host time per frame there, ~2.5 us per launch here), which is also what
+// lets several independent sequence replicas share one GPU from separate host threads (dyb_stepper_* are re-entrant
+// per stepper: every stepper owns its workspace, events and streams' ordering).
+//
+// Same kernels, same order, same operands as the Python path => identical weights / Adam state (tests assert
+// bit-equality); the metric reductions (MPJPE / PVE means) are this file's own kernels and agree to rounding.
+//
+// First-order MAML only (reference base_adaptor.py:119 first_order=True): theta_fast_{k+1} = theta_fast_k - fastlr*g_k,
+// outer gradient = gradient of the upper-level loss AT the last fast weights (learn2learn clone() + adapt() with
+// first_order=True: SURVEY Appendix B).
+#include <math.h>
+#include <string.h>
+
+#include <string>
+
+#include "dyb_common.h"
+
+extern "C" {
+size_t dyb_hmr_param_floats(const void*);
+size_t dyb_hmr_act_floats(const void*);
+size_t dyb_hmr_workspace_bytes(const void*);
+long long dyb_hmr_act_offset_rotmat(const void*);
+long long dyb_hmr_act_offset_state(const void*);
+size_t dyb_lbs_saved_floats(int);
+size_t dyb_lbs_bwd_workspace_bytes(int);
+int dyb_lbs_fwd(const float* const*, const int* const*, const float*, int, const float*, float*, float*, float*, int, hipStream_t);
+int dyb_lbs_bwd(const float* const*, const int* const*, const float*, const float*, const float*, const float*, float*, float*, int,
+                int, void*, size_t, hipStream_t);
+int dyb_regress_joints(const float*, const float*, float*, int, int, hipStream_t);
+int dyb_rodrigues_fwd(const float*, float*, int, hipStream_t);
+int dyb_frame_losses(const float*, const float*, int, const float*, int, const float*, const float*, const float*, const float*,
+                     const float*, float, float, float, float*, float*, float*, int, float*, int, float*, int, void*, size_t,
+                     hipStream_t);
+int dyb_scale_add(const float*, const float*, const float*, float*, size_t, hipStream_t);
+int dyb_head_grad_combine(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                          const float*, const float*, float*, float*, int, hipStream_t);
+int dyb_fastweight_update(const float*, const float*, float*, float, size_t, hipStream_t);
+int dyb_adam_step(float*, const float*, float*, float*, float, float, float, float, float, size_t, hipStream_t);
+}
+
+#define STATE_LD 160
+#define NV 6890
+#define NJ 49
+#define RUN(x)                       \
+  do {                               \
+    int rc__ = (x);                  \
+    if (rc__ != DYB_OK) return rc__; \
+  } while (0)
+#define HIPOK(x)                                  \
+  do {                                            \
+    if ((x) != hipSuccess) return DYB_ERR_LAUNCH; \
+  } while (0)
+
+// ---- metric record of one inference() (reference dynaboa_benchmark.py:204-262) ----------------------------------------
+// pred17 / gt17m / gt17f: J_regressor_h36m @ vertices [B][17][3]; rec = pred14[B][14][3] | gt14[B][14][3] | mpjpe[B] | pve.
+// pred14 = joints[H36M_TO_J14] - joints[0] (pelvis), gt from the male or the female mesh by gender (:221-233);
+// mpjpe = mean_j |pred14 - gt14| (:236), pve = mean over batch and vertices of |gt_neutral - pred| (:244).
+// PA-MPJPE needs an SVD per sample and is evaluated over all records at once (dyb_pa_mpjpe) when they are read.
+__global__ __launch_bounds__(256) void metric_record_kernel(const float* __restrict__ pred17, const float* __restrict__ gt17m,
+                                                            const float* __restrict__ gt17f, const long long* __restrict__ gender,
+                                                            const int* __restrict__ j14, const float* __restrict__ pverts,
+                                                            const float* __restrict__ gverts, float* __restrict__ rec, int B) {
+  __shared__ float s_err[64 * 14];
+  __shared__ float s_red[4];
+  const int t = threadIdx.x;
+  float* pred14 = rec;
+  float* gt14 = rec + (size_t)B * 42;
+  float* mpjpe = rec + (size_t)B * 84;
+  float* pve = mpjpe + B;
+  for (int i = t; i < B * 14; i += 256) {
+    const int b = i / 14, j = i - b * 14, src = j14[j];
+    const float* g17 = (gender[b] == 1 ? gt17f : gt17m) + (size_t)b * 51;
+    const float* p17 = pred17 + (size_t)b * 51;
+    float e2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float p = p17[src * 3 + c] - p17[c], g = g17[src * 3 + c] - g17[c];
+      pred14[i * 3 + c] = p;
+      gt14[i * 3 + c] = g;
+      e2 += (p - g) * (p - g);
+    }
+    s_err[i] = sqrtf(e2);
+  }
+  float acc = 0.f;
+  const int nv = B * NV;
+  for (int i = t; i < nv; i += 256) {
+    const float dx = gverts[i * 3] - pverts[i * 3], dy = gverts[i * 3 + 1] - pverts[i * 3 + 1], dz = gverts[i * 3 + 2] - pverts[i * 3 + 2];
+    acc += sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  acc = dyb_wave_sum(acc);
+  if ((t & 63) == 0) s_red[t >> 6] = acc;
+  __syncthreads();
+  if (t < B) {
+    float s = 0.f;
+    for (int j = 0; j < 14; ++j) s += s_err[t * 14 + j];
+    mpjpe[t] = s / 14.f;
+  }
+  if (t == 0) pve[0] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)nv;
+}
+
+// ---- one forward (+ backward) of HMR -> SMPL -> loss head ---------------------------------------------------------------
+struct Pass {
+  float* acts;
+  char* ws;                 // engine workspace of the chain this pass runs on
+  float *verts, *joints, *saved;
+  float *losses, *drot_l, *dshape_l, *dcam_l, *djoints_l, *lws;      // dyb_frame_losses outputs
+  float *djoints, *drot_s, *dbetas_s;                                // gradient assembly
+  char* lbs_ws;
+  float *d_rot, *d_state;
+  float* pred17;
+};
+
+struct Stepper {
+  void* plan = nullptr;
+  int B = 1, H = 224, W = 224;
+  size_t n_params = 0, act_floats = 0, ws_bytes = 0, off_rot = 0, off_state = 0, lbs_saved = 0, lbs_wsb = 0;
+  // options (doubles: the Python floats, so host-side scalars round exactly as in dynaboa_amd/optim.py / maml.py)
+  int n_iter = 3, inner_step = 1, eval_lower = 1, use_side = 0, metrics = 1;
+  double lr = 3e-6, beta1 = 0.5, beta2 = 0.9, eps = 1e-8, fastlr = 8e-6, w2d = 10.0, wshape = 2e-6, wpose = 1e-4;
+  long long adam_t = 0;
+  // caller-owned state and tables (device pointers)
+  float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  const float* init_state = nullptr;
+  const float* smpl_f[3][7] = {};         // neutral, male, female: the dyb_lbs_fwd table order
+  const int* smpl_i[3][3] = {};
+  const float *gmm_means = nullptr, *gmm_prec = nullptr, *gmm_logw = nullptr, *j_h36m = nullptr;
+  const int* j14 = nullptr;
+  float *records = nullptr, *loss_log = nullptr;
+  int record_capacity = 0, loss_capacity = 0;
+  // workspace
+  char* wsp = nullptr;
+  size_t wsp_bytes = 0;
+  bool bound = false, fresh = true;
+  Pass main{}, fin{};
+  float *theta_fast = nullptr, *grads = nullptr;
+  float *gt_rot = nullptr, *gt_verts[3] = {}, *gt_joints = nullptr, *gt_saved = nullptr, *gt17[2] = {};
+  DybEvents* ev = nullptr;
+  hipEvent_t e_theta = nullptr, e_side = nullptr, e_gt = nullptr;
+  bool side_pending = false;
+  std::string err;
+};
+
+static size_t a64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+// carve (or, with base == nullptr, size) the workspace
+static size_t carve(Stepper& S, char* base) {
+  size_t off = 0;
+  auto take_f = [&](size_t nfloats) -> float* {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += a64(nfloats) * sizeof(float);
+    return p;
+  };
+  auto take_b = [&](size_t nbytes) -> char* {
+    char* p = base ? base + off : nullptr;
+    off += a64((nbytes + 3) / 4) * sizeof(float);
+    return p;
+  };
+  const size_t B = (size_t)S.B;
+  auto pass = [&](Pass& P, bool with_grad) {
+    P.acts = take_f(S.act_floats);
+    P.ws = take_b(S.ws_bytes);
+    P.verts = take_f(B * NV * 3);
+    P.joints = take_f(B * NJ * 3);
+    P.saved = take_f(S.lbs_saved);
+    P.pred17 = take_f(B * 51);
+    if (with_grad) {
+      P.losses = take_f(4);
+      P.drot_l = take_f(B * 216);
+      P.dshape_l = take_f(B * 10);
+      P.dcam_l = take_f(B * 3);
+      P.djoints_l = take_f(B * NJ * 3);
+      P.lws = take_f(B * 4);
+      P.djoints = take_f(B * NJ * 3);
+      P.drot_s = take_f(B * 216);
+      P.dbetas_s = take_f(B * 10);
+      P.lbs_ws = take_b(S.lbs_wsb);
+      P.d_rot = take_f(B * 216);
+      P.d_state = take_f(B * STATE_LD);
+    }
+  };
+  pass(S.main, true);
+  pass(S.fin, false);
+  S.theta_fast = take_f(S.n_params);
+  S.grads = take_f(S.n_params);
+  S.gt_rot = take_f(B * 24 * 9);
+  for (int i = 0; i < 3; ++i) S.gt_verts[i] = take_f(B * NV * 3);
+  S.gt_joints = take_f(B * NJ * 3);
+  S.gt_saved = take_f(S.lbs_saved);
+  S.gt17[0] = take_f(B * 51);
+  S.gt17[1] = take_f(B * 51);
+  return off;
+}
+
+extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
+  DYB_REQUIRE(plan && out && B > 0 && B <= 64, DYB_ERR_ARG);
+  Stepper* S = new Stepper();
+  S->plan = plan; S->B = B; S->H = H; S->W = W;
+  S->n_params = dyb_hmr_param_floats(plan);
+  S->act_floats = dyb_hmr_act_floats(plan);
+  S->ws_bytes = dyb_hmr_workspace_bytes(plan);
+  S->off_rot = (size_t)dyb_hmr_act_offset_rotmat(plan);
+  S->off_state = (size_t)dyb_hmr_act_offset_state(plan);
+  S->lbs_saved = dyb_lbs_saved_floats(B);
+  S->lbs_wsb = dyb_lbs_bwd_workspace_bytes(B);
+  S->ev = dyb_hmr_events_create(plan);
+  if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess) {
+    delete S;
+    return DYB_ERR_LAUNCH;
+  }
+  *out = S;
+  return DYB_OK;
+}
+extern "C" void dyb_stepper_destroy(void* stepper) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  if (!S) return;
+  dyb_hmr_events_destroy(S->ev);
+  if (S->e_theta) (void)hipEventDestroy(S->e_theta);
+  if (S->e_side) (void)hipEventDestroy(S->e_side);
+  if (S->e_gt) (void)hipEventDestroy(S->e_gt);
+  delete S;
+}
+
+// ---- string-keyed setters (the whole configuration surface of the stepper; unknown key => DYB_ERR_ARG) -----------------
+extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S && key, DYB_ERR_ARG);
+  const std::string k(key);
+  if (k == "n_iter") S->n_iter = (int)v;
+  else if (k == "inner_step") S->inner_step = (int)v;
+  else if (k == "eval_lower") S->eval_lower = (int)v;
+  else if (k == "use_side") S->use_side = (int)v;
+  else if (k == "metrics") S->metrics = (int)v;
+  else if (k == "adam_step") S->adam_t = v;
+  else if (k == "record_capacity") S->record_capacity = (int)v;
+  else if (k == "loss_capacity") S->loss_capacity = (int)v;
+  else return DYB_ERR_ARG;
+  return DYB_OK;
+}
+extern "C" int dyb_stepper_set_f(void* stepper, const char* key, double v) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S && key, DYB_ERR_ARG);
+  const std::string k(key);
+  if (k == "lr") S->lr = v;
+  else if (k == "beta1") S->beta1 = v;
+  else if (k == "beta2") S->beta2 = v;
+  else if (k == "eps") S->eps = v;
+  else if (k == "fastlr") S->fastlr = v;
+  else if (k == "s2dloss_weight") S->w2d = v;
+  else if (k == "shape_prior_weight") S->wshape = v;
+  else if (k == "pose_prior_weight") S->wpose = v;
+  else return DYB_ERR_ARG;
+  return DYB_OK;
+}
+// "smpl_<neutral|male|female>_<0..6>" = the seven float tables of dyb_lbs_fwd, "smpli_<...>_<0..2>" the three int tables
+extern "C" int dyb_stepper_set_p(void* stepper, const char* key, const void* p) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S && key, DYB_ERR_ARG);
+  const std::string k(key);
+  static const char* const which[3] = {"neutral", "male", "female"};
+  if (k == "theta") S->theta = (float*)p;
+  else if (k == "adam_m") S->adam_m = (float*)p;
+  else if (k == "adam_v") S->adam_v = (float*)p;
+  else if (k == "init_state") S->init_state = (const float*)p;
+  else if (k == "gmm_means") S->gmm_means = (const float*)p;
+  else if (k == "gmm_precisions") S->gmm_prec = (const float*)p;
+  else if (k == "gmm_log_weights") S->gmm_logw = (const float*)p;
+  else if (k == "j_regressor_h36m") S->j_h36m = (const float*)p;
+  else if (k == "j14") S->j14 = (const int*)p;
+  else if (k == "records") S->records = (float*)p;
+  else if (k == "loss_log") S->loss_log = (float*)p;
+  else {
+    for (int g = 0; g < 3; ++g) {
+      const std::string pf = std::string("smpl_") + which[g] + "_", pi = std::string("smpli_") + which[g] + "_";
+      if (k.compare(0, pf.size(), pf) == 0 && k.size() == pf.size() + 1 && k.back() >= '0' && k.back() <= '6') {
+        S->smpl_f[g][k.back() - '0'] = (const float*)p;
+        return DYB_OK;
+      }
+      if (k.compare(0, pi.size(), pi) == 0 && k.size() == pi.size() + 1 && k.back() >= '0' && k.back() <= '2') {
+        S->smpl_i[g][k.back() - '0'] = (const int*)p;
+        return DYB_OK;
+      }
+    }
+    return DYB_ERR_ARG;
+  }
+  return DYB_OK;
+}
+extern "C" long long dyb_stepper_get_i(const void* stepper, const char* key) {
+  const Stepper* S = reinterpret_cast<const Stepper*>(stepper);
+  if (!S || !key) return -1;
+  const std::string k(key);
+  if (k == "adam_step") return S->adam_t;
+  if (k == "record_floats") return (long long)a64((size_t)S->B * 85 + 1);
+  if (k == "loss_floats") return 4 * (long long)(S->inner_step + 1);
+  return -1;
+}
+extern "C" size_t dyb_stepper_workspace_bytes(void* stepper) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  if (!S) return 0;
+  Stepper tmp = *S;
+  return carve(tmp, nullptr);
+}
+// `ws` must stay valid (and untouched by others) while the stepper lives; its gradient staging is zeroed here, on `stream`.
+extern "C" int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes, hipStream_t st) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S && ws, DYB_ERR_ARG);
+  const size_t need = carve(*S, nullptr);
+  DYB_REQUIRE(bytes >= need, DYB_ERR_WORKSPACE);
+  S->wsp = reinterpret_cast<char*>(ws);
+  S->wsp_bytes = bytes;
+  carve(*S, S->wsp);
+  // the engine overwrites every tensor span of the gradient arena and only columns 144..156 of d_state: pads stay zero
+  HIPOK(hipMemsetAsync(S->grads, 0, S->n_params * sizeof(float), st));
+  HIPOK(hipMemsetAsync(S->main.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+  S->bound = true;
+  return DYB_OK;
+}
+
+static int check_ready(const Stepper& S) {
+  DYB_REQUIRE(S.bound && S.theta && S.adam_m && S.adam_v && S.init_state && S.gmm_means && S.gmm_prec && S.gmm_logw, DYB_ERR_ARG);
+  for (int i = 0; i < 7; ++i) DYB_REQUIRE(S.smpl_f[0][i], DYB_ERR_ARG);
+  for (int i = 0; i < 3; ++i) DYB_REQUIRE(S.smpl_i[0][i], DYB_ERR_ARG);
+  if (S.metrics) {
+    DYB_REQUIRE(S.j_h36m && S.j14 && S.records, DYB_ERR_ARG);
+    for (int g = 1; g < 3; ++g) {
+      for (int i = 0; i < 7; ++i) DYB_REQUIRE(S.smpl_f[g][i], DYB_ERR_ARG);
+      for (int i = 0; i < 3; ++i) DYB_REQUIRE(S.smpl_i[g][i], DYB_ERR_ARG);
+    }
+  }
+  DYB_REQUIRE(S.inner_step >= 0 && S.inner_step <= 16 && S.n_iter >= 1 && S.n_iter <= 3, DYB_ERR_UNSUPPORTED);
+  return DYB_OK;
+}
+
+// HMR forward at `theta` -> rotmat / shape / cam in the pass's arena -> SMPL (neutral) vertices + 49 joints
+static int pass_forward(Stepper& S, Pass& P, const float* theta, const float* image, hipStream_t st) {
+  RUN(dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st));
+  const float* rot = P.acts + S.off_rot;
+  const float* state = P.acts + S.off_state;
+  return dyb_lbs_fwd(S.smpl_f[0], S.smpl_i[0], state + 144, STATE_LD, rot, P.verts, P.joints, P.saved, S.B, st);
+}
+// frame-loss head (reference base_adaptor.py:229-240 / :279-289): value + gradient in one launch
+static int pass_frame_head(Stepper& S, Pass& P, const float* kp2d, hipStream_t st) {
+  const float* rot = P.acts + S.off_rot;
+  const float* state = P.acts + S.off_state;
+  return dyb_frame_losses(rot, state + 144, STATE_LD, state + 154, STATE_LD, P.joints, kp2d, S.gmm_means, S.gmm_prec, S.gmm_logw,
+                          (float)S.w2d, (float)S.wshape, (float)S.wpose, P.losses, P.drot_l, P.dshape_l, 10, P.dcam_l, 3, P.djoints_l,
+                          S.B, P.lws, (size_t)S.B * 16, st);
+}
+// gradient of the pass's loss total w.r.t. `theta` into `grads` (the same five C calls as fused_level._LevelFunction.backward)
+static int pass_backward(Stepper& S, Pass& P, const float* theta, float* grads, hipStream_t st, hipStream_t aux) {
+  RUN(dyb_scale_add(nullptr, P.djoints_l, nullptr, P.djoints, (size_t)S.B * NJ * 3, st));
+  RUN(dyb_lbs_bwd(S.smpl_f[0], S.smpl_i[0], P.acts + S.off_rot, P.saved, P.djoints, nullptr, P.drot_s, P.dbetas_s, 10, S.B, P.lbs_ws,
+                  S.lbs_wsb, st));
+  RUN(dyb_head_grad_combine(nullptr, P.drot_l, P.drot_s, nullptr, P.dshape_l, P.dbetas_s, nullptr, P.dcam_l, nullptr, P.d_rot,
+                            P.d_state, S.B, st));
+  return dyb_hmr_backward_ev(S.plan, theta, P.acts, P.d_rot, P.d_state, S.n_iter, grads, P.ws, S.ws_bytes, st, aux, S.ev);
+}
+// ground-truth side of the metrics (depends on the batch only): male / female / neutral meshes from the axis-angle pose
+static int gt_meshes(Stepper& S, const float* gt_pose, const float* gt_betas, hipStream_t st) {
+  RUN(dyb_rodrigues_fwd(gt_pose, S.gt_rot, S.B * 24, st));
+  for (int g = 0; g < 3; ++g)
+    RUN(dyb_lbs_fwd(S.smpl_f[g], S.smpl_i[g], gt_betas, 10, S.gt_rot, S.gt_verts[g], S.gt_joints, S.gt_saved, S.B, st));
+  RUN(dyb_regress_joints(S.j_h36m, S.gt_verts[1], S.gt17[0], 17, S.B, st));
+  return dyb_regress_joints(S.j_h36m, S.gt_verts[2], S.gt17[1], 17, S.B, st);
+}
+static int record_metrics(Stepper& S, Pass& P, const long long* gender, int slot, hipStream_t st) {
+  DYB_REQUIRE(slot >= 0 && slot < S.record_capacity, DYB_ERR_ARG);
+  RUN(dyb_regress_joints(S.j_h36m, P.verts, P.pred17, 17, S.B, st));
+  float* rec = S.records + (size_t)slot * a64((size_t)S.B * 85 + 1);
+  hipLaunchKernelGGL(metric_record_kernel, dim3(1), dim3(256), 0, st, P.pred17, S.gt17[0], S.gt17[1], gender, S.j14, P.verts,
+                     S.gt_verts[0], rec, S.B);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// One adapted frame.  image [B][3][H][W], kp2d [B][49][3]; gt_pose [B][72] / gt_betas [B][10] / gender [B] (int64) feed the
+// metric records only (NULL with metrics = 0).  Records: inner_step (eval_lower) + 1 slots starting at record_slot, in
+// schedule order - after inner step 0, 1, ..., then the final one; losses: loss_slot*(inner_step+1) 4-vectors
+// (s2d, shape prior, pose prior, weighted total) per level.  side (may be NULL): stream for the final no-grad forward and
+// its metrics, overlapped with the next frame's first level; the call orders the weight hazards itself.
+extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose,
+                                       const float* gt_betas, const long long* gender, int record_slot, int loss_slot,
+                                       hipStream_t st, hipStream_t aux, hipStream_t side) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && image && kp2d, DYB_ERR_ARG);
+  Stepper& S = *Sp;
+  RUN(check_ready(S));
+  const bool metrics = S.metrics != 0;
+  DYB_REQUIRE(!metrics || (gt_pose && gt_betas && gender), DYB_ERR_ARG);
+  if (!S.use_side || side == st) side = nullptr;
+  const int K = S.inner_step;
+  const size_t n = S.n_params;
+  float* losslog = (S.loss_log && loss_slot >= 0 && loss_slot < S.loss_capacity) ? S.loss_log + (size_t)loss_slot * 4 * (K + 1) : nullptr;
+  int slot = record_slot;
+
+  if (metrics) {
+    // the ground-truth meshes only feed metric kernels: on the side stream when there is one (behind the previous frame's
+    // tail, which still reads the buffers)
+    hipStream_t gs = side ? side : st;
+    RUN(gt_meshes(S, gt_pose, gt_betas, gs));
+    if (side) {
+      HIPOK(hipEventRecord(S.e_gt, side));
+      HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
+    }
+  }
+  const float* cur = S.theta;                    // clone(): the learner starts as an alias of theta
+  for (int i = 0; i <= K; ++i) {                 // i < K: lower level + adapt; i == K: upper level
+    RUN(pass_forward(S, S.main, cur, image, st));
+    RUN(pass_frame_head(S, S.main, kp2d, st));
+    if (losslog) HIPOK(hipMemcpyAsync(losslog + 4 * i, S.main.losses, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
+    if (metrics && S.eval_lower && i > 0) RUN(record_metrics(S, S.main, gender, slot++, st));
+    RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
+    if (i < K) {
+      RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, n, st));
+      cur = S.theta_fast;
+    }
+  }
+  // optimizer.step(): theta is about to change in place - the previous frame's tail on the side stream reads it
+  if (S.side_pending) {
+    HIPOK(hipStreamWaitEvent(st, S.e_side, 0));
+    S.side_pending = false;
+  }
+  S.adam_t += 1;
+  const double t = (double)S.adam_t;
+  const double step_size = S.lr / (1.0 - pow(S.beta1, t));
+  const double bc2_sqrt = sqrt(1.0 - pow(S.beta2, t));
+  RUN(dyb_adam_step(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, (float)step_size, (float)bc2_sqrt,
+                    (float)S.eps, n, st));
+  // final inference() with the updated weights (dynaboa_benchmark.py:156)
+  hipStream_t fs = st;
+  if (side) {
+    HIPOK(hipEventRecord(S.e_theta, st));
+    HIPOK(hipStreamWaitEvent(side, S.e_theta, 0));
+    fs = side;
+  }
+  RUN(pass_forward(S, S.fin, S.theta, image, fs));
+  if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, fs));
+  if (side) {
+    HIPOK(hipEventRecord(S.e_side, side));
+    S.side_pending = true;
+  }
+  return DYB_OK;
+}
+// make `st` wait for everything the stepper has in flight on its side stream (before reading records / the final prediction)
+extern "C" int dyb_stepper_join(void* stepper, hipStream_t st) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S, DYB_ERR_ARG);
+  if (S->side_pending) {
+    HIPOK(hipStreamWaitEvent(st, S->e_side, 0));
+    S->side_pending = false;
+  }
+  return DYB_OK;
+}
+// device locations of the last final-inference outputs: which = 0 rotmat [B][24][9], 1 state [B][160] (shape 144.., cam 154..),
+// 2 vertices [B][6890][3], 3 joints [B][49][3]
+extern "C" const float* dyb_stepper_output(const void* stepper, int which) {
+  const Stepper* S = reinterpret_cast<const Stepper*>(stepper);
+  if (!S || !S->bound) return nullptr;
+  switch (which) {
+    case 0: return S->fin.acts + S->off_rot;
+    case 1: return S->fin.acts + S->off_state;
+    case 2: return S->fin.verts;
+    case 3: return S->fin.joints;
+    default: return nullptr;
+  }
+}

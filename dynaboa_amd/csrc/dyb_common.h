@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #define DYB_OK 0
 #define DYB_ERR_ARG (-1)      // bad pointer / dimension
 #define DYB_ERR_LAUNCH (-2)   // hipGetLastError() after a launch
@@ -75,3 +77,16 @@ int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);
 int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, const float* tail,
                          int tail_ld, int tail_cols, int tail_dst_col, hipStream_t st);
+
+// ---- engine internals used by the native frame stepper (adapt_step.hip) ---------------------------------------------
+// cross-stream events of ONE backward chain (per conv layer + the final join)
+struct DybEvents {
+  std::vector<hipEvent_t> dy;
+  hipEvent_t join = nullptr;
+};
+DybEvents* dyb_hmr_events_create(const void* plan);
+void dyb_hmr_events_destroy(DybEvents* e);
+int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, const float* init_state, int n_iter, float* acts,
+                          void* ws, size_t ws_bytes, hipStream_t st);
+int dyb_hmr_backward_ev(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
+                        int n_iter, float* grads, void* ws, size_t ws_bytes, hipStream_t st, hipStream_t aux, const DybEvents* ev);

@@ -121,9 +121,10 @@ struct HmrPlan {
   int graph_mode;
   int fold_in_reduce;          // leave data-gradient split-K slabs for the next GroupNorm-backward reduce to fold
   long g_hits, g_eager, g_captures, g_fail_begin, g_fail_body, g_fail_end, g_fail_inst, g_fail_launch;
-  // cross-stream ordering for the weight-gradient convolutions (created on first use)
-  std::vector<hipEvent_t> ev_dy;
-  hipEvent_t ev_join;
+  // cross-stream ordering for the weight-gradient convolutions (created on first use): the plan's own set serves the
+  // dyb_hmr_backward entry point; a caller that runs several backward chains of one plan concurrently (replica
+  // streams of the native frame stepper) brings one set per chain (dyb_hmr_events_create)
+  DybEvents ev;
   bool events_ready;
   std::unordered_map<GKey, GEntry, GKeyHash> gfwd, gbwd;
   // one plan serves every stream / host thread of the process (metric worker, replica threads): the lazily created
@@ -265,22 +266,44 @@ extern "C" void dyb_hmr_plan_destroy(void* plan) {
   HmrPlan* P = reinterpret_cast<HmrPlan*>(plan);
   if (!P) return;
   if (P->events_ready) {
-    for (hipEvent_t e : P->ev_dy) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(P->ev_join);
+    for (hipEvent_t e : P->ev.dy) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(P->ev.join);
   }
   for (auto& kv : P->gfwd) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   for (auto& kv : P->gbwd) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   delete P;
 }
+#define RUN_RC(x)                \
+  do {                           \
+    int rc__ = (x);              \
+    if (rc__ != DYB_OK) return rc__; \
+  } while (0)
+static int fill_events(const HmrPlan& P, DybEvents& e) {
+  e.dy.resize(P.convs.size());
+  for (size_t i = 0; i < P.convs.size(); ++i)
+    if (hipEventCreateWithFlags(&e.dy[i], hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
+  if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
+  return DYB_OK;
+}
 static int ensure_events(HmrPlan& P) {
   std::lock_guard<std::mutex> lock(P.mu);
   if (P.events_ready) return DYB_OK;
-  P.ev_dy.resize(P.convs.size());
-  for (size_t i = 0; i < P.convs.size(); ++i)
-    if (hipEventCreateWithFlags(&P.ev_dy[i], hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
-  if (hipEventCreateWithFlags(&P.ev_join, hipEventDisableTiming) != hipSuccess) return DYB_ERR_LAUNCH;
+  RUN_RC(fill_events(P, P.ev));
   P.events_ready = true;
   return DYB_OK;
+}
+DybEvents* dyb_hmr_events_create(const void* plan) {
+  const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
+  if (!P) return nullptr;
+  DybEvents* e = new DybEvents();
+  if (fill_events(*P, *e) != DYB_OK) { delete e; return nullptr; }
+  return e;
+}
+void dyb_hmr_events_destroy(DybEvents* e) {
+  if (!e) return;
+  for (hipEvent_t x : e->dy) (void)hipEventDestroy(x);
+  (void)hipEventDestroy(e->join);
+  delete e;
 }
 extern "C" size_t dyb_hmr_param_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->n_params; }
 extern "C" size_t dyb_hmr_act_floats(const void* plan) { return reinterpret_cast<const HmrPlan*>(plan)->act_floats; }
@@ -611,7 +634,32 @@ static int layer_dgrad_k4(HmrPlan& P, int ci, int pi, const float* params, const
 // aux_stream (may be NULL): a second stream the weight-gradient convolutions are issued on; the call
 // returns with `stream` already waiting for them, so callers keep ordering on `stream` only.
 static int backward_body(HmrPlan& P, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
-                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux);
+                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E);
+
+// the same call with the caller's own event set and no graph cache: what the native frame stepper issues (several chains
+// of one plan may be in flight on different streams, each with its own workspace and events)
+int dyb_hmr_backward_ev(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
+                        int n_iter, float* grads, void* ws, size_t ws_bytes, hipStream_t st, hipStream_t aux, const DybEvents* ev) {
+  HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && acts && d_rotmat && d_state && grads && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(ws_bytes >= Pp->ws_total, DYB_ERR_WORKSPACE);
+  if (aux == st || !ev) aux = nullptr;
+  WsCarve w = carve(*Pp, ws);
+  static const DybEvents none;
+  return backward_body(*Pp, params, acts, d_rotmat, d_state, n_iter, grads, w, st, aux, ev ? *ev : none);
+}
+// forward without the graph cache (same reason)
+int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, const float* init_state, int n_iter, float* acts,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+  HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && image && init_state && acts && ws, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(ws_bytes >= Pp->ws_total && Pp->featHW == 49, DYB_ERR_WORKSPACE);
+  WsCarve w = carve(*Pp, ws);
+  RUN(dyb_nchw3_to_nhwc4(image, acts + Pp->a_x4, Pp->B, Pp->H, Pp->W, st));
+  return forward_body(*Pp, params, init_state, n_iter, acts, w, st);
+}
 
 extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* acts, const float* d_rotmat,
                                 const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes,
@@ -627,11 +675,11 @@ extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* ac
   GKey key{{(uintptr_t)params, (uintptr_t)acts, (uintptr_t)d_rotmat, (uintptr_t)d_state, (uintptr_t)grads, (uintptr_t)ws,
             (uintptr_t)st, (uintptr_t)aux, (uintptr_t)n_iter, 0}};
   return run_cached(P, P.gbwd, key, st,
-                    [&]() { return backward_body(P, params, acts, d_rotmat, d_state, n_iter, grads, w, st, aux); });
+                    [&]() { return backward_body(P, params, acts, d_rotmat, d_state, n_iter, grads, w, st, aux, P.ev); });
 }
 
 static int backward_body(HmrPlan& P, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
-                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux) {
+                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E) {
   const int B = P.B;
   float* d_st[MAX_ITER + 1];
   float *d_h2[MAX_ITER], *d_h1[MAX_ITER];
@@ -689,7 +737,7 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
     const float *dm3 = nullptr, *dm2 = nullptr, *dm1 = nullptr, *dmd = nullptr;
     Pending p3, p2, pout;
     bool k4 = false;
-    hipEvent_t ev = aux ? P.ev_dy[b.c1] : nullptr;      // rides on the block's last reduce
+    hipEvent_t ev = aux ? E.dy[b.c1] : nullptr;      // rides on the block's last reduce
     // out = relu(gn3(conv3(a2)) + res)
     if (bs.reduced[b.c3]) {            // done by the K4 data gradient of the next block's conv1
       dm3 = w.dy + P.convs[b.c3].dy;
@@ -740,11 +788,11 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), spare, B, stem.Ho, stem.Wo, stem.K, st));
   const float* dm0;
   RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, nullptr, plain(spare), 1, &dm0, w, st, jobs,
-                   aux ? P.ev_dy[0] : nullptr));
-  if (aux) RUN(flush_wgrads(P, jobs_store, P.ev_dy[0], params, acts, grads, w, aux));
+                   aux ? E.dy[0] : nullptr));
+  if (aux) RUN(flush_wgrads(P, jobs_store, E.dy[0], params, acts, grads, w, aux));
   if (aux) {
-    if (hipEventRecord(P.ev_join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
-    if (hipStreamWaitEvent(st, P.ev_join, 0) != hipSuccess) return DYB_ERR_LAUNCH;
+    if (hipEventRecord(E.join, aux) != hipSuccess) return DYB_ERR_LAUNCH;
+    if (hipStreamWaitEvent(st, E.join, 0) != hipSuccess) return DYB_ERR_LAUNCH;
   }
   return DYB_OK;
 }

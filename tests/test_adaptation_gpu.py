@@ -460,3 +460,45 @@ def test_second_order_inner3_matches_reference_second_order():
             print("SO inner3 grad-norm error: median %.2e max %.2e; FO-vs-SO gap: median %.2e" % (np.median(err_so), err_so.max(), np.median(gap)))
             assert np.median(err_so) < 1e-2 and err_so.max() < 5e-2
             assert np.median(err_so) < 0.1 * np.median(gap)
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_native_stepper_is_bit_identical_to_autograd_path(overlap):
+    """One C call per frame (csrc/adapt_step.hip, the default for the frame-loss configurations) against the
+    torch.autograd composition of the same kernels on the 3-inner-step stream, with and without the side stream for
+    the final inference: identical weights / Adam state, metric records equal to rounding."""
+    from dynaboa_amd import assets
+    frames = [{k: v.to("cuda:0") for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(4)]
+    opts, ident = STREAMS["fo_inner3_frameonly"]
+    outs = []
+    for native in (1, 0):
+        ad, _ = make_adaptor(dict(opts, native_step=native, overlap_metrics=overlap), ident, deferred=1)
+        res = ad.excute(frames, nframes=4)
+        assert (ad._native is not None) == bool(native)
+        st = ad.optimizer.state[ad.model.module.theta]
+        recs = [(r["step"], r["tag"], float(np.ravel(r["mpjpe"])[0]), float(np.ravel(r["pampjpe"])[0]), r["pve"]) for r in ad.metric_records]
+        outs.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"], res, recs,
+                     {k: float(v) for k, v in ad.last_summaries.items()}))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] == 4
+    assert len(a[5]) == len(b[5]) == 16
+    for x, y in zip(a[5], b[5]):
+        assert x[:2] == y[:2]
+        np.testing.assert_allclose(x[2:], y[2:], rtol=2e-5)
+    for k in a[6]:
+        assert abs(a[6][k] - b[6][k]) <= 1e-6 * abs(b[6][k]), k
+
+
+def test_native_stepper_immediate_metrics_and_batch():
+    """deferred_metrics=0 (values returned per frame like the reference) and batch 2 through the native stepper."""
+    from dynaboa_amd import assets
+    frames = [{k: v.to("cuda:0") for k, v in assets.make_frame(s, 2, seed=22).items()} for s in range(2)]
+    outs = []
+    for native in (1, 0):
+        ad, _ = make_adaptor(dict(FRAME_ONLY, inner_step=2, batch_size=2, native_step=native), False, deferred=0)
+        res = ad.excute(frames, nframes=2)
+        outs.append((ad.model.module.theta.detach().clone(), res, ad.mpjpe_all_lower))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in ("mpjpe", "pampjpe", "pve"):
+        np.testing.assert_allclose(np.ravel(np.array(outs[0][1][k], np.float64)), np.ravel(np.array(outs[1][1][k], np.float64)), rtol=2e-5)
+    np.testing.assert_allclose(np.ravel(np.array(outs[0][2], np.float64)), np.ravel(np.array(outs[1][2], np.float64)), rtol=2e-5)

@@ -182,3 +182,44 @@ def test_full_frame_on_emulator_matches_reference(emu_lib):
         r, s, c = ad.model(batch["image"])
     assert rel_err(r.numpy(), g["pred0_rotmat"]) < 1e-3 and rel_err(c.numpy(), g["pred0_cam"]) < 1e-3
     assert float((ad.model.module.theta.detach() - theta0).abs().max()) > 0
+
+
+@pytest.mark.slow
+def test_native_stepper_is_bit_identical_to_autograd_path(emu_lib):
+    """csrc/adapt_step.hip (one C call per frame) against the torch.autograd composition of the same kernels on the
+    emulator: weights and Adam moments must be IDENTICAL, metric records / logged losses equal to rounding."""
+    from dynaboa_amd import assets
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    frames = [assets.make_frame(0, 1, seed=22)]
+    outs = []
+    for native in (1, 0):
+        o = DB.frame_only_options(inner_step=1)
+        o.native_step, o.deferred_metrics = native, 1
+        ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True, randomize_norm=True), device="cpu")
+        res = ad.excute(frames, nframes=1)
+        assert (ad._native is not None) == bool(native)
+        st = ad.optimizer.state[ad.model.module.theta]
+        outs.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"], res,
+                     ad.metric_records, {k: float(v) for k, v in ad.last_summaries.items()}))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] == 1
+    for k in ("mpjpe", "pampjpe", "pve"):
+        np.testing.assert_allclose(np.ravel(np.array(a[4][k], np.float64)), np.ravel(np.array(b[4][k], np.float64)), rtol=1e-5)
+    assert [(r["step"], r["tag"]) for r in a[5]] == [(r["step"], r["tag"]) for r in b[5]] == [(0, ('lower', 0)), (0, ('final', 0))]
+    for x, y in zip(a[5], b[5]):
+        np.testing.assert_allclose(np.ravel(x["mpjpe"]), np.ravel(y["mpjpe"]), rtol=1e-5)
+        np.testing.assert_allclose(np.ravel(x["pampjpe"]), np.ravel(y["pampjpe"]), rtol=1e-5)
+    assert a[6].keys() == b[6].keys()
+    for k in a[6]:
+        assert a[6][k] == b[6][k], k
+    g = golden("g5_fo_inner1_frameonly_identity.npz")
+    assert abs(a[6]["ul/total"] - g["upper_loss"][0]) < 1e-4 * abs(g["upper_loss"][0])
+
+
+def test_native_stepper_coverage_rules(emu_lib):
+    from dynaboa_amd import benchmark as DB, native_step as NS
+    assert NS.supported(DB.frame_only_options(inner_step=3)) is None
+    assert NS.supported(DB.parser.parse_args([])) is not None                       # the full default term set: autograd path
+    assert NS.supported(DB.frame_only_options(second_order=1)) == "second order"
+    assert NS.supported(DB.frame_only_options(share_forwards=0)) is not None
