@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._abi import check
-from .hmr import aux_stream_of, get_layout, stream_of
+from .hmr import get_layout, stream_of
 
 
 def supported(o) -> Optional[str]:
@@ -96,6 +96,9 @@ class NativeStepper:
         check(lib.dyb_stepper_bind_workspace(h, self.ws.data_ptr(), nbytes, stream_of(theta)), "dyb_stepper_bind_workspace")
         self.frame = 0
         self._theta = theta
+        # the weight-gradient stream is this stepper's own: several steppers (sequence replicas on one GPU) must not
+        # serialise on one shared auxiliary stream
+        self._aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
     def __del__(self):
         try:
@@ -121,7 +124,8 @@ class NativeStepper:
                 if t.is_cuda:
                     t.record_stream(side_stream)
         check(self.lib.dyb_stepper_adapt_frame(self.h, img.data_ptr(), kp.data_ptr(), pose.data_ptr(), betas.data_ptr(), gender.data_ptr(),
-                                               slot0, f, stream_of(self._theta), aux_stream_of(self._theta), side), "dyb_stepper_adapt_frame")
+                                               slot0, f, stream_of(self._theta), self._aux.cuda_stream if self._aux is not None else None, side),
+              "dyb_stepper_adapt_frame")
         self._adam["step"] = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
         self.frame += 1
         return f, slot0
