@@ -200,60 +200,38 @@ def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
 
 
 def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, dist=None, **kw):
-    """S independent sequence replicas on ONE GPU (the shard axis of SURVEY 8e inside a device: every replica owns its
-    weights, Adam state, stepper workspace and streams and walks its own frames; nothing is shared but the tables).  One
-    host thread per replica - the native stepper spends a frame inside a single C call with the GIL released - between a
-    barrier and a device synchronise on both sides.  -> frames/s over all replicas."""
-    import threading
-    from dynaboa_amd import assets
-    ads, frs, streams = [], [], []
-    for r in range(S):
-        ad = build_adaptor(device, batch, inner_step, **kw)
-        fr = [{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + (r + 1) * 7_000 + s, batch, seed=22).items()}
-              for s in range(warmup + steps)]
-        ad.reset_records(warmup + steps)
-        ads.append(ad); frs.append(fr); streams.append(torch.cuda.Stream(device=device))
-    errs = []
+    """S independent sequence replicas on ONE GPU (the shard axis of SURVEY 8e inside a device): every replica owns its
+    weights, Adam state, workspace and records and walks its own frames; the native stepper issues ONE chain of launches
+    per frame step, each launch covering all replicas (replica = a grid dimension, csrc/dyb_common.h) - per-replica results
+    are bit-identical to running alone (tests).  -> frames/s over all replicas, same clock discipline as the main run."""
+    from dynaboa_amd import assets, native_step as NS
+    ads = [build_adaptor(device, batch, inner_step, overlap=0, **kw) for _ in range(S)]
+    frs = [[{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + (r + 1) * 7_000 + s, batch, seed=22).items()}
+            for s in range(warmup + steps)] for r in range(S)]
+    grp = NS.ReplicaGroup(ads, warmup + steps)
+    stream = torch.cuda.Stream(device=device)
 
-    def work(r, lo, hi, flush):
-        try:
-            torch.cuda.set_device(device)
-            ad = ads[r]
-            with torch.cuda.stream(streams[r]):
-                for s in range(lo, hi):
-                    ad.global_step = s
-                    ad.fit_losses = {}
-                    ad.model.eval()
-                    ad.adaptation(frs[r][s])
-                if flush:
-                    ad.flush_metrics()
-        except BaseException as e:      # noqa: BLE001
-            errs.append(e)
-
-    def phase(lo, hi, flush):
-        th = [threading.Thread(target=work, args=(r, lo, hi, flush)) for r in range(S)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
+    def phase(lo, hi):
+        with torch.cuda.stream(stream):
+            for s in range(lo, hi):
+                grp.step([frs[r][s] for r in range(S)], s)
+            return grp.flush_metrics()
     torch.cuda.synchronize()
-    phase(0, warmup, True)
+    phase(0, warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    phase(warmup, warmup + steps, True)
+    metrics = phase(warmup, warmup + steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    native = all(a._native is not None for a in ads)
+    pa = float(np.mean([np.mean(np.concatenate([np.atleast_1d(x) for x in m["pampjpe"]])) for m in metrics]))
     return dict(value=S * steps * batch / dt, unit="adapted frames/s", replicas=S, steps_per_replica=steps, warmup=warmup,
-                ms_per_step_per_replica=dt * 1e3 / steps, native_stepper=native, dt=dt)
+                ms_per_group_step=dt * 1e3 / steps, pa_mpjpe_mm_synthetic_mean=pa, dt=dt, group=grp)
 
 
 def sub_record(device, name, steps, warmup, batch, inner_step, note, **kw):
@@ -289,9 +267,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
-    ap.add_argument("--replicas", type=str, default="2,4",
+    ap.add_argument("--replicas", type=str, default="2,4,8,16",
                     help="comma list: also measure S independent sequence replicas sharing the GPU (own weights / Adam state / "
-                         "streams each, one host thread each) and report their aggregate frames/s beside the single-stream value")
+                         "records each; every launch of the chain covers all S) and report their aggregate frames/s beside the "
+                         "single-sequence value")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--cpu_baseline_only", action="store_true")
     args = ap.parse_args()
@@ -425,15 +404,16 @@ def main():
             reps = {}
             for S in [int(x) for x in args.replicas.split(",") if x.strip()]:
                 try:
-                    r = replica_run(device, S, max(20, args.steps // 2), 6, args.batch, args.inner_step, overlap=1)
-                    r.pop("dt")
+                    r = replica_run(device, S, max(20, args.steps // 2), 6, args.batch, args.inner_step)
+                    r.pop("dt"); r.pop("group")
                     reps[f"S{S}"] = r
                 except Exception as e:      # noqa: BLE001
                     reps[f"S{S}"] = dict(value=None, error=f"{type(e).__name__}: {e}")
                 torch.cuda.empty_cache()
             out["sequence_replicas_per_gpu"] = dict(
-                note="S independent sequences adapted concurrently on this ONE GPU (batch 1 each, own weights / Adam state / streams; "
-                     "the per-sequence chain leaves most of the chip idle): aggregate frames/s; `value` above is S = 1", **reps)
+                note="S independent sequences adapted in lockstep on this ONE GPU (batch 1 each, own weights / Adam state / records; "
+                     "every launch of the per-frame chain covers all S - the single-sequence chain leaves most of the chip "
+                     "idle): aggregate frames/s; per-replica results are bit-identical to running alone; `value` above is S = 1", **reps)
             out["second_order"] = sub_record(device, "second_order", 24, 4, 1, args.inner_step,
                                              "configs[1] second-order arm: same stream, second_order=1 (finite-difference Hessian-vector "
                                              "products, +2 forward+backward per inner step)", second_order=1)

@@ -240,26 +240,30 @@ class Adaptor(BaseAdaptor):
 
     def _adapt_native(self, batch):
         from . import native_step as NS
-        o = self.options
         if self._native is None:
-            self._native = NS.NativeStepper(self, self._nframes)
-        ns = self._native
+            self._native, self._native_replica = NS.NativeStepper(self, self._nframes), 0
+        f, slot = self._native.adapt_frame(batch, side_stream=self._side)
+        return self._native_bookkeeping(f, slot)
+
+    def _native_bookkeeping(self, f, slot):
+        """What adaptation() leaves behind besides the weights: logged losses, metric records, per-step statistics - read
+        from the stepper's device buffers (views; nothing synchronises unless deferred_metrics = 0)."""
+        o, ns, r = self.options, self._native, getattr(self, "_native_replica", 0)
         K = o.inner_step
-        f, slot = ns.adapt_frame(batch, side_stream=self._side)
         for i in range(K):
-            self.kp2dlosses_lower.append(ns.losses(f, i)[0])
+            self.kp2dlosses_lower.append(ns.losses(f, i, r)[0])
         log = self.fit_losses
         for tag, lv in ((("ll", K - 1),) if K > 0 else ()) + (("ul", K),):
-            l4 = ns.losses(f, lv)
+            l4 = ns.losses(f, lv, r)
             log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"] = l4[0], l4[1], l4[2]
             log[f"{tag}/unlabelloss"] = log[f"{tag}/total"] = l4[3]
-        self.kp2dlosses_upper[self.global_step] = ns.losses(f, K)[0]
+        self.kp2dlosses_upper[self.global_step] = ns.losses(f, K, r)[0]
         out = (None, None, None)
         tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', 0)]
         if not o.deferred_metrics:
             ns.join()
         for tag in tags:
-            v = ns.record_views(slot)
+            v = ns.record_views(slot, r)
             slot += 1
             if o.deferred_metrics:
                 self._pending.append(dict(step=self.global_step, tag=tag, **v))

@@ -66,7 +66,10 @@ int dyb_adam_step(float*, const float*, float*, float*, float, float, float, flo
 __global__ __launch_bounds__(256) void metric_record_kernel(const float* __restrict__ pred17, const float* __restrict__ gt17m,
                                                             const float* __restrict__ gt17f, const long long* __restrict__ gender,
                                                             const int* __restrict__ j14, const float* __restrict__ pverts,
-                                                            const float* __restrict__ gverts, float* __restrict__ rec, int B) {
+                                                            const float* __restrict__ gverts, float* __restrict__ rec, int B,
+                                                            DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, pred17); DYB_RB(Rp, gt17m); DYB_RB(Rp, gt17f); DYB_RB(Rp, gender); DYB_RB(Rp, pverts); DYB_RB(Rp, gverts); DYB_RB(Rp, rec);
   __shared__ float s_err[64 * 14];
   __shared__ float s_red[4];
   const int t = threadIdx.x;
@@ -105,6 +108,29 @@ __global__ __launch_bounds__(256) void metric_record_kernel(const float* __restr
   if (t == 0) pve[0] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)nv;
 }
 
+// dst[0..3] = src[0..3] (a level's loss 4-vector into the frame's log row; replica-aware, unlike a device-to-device memcpy)
+__global__ void copy4_kernel(const float* __restrict__ src, float* __restrict__ dst, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, src); DYB_RB(Rp, dst);
+  if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
+}
+// replica r's frame inputs (separate caller tensors) into its staging area inside the workspace, one launch for all replicas
+#define DYB_MAX_REPLICAS 16
+struct GatherArgs {
+  const float* src[5][DYB_MAX_REPLICAS];     // image, kp2d, gt_pose, gt_betas, gender (int64 viewed as 2 floats)
+  float* dst[5];                             // replica 0's staging buffers
+  unsigned n[5];                             // floats per input
+};
+__global__ __launch_bounds__(256) void gather_inputs_kernel(GatherArgs a, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  const int k = blockIdx.y;
+  const float* src = a.src[k][dyb_rep];
+  if (!src) return;
+  float* dst = a.dst[k];
+  DYB_RB(Rp, dst);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.n[k]; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- one forward (+ backward) of HMR -> SMPL -> loss head ---------------------------------------------------------------
 struct Pass {
   float* acts;
@@ -123,6 +149,9 @@ struct Stepper {
   size_t n_params = 0, act_floats = 0, ws_bytes = 0, off_rot = 0, off_state = 0, lbs_saved = 0, lbs_wsb = 0;
   // options (doubles: the Python floats, so host-side scalars round exactly as in dynaboa_amd/optim.py / maml.py)
   int n_iter = 3, inner_step = 1, eval_lower = 1, use_side = 0, metrics = 1;
+  int nrep = 1;                       // sequence replicas stepped in lockstep by every launch (dyb_common.h)
+  size_t blob = 0;                    // workspace bytes of ONE replica
+  float* in_stage[5] = {};            // image, kp2d, gt_pose, gt_betas, gender staging (replica 0; nrep > 1 only)
   double lr = 3e-6, beta1 = 0.5, beta2 = 0.9, eps = 1e-8, fastlr = 8e-6, w2d = 10.0, wshape = 2e-6, wpose = 1e-4;
   long long adam_t = 0;
   // caller-owned state and tables (device pointers)
@@ -195,6 +224,13 @@ static size_t carve(Stepper& S, char* base) {
   S.gt_saved = take_f(S.lbs_saved);
   S.gt17[0] = take_f(B * 51);
   S.gt17[1] = take_f(B * 51);
+  if (S.nrep > 1) {
+    S.in_stage[0] = take_f(B * 3 * (size_t)S.H * S.W);
+    S.in_stage[1] = take_f(B * NJ * 3);
+    S.in_stage[2] = take_f(B * 72);
+    S.in_stage[3] = take_f(B * 10);
+    S.in_stage[4] = take_f(B * 2);
+  }
   return off;
 }
 
@@ -240,6 +276,10 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") S->adam_t = v;
+  else if (k == "replicas") {
+    DYB_REQUIRE(v >= 1 && v <= DYB_MAX_REPLICAS && !S->bound, DYB_ERR_ARG);
+    S->nrep = (int)v;
+  }
   else if (k == "record_capacity") S->record_capacity = (int)v;
   else if (k == "loss_capacity") S->loss_capacity = (int)v;
   else return DYB_ERR_ARG;
@@ -306,20 +346,22 @@ extern "C" size_t dyb_stepper_workspace_bytes(void* stepper) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   if (!S) return 0;
   Stepper tmp = *S;
-  return carve(tmp, nullptr);
+  return a64(carve(tmp, nullptr) / 4) * 4 * (size_t)S->nrep;
 }
 // `ws` must stay valid (and untouched by others) while the stepper lives; its gradient staging is zeroed here, on `stream`.
 extern "C" int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes, hipStream_t st) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   DYB_REQUIRE(S && ws, DYB_ERR_ARG);
-  const size_t need = carve(*S, nullptr);
-  DYB_REQUIRE(bytes >= need, DYB_ERR_WORKSPACE);
+  S->blob = a64(carve(*S, nullptr) / 4) * 4;
+  DYB_REQUIRE(bytes >= S->blob * (size_t)S->nrep, DYB_ERR_WORKSPACE);
   S->wsp = reinterpret_cast<char*>(ws);
   S->wsp_bytes = bytes;
-  carve(*S, S->wsp);
+  carve(*S, S->wsp);                 // replica 0's pointers; replica r's = + r * blob (resolved inside the kernels)
   // the engine overwrites every tensor span of the gradient arena and only columns 144..156 of d_state: pads stay zero
-  HIPOK(hipMemsetAsync(S->grads, 0, S->n_params * sizeof(float), st));
-  HIPOK(hipMemsetAsync(S->main.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+  for (int r = 0; r < S->nrep; ++r) {
+    HIPOK(hipMemsetAsync(reinterpret_cast<char*>(S->grads) + (size_t)r * S->blob, 0, S->n_params * sizeof(float), st));
+    HIPOK(hipMemsetAsync(reinterpret_cast<char*>(S->main.d_state) + (size_t)r * S->blob, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+  }
   S->bound = true;
   return DYB_OK;
 }
@@ -375,8 +417,9 @@ static int record_metrics(Stepper& S, Pass& P, const long long* gender, int slot
   DYB_REQUIRE(slot >= 0 && slot < S.record_capacity, DYB_ERR_ARG);
   RUN(dyb_regress_joints(S.j_h36m, P.verts, P.pred17, 17, S.B, st));
   float* rec = S.records + (size_t)slot * a64((size_t)S.B * 85 + 1);
-  hipLaunchKernelGGL(metric_record_kernel, dim3(1), dim3(256), 0, st, P.pred17, S.gt17[0], S.gt17[1], gender, S.j14, P.verts,
-                     S.gt_verts[0], rec, S.B);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(metric_record_kernel, dim3(1, 1, Rp.n), dim3(256), 0, st, P.pred17, S.gt17[0], S.gt17[1], gender, S.j14, P.verts,
+                     S.gt_verts[0], rec, S.B, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -386,13 +429,9 @@ static int record_metrics(Stepper& S, Pass& P, const long long* gender, int slot
 // schedule order - after inner step 0, 1, ..., then the final one; losses: loss_slot*(inner_step+1) 4-vectors
 // (s2d, shape prior, pose prior, weighted total) per level.  side (may be NULL): stream for the final no-grad forward and
 // its metrics, overlapped with the next frame's first level; the call orders the weight hazards itself.
-extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose,
-                                       const float* gt_betas, const long long* gender, int record_slot, int loss_slot,
-                                       hipStream_t st, hipStream_t aux, hipStream_t side) {
-  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
-  DYB_REQUIRE(Sp && image && kp2d, DYB_ERR_ARG);
-  Stepper& S = *Sp;
-  RUN(check_ready(S));
+static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
+                            const long long* gender, int record_slot, int loss_slot, hipStream_t st, hipStream_t aux,
+                            hipStream_t side) {
   const bool metrics = S.metrics != 0;
   DYB_REQUIRE(!metrics || (gt_pose && gt_betas && gender), DYB_ERR_ARG);
   if (!S.use_side || side == st) side = nullptr;
@@ -415,7 +454,11 @@ extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const 
   for (int i = 0; i <= K; ++i) {                 // i < K: lower level + adapt; i == K: upper level
     RUN(pass_forward(S, S.main, cur, image, st));
     RUN(pass_frame_head(S, S.main, kp2d, st));
-    if (losslog) HIPOK(hipMemcpyAsync(losslog + 4 * i, S.main.losses, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (losslog) {
+      hipLaunchKernelGGL(copy4_kernel, dim3(1, 1, dyb_rep_current().n), dim3(64), 0, st, (const float*)S.main.losses, losslog + 4 * i,
+                         dyb_rep_current());
+      DYB_CHECK_LAUNCH();
+    }
     // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
     if (metrics && S.eval_lower && i > 0) RUN(record_metrics(S, S.main, gender, slot++, st));
     RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
@@ -449,6 +492,69 @@ extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const 
     S.side_pending = true;
   }
   return DYB_OK;
+}
+extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose,
+                                       const float* gt_betas, const long long* gender, int record_slot, int loss_slot,
+                                       hipStream_t st, hipStream_t aux, hipStream_t side) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && image && kp2d, DYB_ERR_ARG);
+  RUN(check_ready(*Sp));
+  DYB_REQUIRE(Sp->nrep == 1, DYB_ERR_ARG);
+  return adapt_frame_impl(*Sp, image, kp2d, gt_pose, gt_betas, gender, record_slot, loss_slot, st, aux, side);
+}
+// The same frame step for `replicas` independent sequences at once: every launch of the chain covers all of them (replica
+// = a grid dimension, dyb_common.h), each with its own weights / Adam moments / workspace / records - theta, adam_m, adam_v
+// are [replicas][param floats], records [replicas][record_capacity][record_floats], loss_log [replicas][loss_capacity]
+// [loss_floats], the workspace `replicas` blobs.  inputs: HOST array of 5 x replicas device pointers, kind-major:
+// image[r], kp2d[r], gt_pose[r], gt_betas[r], gender[r] (the last three may be NULL with metrics = 0).
+extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs, int record_slot, int loss_slot, hipStream_t st,
+                                        hipStream_t aux, hipStream_t side) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && inputs, DYB_ERR_ARG);
+  Stepper& S = *Sp;
+  RUN(check_ready(S));
+  const int n = S.nrep;
+  if (n == 1)
+    return adapt_frame_impl(S, (const float*)inputs[0], (const float*)inputs[1], (const float*)inputs[2], (const float*)inputs[3],
+                            (const long long*)inputs[4], record_slot, loss_slot, st, aux, side);
+  DybRep R{};
+  R.n = n;
+  auto arena = [&](const void* lo, size_t bytes) {
+    if (!lo || !bytes) return;
+    R.lo[R.narenas] = reinterpret_cast<const char*>(lo);
+    R.span[R.narenas] = bytes;
+    R.stride[R.narenas] = bytes;
+    ++R.narenas;
+  };
+  arena(S.wsp, S.blob);
+  arena(S.theta, S.n_params * sizeof(float));
+  arena(S.adam_m, S.n_params * sizeof(float));
+  arena(S.adam_v, S.n_params * sizeof(float));
+  arena(S.records, (size_t)S.record_capacity * a64((size_t)S.B * 85 + 1) * sizeof(float));
+  arena(S.loss_log, (size_t)S.loss_capacity * 4 * (S.inner_step + 1) * sizeof(float));
+  DybRepScope scope(R);
+  GatherArgs g{};
+  const size_t B = (size_t)S.B;
+  const unsigned cnt[5] = {(unsigned)(B * 3 * S.H * S.W), (unsigned)(B * NJ * 3), (unsigned)(B * 72), (unsigned)(B * 10), (unsigned)(B * 2)};
+  for (int k = 0; k < 5; ++k) {
+    g.dst[k] = S.in_stage[k];
+    g.n[k] = cnt[k];
+    for (int r = 0; r < n; ++r) g.src[k][r] = reinterpret_cast<const float*>(inputs[k * n + r]);
+  }
+  for (int r = 0; r < n; ++r) DYB_REQUIRE(g.src[0][r] && g.src[1][r], DYB_ERR_ARG);
+  // previous frame's tail on the side stream still reads the staged inputs
+  hipStream_t gst = st;
+  if (S.side_pending) HIPOK(hipStreamWaitEvent(gst, S.e_side, 0));
+  hipLaunchKernelGGL(gather_inputs_kernel, dim3(64, 5, n), dim3(256), 0, gst, g, R);
+  DYB_CHECK_LAUNCH();
+  const bool have_gt = g.src[2][0] && g.src[3][0] && g.src[4][0];
+  if (S.use_side && side && side != st) {
+    // the ground-truth meshes are issued on the side stream: it has to see the staged inputs
+    HIPOK(hipEventRecord(S.e_gt, st));
+    HIPOK(hipStreamWaitEvent(side, S.e_gt, 0));
+  }
+  return adapt_frame_impl(S, S.in_stage[0], S.in_stage[1], have_gt ? S.in_stage[2] : nullptr, have_gt ? S.in_stage[3] : nullptr,
+                          have_gt ? reinterpret_cast<const long long*>(S.in_stage[4]) : nullptr, record_slot, loss_slot, st, aux, side);
 }
 // make `st` wait for everything the stepper has in flight on its side stream (before reading records / the final prediction)
 extern "C" int dyb_stepper_join(void* stepper, hipStream_t st) {

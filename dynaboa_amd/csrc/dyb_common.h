@@ -48,6 +48,48 @@ __device__ __forceinline__ float dyb_wave_sum(float v) {
   return v;
 }
 
+// ---- sequence replicas in the grid ------------------------------------------------------------------------------
+// The per-frame chain of ONE sequence is a few thousand small dependent launches that leave most of the 256 CUs
+// idle, and independent sequences (own weights, own Adam state: SURVEY 8e) are the only parallel axis the algorithm
+// has.  So a launch may cover n such replicas at once: the grid's z extent is multiplied by n, workgroup z / own_z
+// is the replica index, and every pointer argument that lies inside replica 0's copy of a registered arena is moved
+// by replica * stride (pointers into shared tables - SMPL, GMM prior, regressors - match no arena and stay).
+// The host side carries the current replica set in a thread-local (DybRepScope), so the launch wrappers need no
+// extra parameters; without a scope n = 1 and every kernel behaves exactly as before.
+#define DYB_MAX_ARENAS 8
+struct DybRep {
+  int n;                                        // replicas covered by the launch
+  int narenas;
+  const char* lo[DYB_MAX_ARENAS];               // replica 0's range of each arena
+  unsigned long long span[DYB_MAX_ARENAS];      // bytes
+  unsigned long long stride[DYB_MAX_ARENAS];    // bytes between consecutive replicas
+};
+template <class T>
+__device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
+  const char* c = reinterpret_cast<const char*>(p);
+#pragma unroll
+  for (int a = 0; a < DYB_MAX_ARENAS; ++a)
+    if (a < R.narenas && (unsigned long long)(c - R.lo[a]) < R.span[a])
+      return reinterpret_cast<T*>(const_cast<char*>(c) + (unsigned long long)rep * R.stride[a]);
+  return p;
+}
+// replica index and the kernel's own z coordinates; then DYB_RB(ptr)... for every pointer the kernel dereferences
+#define DYB_REP_PROLOGUE(R)                                   \
+  const unsigned dyb_gz = gridDim.z / (unsigned)(R).n;        \
+  const int dyb_rep = (int)(blockIdx.z / dyb_gz);             \
+  const unsigned dyb_bz = blockIdx.z - (unsigned)dyb_rep * dyb_gz; \
+  (void)dyb_bz
+#define DYB_RB(R, p) \
+  do {               \
+    if (dyb_rep) (p) = dyb_rb((p), (R), dyb_rep); \
+  } while (0)
+const DybRep& dyb_rep_current();                 // thread-local; {n = 1} outside a scope (igemm_conv.hip)
+struct DybRepScope {
+  DybRep saved;
+  explicit DybRepScope(const DybRep& r);
+  ~DybRepScope();
+};
+
 // ---- cross-file internals (not part of the C ABI) ----------------------------------------
 struct ConvDesc {
   int N, H, W, C, K, R, S, stride, pad;

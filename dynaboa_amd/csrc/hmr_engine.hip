@@ -52,6 +52,7 @@ int dyb_linear_bwd_dw(const float* const*, const int*, const float* const*, cons
                       float*, hipStream_t);
 int dyb_rot6d_fwd(const float*, int, float*, int, hipStream_t);
 int dyb_rot6d_bwd(const float*, int, const float*, float*, int, int, hipStream_t);
+int dyb_scale_add(const float*, const float*, const float*, float*, size_t, hipStream_t);
 }
 
 #define FC1_IN_PAD 2208
@@ -690,8 +691,8 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   float* d_xf = r;                                         // [B][2208], columns < 2048 used
 
   // ---- regressor
-  if (hipMemcpyAsync(d_st[n_iter], d_state, (size_t)B * STATE_LD * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return DYB_ERR_LAUNCH;
+  // (a kernel rather than a device-to-device memcpy: it is replica-aware like everything else on the chain, dyb_common.h)
+  RUN(dyb_scale_add(nullptr, d_state, nullptr, d_st[n_iter], (size_t)B * STATE_LD, st));
   RUN(dyb_rot6d_bwd(acts + P.a_state, STATE_LD, d_rotmat, d_st[n_iter], STATE_LD, B, st));
   for (int t = n_iter - 1; t >= 0; --t) {
     RUN(dyb_linear_bwd_dx(d_st[t + 1], STATE_LD, params + P.dec_w, HID, B, HID, STATE_LD, d_h2[t], HID, 0, HID, nullptr, 0,

@@ -262,6 +262,18 @@ struct GnFwdFuse {
   float eps;
   int relu;
 };
+// replica rebasing of the argument blocks (dyb_common.h: sequence replicas in the grid)
+__device__ __forceinline__ void rebase(IgemmArgs& g, const DybRep& R, int rep) {
+  g.A = dyb_rb(g.A, R, rep); g.B = dyb_rb(g.B, R, rep); g.out = dyb_rb(g.out, R, rep); g.addend = dyb_rb(g.addend, R, rep);
+}
+__device__ __forceinline__ void rebase(GnBwdFuse& f, const DybRep& R, int rep) {
+  f.y = dyb_rb(f.y, R, rep); f.stats = dyb_rb(f.stats, R, rep); f.gpart = dyb_rb(f.gpart, R, rep); f.gamma = dyb_rb(f.gamma, R, rep);
+  f.partials = dyb_rb(f.partials, R, rep); f.dgamma = dyb_rb(f.dgamma, R, rep); f.dbeta = dyb_rb(f.dbeta, R, rep);
+}
+__device__ __forceinline__ void rebase(GnFwdFuse& nf, const DybRep& R, int rep) {
+  nf.partials = dyb_rb(nf.partials, R, rep); nf.stats_in = dyb_rb(nf.stats_in, R, rep); nf.gamma = dyb_rb(nf.gamma, R, rep);
+  nf.beta = dyb_rb(nf.beta, R, rep); nf.stats_out = dyb_rb(nf.stats_out, R, rep);
+}
 __device__ __forceinline__ float4 gnf_apply(float4 y, float4 ga, float4 be, float mean, float rstd, int relu) {
   float4 o;
   o.x = fmaf((y.x - mean) * rstd, ga.x, be.x);
@@ -364,7 +376,13 @@ __device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, 
 }
 
 template <int MODE, bool GB, bool FA>
-__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f, GnFwdFuse nf) {
+__global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f, GnFwdFuse nf, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  if (dyb_rep) {
+    rebase(g, R, dyb_rep);
+    if constexpr (GB) rebase(f, R, dyb_rep);
+    if constexpr (FA) rebase(nf, R, dyb_rep);
+  }
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
   __shared__ float s_coef[GB ? 64 * DYB_GN_GROUPS * 4 : 4];   // [n][g] -> mean, rstd, c1, c2
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int kt_begin = blockIdx.z * g.tiles_per_split;
+  const int kt_begin = (int)dyb_bz * g.tiles_per_split;
   int kt_end = kt_begin + g.tiles_per_split;
   if (kt_end > g.ktiles) kt_end = g.ktiles;
 
@@ -520,7 +538,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   }
   if constexpr (GB) gnb_prologue(f, g.N, tid, s_raw, s_coef);
 
-  if constexpr (FA) gnf_prologue(nf, g.N, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, s_rawd, s_nrm);
+  if constexpr (FA) gnf_prologue(nf, g.N, g.C, tid, blockIdx.x == 0 && blockIdx.y == 0 && dyb_bz == 0, s_rawd, s_nrm);
 
   if (kt_begin < kt_end) {
     // register prefetch one K-step ahead, two LDS buffers, one barrier per step
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   }
 
   // C/D fragment of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* outp = g.out + (g.nsplit > 1 ? (size_t)blockIdx.z * g.M * g.Ncols : 0);
+  float* outp = g.out + (g.nsplit > 1 ? (size_t)dyb_bz * g.M * g.Ncols : 0);
   const int col = n0 + wn * 32 + (lane & 31);
   if (g.nsplit == 1 && g.addend) {
     // the 16 addend values are fetched together (clamped addresses), not one conditional load + wait per row
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
   if constexpr (GB && MODE == MODE_WGRAD) {
     // dgamma / dbeta of the 64 channels of this column block: 4 lanes per channel split the
     // (image, chunk) range of the per-channel partials and meet in LDS (reusing the A stage)
-    if (blockIdx.x == 0 && blockIdx.z == 0) {
+    if (blockIdx.x == 0 && dyb_bz == 0) {
       __syncthreads();
       float(*s_gb)[64][2] = reinterpret_cast<float(*)[64][2]>(&As[0][0][0]);
       const int cl = tid & 63, part = tid >> 6;
@@ -639,7 +657,12 @@ struct K4Args {
 };
 // MULTI (batch > 1, experimental behind DYB_K4_BATCH=1): blockIdx.x = image * tpi + tile; partials are per image.
 template <bool FA, bool MULTI>
-__global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse nf) {
+__global__ __launch_bounds__(256) void igemm_k4_fwd_kernel(K4Args g, GnFwdFuse nf, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  if (dyb_rep) {
+    g.x = dyb_rb(g.x, R, dyb_rep); g.w = dyb_rb(g.w, R, dyb_rep); g.y = dyb_rb(g.y, R, dyb_rep); g.partials = dyb_rb(g.partials, R, dyb_rep);
+    if constexpr (FA) rebase(nf, R, dyb_rep);
+  }
   __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
   __shared__ float s_nrm[FA ? (MULTI ? 64 : 1) * DYB_GN_GROUPS * 2 : 4];
@@ -806,7 +829,15 @@ struct K4DgradArgs {
 };
 // MULTI (batch > 1, experimental behind DYB_K4_BATCH=1): blockIdx.x = image * tpi + tile, per-image coefficients / statistics
 template <bool MULTI>
-__global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBwdFuse f) {
+__global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBwdFuse f, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  if (dyb_rep) {
+    g.dm = dyb_rb(g.dm, R, dyb_rep); g.w = dyb_rb(g.w, R, dyb_rep); g.addend = dyb_rb(g.addend, R, dyb_rep);
+    g.y_p = dyb_rb(g.y_p, R, dyb_rep); g.out_p = dyb_rb(g.out_p, R, dyb_rep); g.stats_p = dyb_rb(g.stats_p, R, dyb_rep);
+    g.gamma_p = dyb_rb(g.gamma_p, R, dyb_rep); g.beta_p = dyb_rb(g.beta_p, R, dyb_rep); g.dm_p = dyb_rb(g.dm_p, R, dyb_rep);
+    g.partials_p = dyb_rb(g.partials_p, R, dyb_rep); g.gpart_p = dyb_rb(g.gpart_p, R, dyb_rep);
+    rebase(f, R, dyb_rep);
+  }
   __shared__ __attribute__((aligned(16))) float As[2][K4_BK][K4_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][K4_BK][K4_LD];
   __shared__ float s_coef[(MULTI ? 64 : 1) * DYB_GN_GROUPS * 4], s_raw[(MULTI ? 64 : 1) * DYB_GN_GROUPS * 2];
@@ -950,7 +981,9 @@ __global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBw
 
 // out[i] = sum_z slab[z][i] (+ addend[i]);  n4 = element count / 4
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ slabs, const float4* __restrict__ addend,
-                                                             float4* __restrict__ out, int nsplit, size_t n4) {
+                                                             float4* __restrict__ out, int nsplit, size_t n4, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, slabs); DYB_RB(R, addend); DYB_RB(R, out);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n4; i += step) {
@@ -1009,6 +1042,12 @@ static float env_float(const char* name, float dflt) {
   const char* v = getenv(name);
   return v ? (float)atof(v) : dflt;
 }
+
+// ---- current replica set of the calling host thread (dyb_common.h) ------------------------------------------------
+static thread_local DybRep t_rep = {1, 0, {}, {}, {}};
+const DybRep& dyb_rep_current() { return t_rep; }
+DybRepScope::DybRepScope(const DybRep& r) : saved(t_rep) { t_rep = r; }
+DybRepScope::~DybRepScope() { t_rep = saved; }
 
 // ---- run-time switches ------------------------------------------------------------------------------------
 // Read from the environment ONCE (first use), never on the dispatch path; dyb_set_option changes one afterwards
@@ -1141,8 +1180,9 @@ static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1) 
   g_timing->used += 2;
   const double creal = d.C == 4 ? 3.0 : (double)d.C;        // the stem's 4th input channel is padding
   const double px = (double)d.N * conv_out_dim(d.H, d.R, d.stride, d.pad) * conv_out_dim(d.W, d.S, d.stride, d.pad);
-  g_timing->flop += 2.0 * px * d.K * d.R * d.S * creal;
-  g_timing->bytes += 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
+  const double nrep = (double)dyb_rep_current().n;          // a launch covering n sequence replicas does n convolutions
+  g_timing->flop += nrep * 2.0 * px * d.K * d.R * d.S * creal;
+  g_timing->bytes += nrep * 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
 }
 
 // Runs one mode.  If `raw_slabs_out` is non-null and the policy picks nsplit>1 the slabs are left
@@ -1163,7 +1203,8 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   const bool split = g.nsplit > 1;
   g.out = split ? reinterpret_cast<float*>(ws) : out;
   g.addend = split ? nullptr : addend;
-  dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit);
+  const DybRep& R = dyb_rep_current();
+  dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit * R.n);
   GnBwdFuse f{};
   GnFwdFuse nf{};
   if (fuse) f = *fuse;
@@ -1174,8 +1215,8 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   timing_acquire(d, &ev0, &ev1);
 #define DYB_IGEMM_LAUNCH(M_, GB_, FA_)                                                                          \
   do {                                                                                                          \
-    if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf); \
-    else hipLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, g, f, nf);                     \
+    if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf, R); \
+    else hipLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, g, f, nf, R);                  \
   } while (0)
   if (mode == MODE_FWD) {
     DYB_REQUIRE(!fuse, DYB_ERR_UNSUPPORTED);
@@ -1198,8 +1239,8 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     size_t n4 = (size_t)g.M * g.Ncols / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
-                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
+                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4, R);
     DYB_CHECK_LAUNCH();
   }
   return DYB_OK;
@@ -1286,16 +1327,17 @@ int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, co
   int rc = make_fuse(f, d, src.y, src.stats, src.part, src.gamma, nullptr, nullptr, src.nch, src.ncolb);
   if (rc != DYB_OK) return rc;
   const int M = d.H * d.W, tpi = dyb_cdiv(M, 32);
-  dim3 grid(d.N * tpi, d.C / 32);
+  const DybRep& R = dyb_rep_current();
+  dim3 grid(d.N * tpi, d.C / 32, R.n);
   K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K,
                 d.N, tpi};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1);                      // bench.py's conv timing scope
 #define DYB_K4D_LAUNCH(MU_)                                                                                          \
   do {                                                                                                               \
-    if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);         \
-    else if (done) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, nullptr, done, 0, g, f); \
-    else hipLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, g, f);                             \
+    if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f, R);      \
+    else if (done) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, nullptr, done, 0, g, f, R); \
+    else hipLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, g, f, R);                          \
   } while (0)
   if (d.N == 1) DYB_K4D_LAUNCH(false);
   else DYB_K4D_LAUNCH(true);
@@ -1319,8 +1361,9 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
   size_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
-                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
+                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -1345,15 +1388,16 @@ int dyb_conv_fwd_k4(const ConvDesc& d, const float* x, const float* w, float* y,
            d.N, 0};
   g.M = g.Ho * g.Wo;
   g.tpi = dyb_cdiv(g.M, 32);
-  dim3 grid(d.N * g.tpi, d.K / 32);
+  const DybRep& R = dyb_rep_current();
+  dim3 grid(d.N * g.tpi, d.K / 32, R.n);
   GnFwdFuse f{};
   if (nf) f = *nf;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1);
 #define DYB_K4_LAUNCH(FA_, MU_)                                                                                       \
   do {                                                                                                                \
-    if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f);       \
-    else hipLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, g, f);                           \
+    if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f, R);    \
+    else hipLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, g, f, R);                        \
   } while (0)
   if (d.N == 1) {
     if (nf) DYB_K4_LAUNCH(true, false);

@@ -17,7 +17,9 @@
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          int ldw, const float* __restrict__ bias,
                                                          const float* __restrict__ res, int ldres, float* __restrict__ y,
-                                                         int ldy, int B, int I, int O) {
+                                                         int ldy, int B, int I, int O, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, x); DYB_RB(R, w); DYB_RB(R, bias); DYB_RB(R, res); DYB_RB(R, y);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + wave;
   if (o >= O) return;
@@ -80,8 +82,9 @@ extern "C" int dyb_linear_fwd(const float* x, int ldx, const float* w, int ldw, 
                               int ldres, float* y, int ldy, int B, int I, int O, hipStream_t st) {
   DYB_REQUIRE(x && w && bias && y && B > 0 && O > 0, DYB_ERR_ARG);
   DYB_REQUIRE(I % 4 == 0 && ldw % 4 == 0 && ldx % 4 == 0, DYB_ERR_UNSUPPORTED);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(dyb_cdiv(O, 4)), dim3(256), 0, st, x, ldx, w, ldw, bias, res, ldres, y, ldy,
-                     B, I, O);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(dyb_cdiv(O, 4), 1, R.n), dim3(256), 0, st, x, ldx, w, ldw, bias, res, ldres, y, ldy,
+                     B, I, O, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -90,7 +93,9 @@ extern "C" int dyb_linear_fwd(const float* x, int ldx, const float* w, int ldw, 
 // grid (ceil(I/256), nsplit), block 256 = 64 float4-columns x 4 row lanes
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
                                                             int ldw, float* __restrict__ partial, int B, int I, int O,
-                                                            int rows_per_split) {
+                                                            int rows_per_split, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dy); DYB_RB(R, w); DYB_RB(R, partial);
   __shared__ float sm[4][64][4];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i4 = blockIdx.x * 64 + tx;
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
 __global__ __launch_bounds__(256) void linear_dx_fold_kernel(const float* __restrict__ partial, int nsplit, int B, int I,
                                                              float* __restrict__ dstA, int ldA, int accA, int split_col,
                                                              float* __restrict__ dstB, int ldB, const float* __restrict__ addB,
-                                                             int ldaddB) {
+                                                             int ldaddB, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, partial); DYB_RB(R, dstA); DYB_RB(R, dstB); DYB_RB(R, addB);
   int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= B * I) return;
   int b = idx / I, i = idx % I;
@@ -191,11 +198,12 @@ extern "C" int dyb_linear_bwd_dx(const float* dy, int lddy, const float* w, int 
   int rps = dyb_cdiv(O, ns);
   ns = dyb_cdiv(O, rps);
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(dyb_cdiv(I, 256), ns), dim3(256), 0, st, dy, lddy, w, ldw, partial, B, I,
-                     O, rps);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(dyb_cdiv(I, 256), ns, R.n), dim3(256), 0, st, dy, lddy, w, ldw, partial, B, I,
+                     O, rps, R);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(linear_dx_fold_kernel, dim3(dyb_cdiv(B * I, 256)), dim3(256), 0, st, (const float*)partial, ns, B,
-                     I, dstA, ldA, accA, split_col, dstB, ldB, addB, ldaddB);
+  hipLaunchKernelGGL(linear_dx_fold_kernel, dim3(dyb_cdiv(B * I, 256), 1, R.n), dim3(256), 0, st, (const float*)partial, ns, B,
+                     I, dstA, ldA, accA, split_col, dstB, ldB, addB, ldaddB, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -208,7 +216,11 @@ struct OuterArgs {
 };
 // grid (ceil(I4/64), ceil(O/4)), block 256: 64 float4-columns x 4 rows
 __global__ __launch_bounds__(256) void linear_outer_kernel(OuterArgs a, int T, int B, int I, int O, float* __restrict__ dw,
-                                                           int ldw, float* __restrict__ db) {
+                                                           int ldw, float* __restrict__ db, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dw); DYB_RB(R, db);
+  if (dyb_rep)
+    for (int t = 0; t < 4; ++t) { a.dy[t] = dyb_rb(a.dy[t], R, dyb_rep); a.x[t] = dyb_rb(a.x[t], R, dyb_rep); }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i4 = blockIdx.x * 64 + tx;
   const int o = blockIdx.y * 4 + ty;
@@ -238,8 +250,9 @@ extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, cons
     a.dy[t] = dys[t]; a.x[t] = xs[t]; a.lddy[t] = lddys[t]; a.ldx[t] = ldxs[t];
     DYB_REQUIRE(a.ldx[t] % 4 == 0, DYB_ERR_UNSUPPORTED);
   }
-  hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4)), dim3(256), 0, st, a, T, B, I, O, dw,
-                     ldw, db);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4), R.n), dim3(256), 0, st, a, T, B, I, O, dw,
+                     ldw, db, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

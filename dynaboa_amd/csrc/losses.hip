@@ -225,7 +225,14 @@ struct FrameLossArgs {
   float w2d, wshape, wpose;
 };
 
-__global__ __launch_bounds__(256) void frame_losses_kernel(FrameLossArgs a) {
+__global__ __launch_bounds__(256) void frame_losses_kernel(FrameLossArgs a, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  if (dyb_rep) {
+    a.rot = dyb_rb(a.rot, Rp, dyb_rep); a.shape = dyb_rb(a.shape, Rp, dyb_rep); a.cam = dyb_rb(a.cam, Rp, dyb_rep);
+    a.joints = dyb_rb(a.joints, Rp, dyb_rep); a.kp = dyb_rb(a.kp, Rp, dyb_rep); a.parts = dyb_rb(a.parts, Rp, dyb_rep);
+    a.drot = dyb_rb(a.drot, Rp, dyb_rep); a.dshape = dyb_rb(a.dshape, Rp, dyb_rep); a.dcam = dyb_rb(a.dcam, Rp, dyb_rep);
+    a.djoints = dyb_rb(a.djoints, Rp, dyb_rep);
+  }
   __shared__ float sAA[ND], sD[NG][ND], sRow[NG][ND], sCol[NG][ND], sQ[NG], sG[ND];
   __shared__ float sCamG[NJ][3], sL2d[NJ];
   __shared__ int sBest;
@@ -332,7 +339,9 @@ __global__ __launch_bounds__(256) void frame_losses_kernel(FrameLossArgs a) {
 }
 
 // out[0..3] = sum_b parts[b][0..3]
-__global__ void loss_fold_kernel(const float* __restrict__ parts, float* __restrict__ out, int B) {
+__global__ void loss_fold_kernel(const float* __restrict__ parts, float* __restrict__ out, int B, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, parts); DYB_RB(Rp, out);
   int t = threadIdx.x;
   if (t < 4) {
     float s = 0.f;
@@ -358,9 +367,10 @@ extern "C" int dyb_frame_losses(const float* rotmat, const float* shape, int lds
   a.drot = drot; a.dshape = dshape; a.dcam = dcam; a.djoints = djoints49;
   a.lds = lds; a.ldc = ldc; a.ldds = ldds; a.lddc = lddc; a.B = B;
   a.w2d = w2d; a.wshape = wshape; a.wpose = wpose;
-  hipLaunchKernelGGL(frame_losses_kernel, dim3(B), dim3(256), 0, st, a);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(frame_losses_kernel, dim3(B, 1, Rp.n), dim3(256), 0, st, a, Rp);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)a.parts, losses_out, B);
+  hipLaunchKernelGGL(loss_fold_kernel, dim3(1, 1, Rp.n), dim3(64), 0, st, (const float*)a.parts, losses_out, B, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -368,7 +378,10 @@ extern "C" int dyb_frame_losses(const float* rotmat, const float* shape, int lds
 // ---- gradient assembly of the fused HMR + SMPL + frame-loss autograd node (dynaboa_amd/fused_level.py) ----
 // out[i] = g * a[i] (+ ext[i]);  g: device scalar (the incoming gradient of the loss total), NULL = 1
 __global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ g, const float* __restrict__ a,
-                                                        const float* __restrict__ ext, float* __restrict__ out, size_t n) {
+                                                        const float* __restrict__ ext, float* __restrict__ out, size_t n,
+                                                        DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, g); DYB_RB(Rp, a); DYB_RB(Rp, ext); DYB_RB(Rp, out);
   const float s = g ? g[0] : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     out[i] = s * a[i] + (ext ? ext[i] : 0.f);
@@ -377,7 +390,8 @@ extern "C" int dyb_scale_add(const float* g, const float* a, const float* ext, f
   DYB_REQUIRE(a && out && n > 0, DYB_ERR_ARG);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(scale_add_kernel, dim3(blocks), dim3(256), 0, st, g, a, ext, out, n);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(scale_add_kernel, dim3(blocks, 1, Rp.n), dim3(256), 0, st, g, a, ext, out, n, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -389,7 +403,14 @@ struct HeadGradArgs {
   float *d_rot, *d_state;
   int B;
 };
-__global__ __launch_bounds__(256) void head_grad_kernel(HeadGradArgs a) {
+__global__ __launch_bounds__(256) void head_grad_kernel(HeadGradArgs a, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  if (dyb_rep) {
+    a.g = dyb_rb(a.g, Rp, dyb_rep); a.drot_l = dyb_rb(a.drot_l, Rp, dyb_rep); a.drot_s = dyb_rb(a.drot_s, Rp, dyb_rep);
+    a.drot_e = dyb_rb(a.drot_e, Rp, dyb_rep); a.dshape_l = dyb_rb(a.dshape_l, Rp, dyb_rep); a.dbetas_s = dyb_rb(a.dbetas_s, Rp, dyb_rep);
+    a.dshape_e = dyb_rb(a.dshape_e, Rp, dyb_rep); a.dcam_l = dyb_rb(a.dcam_l, Rp, dyb_rep); a.dcam_e = dyb_rb(a.dcam_e, Rp, dyb_rep);
+    a.d_rot = dyb_rb(a.d_rot, Rp, dyb_rep); a.d_state = dyb_rb(a.d_state, Rp, dyb_rep);
+  }
   const float s = a.g ? a.g[0] : 1.f;
   const int per = 216 + 13;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B * per; i += gridDim.x * 256) {
@@ -412,7 +433,8 @@ extern "C" int dyb_head_grad_combine(const float* g, const float* drot_loss, con
                                      hipStream_t st) {
   DYB_REQUIRE(drot_loss && drot_smpl && dshape_loss && dbetas_smpl && dcam_loss && d_rot && d_state && B > 0, DYB_ERR_ARG);
   HeadGradArgs a{g, drot_loss, drot_smpl, drot_ext, dshape_loss, dbetas_smpl, dshape_ext, dcam_loss, dcam_ext, d_rot, d_state, B};
-  hipLaunchKernelGGL(head_grad_kernel, dim3(dyb_cdiv(B * 229, 256)), dim3(256), 0, st, a);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(head_grad_kernel, dim3(dyb_cdiv(B * 229, 256), 1, Rp.n), dim3(256), 0, st, a, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

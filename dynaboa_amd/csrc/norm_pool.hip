@@ -27,7 +27,9 @@
 // grid (nchunks, N), block 256 = 4 waves, wave w <-> group w
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ src, float* __restrict__ y, int nslabs,
                                                        size_t slab_stride, float* __restrict__ partials, int HW,
-                                                       int C, int rows_per_chunk) {
+                                                       int C, int rows_per_chunk, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, src); DYB_RB(R, y); DYB_RB(R, partials);
   const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cqg = C >> 4;                        // float4 columns per group
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int nchunks, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, GnResidual rs,
                                                        float* __restrict__ out, float* __restrict__ stats, int HW, int C,
-                                                       int relu, float eps) {
+                                                       int relu, float eps, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, y); DYB_RB(R, partials); DYB_RB(R, gamma); DYB_RB(R, beta); DYB_RB(R, out); DYB_RB(R, stats);
+  DYB_RB(R, rs.y); DYB_RB(R, rs.partials); DYB_RB(R, rs.gamma); DYB_RB(R, rs.beta); DYB_RB(R, rs.stats);
   __shared__ float s_mean[2][G], s_rstd[2][G];
   const int n = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -226,8 +231,9 @@ extern "C" int dyb_groupnorm_stats(const float* slabs, int nslabs, float* y, flo
   int nch = gn_chunks(HW, N);
   int rows = dyb_cdiv(HW, nch);
   const float* src = nslabs > 1 ? slabs : y;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, N), dim3(256), 0, st, src, y, nslabs, (size_t)N * HW * C, partials, HW,
-                     C, rows);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, N, R.n), dim3(256), 0, st, src, y, nslabs, (size_t)N * HW * C, partials, HW,
+                     C, rows, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -250,8 +256,9 @@ extern "C" int dyb_groupnorm_apply_n(const float* y, const float* partials, int 
   if (bpi > cap) bpi = cap;
   if (bpi < 1) bpi = 1;
   GnResidual rs{residual, res_partials, res_gamma, res_beta, res_stats, res_nch};
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, st, y, partials, nch, gamma, beta, rs, out, stats, HW, C,
-                     relu, DYB_GN_EPS);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N, R.n), dim3(256), 0, st, y, partials, nch, gamma, beta, rs, out, stats, HW, C,
+                     relu, DYB_GN_EPS, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -300,10 +307,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ partials,
                                                             float* __restrict__ gpart, int HW, int C, int rows_per_chunk,
-                                                            int relu, int TX) {
+                                                            int relu, int TX, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dout); DYB_RB(R, addend); DYB_RB(R, folded); DYB_RB(R, dm); DYB_RB(R, out); DYB_RB(R, y); DYB_RB(R, stats);
+  DYB_RB(R, gamma); DYB_RB(R, beta); DYB_RB(R, partials); DYB_RB(R, gpart);
   __shared__ float sm[256 * 8];
   __shared__ float sg[256][2];
-  const int n = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
+  const int n = (int)dyb_bz, chunk = blockIdx.y, nchunks = gridDim.y;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cq = blockIdx.x * TX + tx;
@@ -548,9 +558,11 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   int rows = dyb_cdiv(HW, nch);
   float* partials = reinterpret_cast<float*>(ws);
   float* gpart = partials + (size_t)N * nch * 2 * C;
+  const DybRep R1 = {1, 0, {}, {}, {}};       // the stand-alone backward is not replica-aware (its apply half is not)
+  DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout_slabs, nslabs, slab_stride, addend,
                      fold ? folded : (float*)nullptr, (float*)nullptr, out, y, stats, gamma, (const float*)nullptr, partials, gpart,
-                     HW, C, rows, relu, TX);
+                     HW, C, rows, relu, TX, R1);
   DYB_CHECK_LAUNCH();
   const float* dsrc = fold ? folded : dout_slabs;
   size_t total4 = (size_t)N * HW * CQ;
@@ -603,13 +615,14 @@ int dyb_gn_bwd_reduce_slabs(const float* dout, int nslabs, size_t slab_stride, c
   // marker packet into the stream and ~6 us of bubble in front of the next kernel (measured)
   float* folded_none = nullptr;
   float* dm_arg = dm == dout ? (float*)nullptr : dm;
+  const DybRep& R = dyb_rep_current();
   if (done)
-    hipExtLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, nullptr, done, 0, dout, nslabs,
+    hipExtLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N * R.n), dim3(256), 0, st, nullptr, done, 0, dout, nslabs,
                           slab_stride, addend, folded_none, dm_arg, out, y, stats, gamma, beta, part, gpart, HW, C, rows, relu,
-                          TX);
+                          TX, R);
   else
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
-                       folded_none, dm_arg, out, y, stats, gamma, beta, part, gpart, HW, C, rows, relu, TX);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ncolb, nch, N * R.n), dim3(256), 0, st, dout, nslabs, slab_stride, addend,
+                       folded_none, dm_arg, out, y, stats, gamma, beta, part, gpart, HW, C, rows, relu, TX, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -624,8 +637,10 @@ extern "C" int dyb_groupnorm_bwd(const float* dout, const float* out, const floa
 // pooling and layout
 // ------------------------------------------------------------------------------------------
 // image [N][3][H][W] -> [N][H][W][4] (4th channel 0)
-__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(DybRep R, const float* __restrict__ x, float* __restrict__ y, int N,
                                                              int HW) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, x); DYB_RB(R, y);
   size_t total = (size_t)N * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     size_t n = i / HW, p = i % HW;
@@ -638,15 +653,18 @@ extern "C" int dyb_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W,
   size_t total = (size_t)N * H * W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, x, y, N, H * W);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, R, x, y, N, H * W);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 
 // 3x3 stride 2 pad 1.  idx holds, per channel, the winning tap (0..8) in one byte.
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(DybRep R, const float* __restrict__ x, float* __restrict__ y,
                                                           uint32_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
                                                           int Wo) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, x); DYB_RB(R, y); DYB_RB(R, idx);
   const int CQ = C >> 2;
   size_t total = (size_t)N * Ho * Wo * CQ;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -690,9 +708,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 // gather form: every input pixel looks at the (<= 4) windows that contain it
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint32_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(DybRep R, const float* __restrict__ dy, const uint32_t* __restrict__ idx,
                                                           float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                           int Wo) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dy); DYB_RB(R, idx); DYB_RB(R, dx);
   const int CQ = C >> 2;
   size_t total = (size_t)N * H * W * CQ;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -729,7 +749,8 @@ extern "C" int dyb_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int
   size_t total = (size_t)N * Ho * Wo * (C / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, y, idx, N, H, W, C, Ho, Wo);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, R, x, y, idx, N, H, W, C, Ho, Wo);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -740,7 +761,8 @@ extern "C" int dyb_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float*
   size_t total = (size_t)N * H * W * (C / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, idx, dx, N, H, W, C, Ho, Wo);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, R, dy, idx, dx, N, H, W, C, Ho, Wo);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -759,7 +781,11 @@ struct AvgTail {
   int src_ld, cols, dst_col;
 };
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, AvgDst dst, int ndst, int ld, int N,
-                                                          int HW, int C, AvgTail tail, int pool_blocks) {
+                                                          int HW, int C, AvgTail tail, int pool_blocks, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, x); DYB_RB(R, tail.src);
+  if (dyb_rep)
+    for (int d = 0; d < 4; ++d) dst.p[d] = dyb_rb(dst.p[d], R, dyb_rep);
   if ((int)blockIdx.x >= pool_blocks) {
     int i = (blockIdx.x - pool_blocks) * 256 + threadIdx.x;
     if (i < N * tail.cols) {
@@ -795,7 +821,9 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
   }
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dxf, int ld, float* __restrict__ dx,
-                                                          int N, int HW, int C) {
+                                                          int N, int HW, int C, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dxf); DYB_RB(R, dx);
   const int CQ = C >> 2;
   size_t total = (size_t)N * HW * CQ;
   float inv = 1.0f / (float)HW;
@@ -815,8 +843,9 @@ int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, i
   int pool_blocks = dyb_cdiv(N * (C / 4) * 4, 256);
   AvgTail t{tail, tail_ld, tail ? tail_cols : 0, tail_dst_col};
   int tail_blocks = tail ? dyb_cdiv(N * tail_cols, 256) : 0;
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(pool_blocks + tail_blocks), dim3(256), 0, st, x, d, ndst, ld, N, HW, C, t,
-                     pool_blocks);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(pool_blocks + tail_blocks, 1, R.n), dim3(256), 0, st, x, d, ndst, ld, N, HW, C, t,
+                     pool_blocks, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -829,7 +858,8 @@ extern "C" int dyb_avgpool_bwd(const float* dxf, int ld, float* dx, int N, int H
   size_t total = (size_t)N * HW * (C / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxf, ld, dx, N, HW, C);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, dxf, ld, dx, N, HW, C, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

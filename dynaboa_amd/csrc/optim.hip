@@ -19,7 +19,9 @@ static int stream_blocks(size_t n4) {
 }
 
 __global__ __launch_bounds__(256) void fastweight_kernel(const float4* __restrict__ p, const float4* __restrict__ g,
-                                                         float4* __restrict__ out, float lr, size_t n4) {
+                                                         float4* __restrict__ out, float lr, size_t n4, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, out);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 a = p[i], b = g[i];
     a.x -= lr * b.x; a.y -= lr * b.y; a.z -= lr * b.z; a.w -= lr * b.w;
@@ -28,8 +30,9 @@ __global__ __launch_bounds__(256) void fastweight_kernel(const float4* __restric
 }
 extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, hipStream_t st) {
   DYB_REQUIRE(p && g && out && n % 4 == 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(fastweight_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (const float4*)p, (const float4*)g,
-                     (float4*)out, lr, n / 4);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(fastweight_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (const float4*)p, (const float4*)g,
+                     (float4*)out, lr, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -45,7 +48,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                                                    float4* __restrict__ v, float b1, float b2, float step_size,
-                                                   float bc2_sqrt, float eps, size_t n4) {
+                                                   float bc2_sqrt, float eps, size_t n4, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, m); DYB_RB(Rp, v);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
     adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
@@ -59,8 +64,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
 extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, float beta2, float step_size,
                              float bc2_sqrt, float eps, size_t n, hipStream_t st) {
   DYB_REQUIRE(p && g && m && v && n % 4 == 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
-                     (float4*)v, beta1, beta2, step_size, bc2_sqrt, eps, n / 4);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
+                     (float4*)v, beta1, beta2, step_size, bc2_sqrt, eps, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -66,14 +66,18 @@ __device__ __forceinline__ void rot6d_one(const float* x, float* R) {
     R[r * 3 + 2] = b3[r];
   }
 }
-__global__ __launch_bounds__(64) void rot6d_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ R, int n) {
+__global__ __launch_bounds__(64) void rot6d_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ R, int n, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, x); DYB_RB(Rp, R);
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   int b = i / NJ, j = i % NJ;
   rot6d_one(x + (size_t)b * ldx + j * 6, R + (size_t)i * 9);
 }
 __global__ __launch_bounds__(64) void rot6d_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dR,
-                                                       float* __restrict__ dx, int lddx, int n) {
+                                                       float* __restrict__ dx, int lddx, int n, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, x); DYB_RB(Rp, dR); DYB_RB(Rp, dx);
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   int b = i / NJ, j = i % NJ;
@@ -108,14 +112,16 @@ __global__ __launch_bounds__(64) void rot6d_bwd_kernel(const float* __restrict__
 }
 extern "C" int dyb_rot6d_fwd(const float* x6, int ldx, float* rotmat, int B, hipStream_t st) {
   DYB_REQUIRE(x6 && rotmat && B > 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(rot6d_fwd_kernel, dim3(dyb_cdiv(B * NJ, 64)), dim3(64), 0, st, x6, ldx, rotmat, B * NJ);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(rot6d_fwd_kernel, dim3(dyb_cdiv(B * NJ, 64), 1, Rp.n), dim3(64), 0, st, x6, ldx, rotmat, B * NJ, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 extern "C" int dyb_rot6d_bwd(const float* x6, int ldx, const float* drotmat, float* dx6, int lddx, int B,
                              hipStream_t st) {
   DYB_REQUIRE(x6 && drotmat && dx6 && B > 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(rot6d_bwd_kernel, dim3(dyb_cdiv(B * NJ, 64)), dim3(64), 0, st, x6, ldx, drotmat, dx6, lddx, B * NJ);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(rot6d_bwd_kernel, dim3(dyb_cdiv(B * NJ, 64), 1, Rp.n), dim3(64), 0, st, x6, ldx, drotmat, dx6, lddx, B * NJ, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -123,7 +129,9 @@ extern "C" int dyb_rot6d_bwd(const float* x6, int ldx, const float* drotmat, flo
 // axis-angle -> rotation matrix as smplx.lbs.batch_rodrigues does it (angle = ||r + 1e-8||,
 // R = I + sin K + (1-cos) K^2): the pose2rot=True path of SMPL.forward, used for the ground-truth
 // meshes of the metric path (reference dynaboa_benchmark.py:221-227,242).  No gradient needed.
-__global__ __launch_bounds__(64) void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, int n) {
+__global__ __launch_bounds__(64) void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, int n, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, aa); DYB_RB(Rp, R);
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   float x = aa[i * 3], y = aa[i * 3 + 1], z = aa[i * 3 + 2];
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(64) void rodrigues_kernel(const float* __restrict__
 }
 extern "C" int dyb_rodrigues_fwd(const float* aa, float* rotmat, int n, hipStream_t st) {
   DYB_REQUIRE(aa && rotmat && n > 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(rodrigues_kernel, dim3(dyb_cdiv(n, 64)), dim3(64), 0, st, aa, rotmat, n);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(rodrigues_kernel, dim3(dyb_cdiv(n, 64), 1, Rp.n), dim3(64), 0, st, aa, rotmat, n, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -152,7 +161,9 @@ extern "C" int dyb_rodrigues_fwd(const float* aa, float* rotmat, int n, hipStrea
 __global__ __launch_bounds__(128) void lbs_pose_kernel(SmplTables T, const float* __restrict__ betas, int ldb,
                                                        const float* __restrict__ rot, float* __restrict__ A,
                                                        float* __restrict__ Jp, float* __restrict__ Jrest,
-                                                       float* __restrict__ pf) {
+                                                       float* __restrict__ pf, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, betas); DYB_RB(Rp, rot); DYB_RB(Rp, A); DYB_RB(Rp, Jp); DYB_RB(Rp, Jrest); DYB_RB(Rp, pf);
   __shared__ float sJ[NJ * 3], sGR[NJ * 9], sGt[NJ * 3], sR[NJ * 9];
   __shared__ int sPar[NJ];
   const int b = blockIdx.x, t = threadIdx.x;
@@ -211,7 +222,9 @@ __global__ __launch_bounds__(128) void lbs_pose_kernel(SmplTables T, const float
 __global__ __launch_bounds__(256) void lbs_skin_kernel(SmplTables T, const float* __restrict__ betas, int ldb,
                                                        const float* __restrict__ A, const float* __restrict__ pf,
                                                        float* __restrict__ verts, float* __restrict__ vposed,
-                                                       float* __restrict__ extra_part) {
+                                                       float* __restrict__ extra_part, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, betas); DYB_RB(Rp, A); DYB_RB(Rp, pf); DYB_RB(Rp, verts); DYB_RB(Rp, vposed); DYB_RB(Rp, extra_part);
   __shared__ float sA[NJ * 12], sPf[NPF_PAD], sBe[NB], sPart[4][LBS_VB][3];
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   {
@@ -295,7 +308,9 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(SmplTables T, const float
 
 __global__ __launch_bounds__(64) void lbs_joints_kernel(SmplTables T, const float* __restrict__ extra_part,
                                                         const float* __restrict__ Jp, const float* __restrict__ verts,
-                                                        float* __restrict__ joints49) {
+                                                        float* __restrict__ joints49, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, extra_part); DYB_RB(Rp, Jp); DYB_RB(Rp, verts); DYB_RB(Rp, joints49);
   __shared__ float sE[NEXTRA * 3];
   const int b = blockIdx.x, t = threadIdx.x;
   if (t < NEXTRA * 3) {
@@ -352,13 +367,14 @@ extern "C" int dyb_lbs_fwd(const float* const* tables_f, const int* const* table
   DYB_REQUIRE(tables_f && tables_i && betas && rotmat && verts && joints49 && saved && B > 0, DYB_ERR_ARG);
   SmplTables T = make_tables(tables_f, tables_i);
   LbsSaved s = carve_saved(saved, B);
-  hipLaunchKernelGGL(lbs_pose_kernel, dim3(B), dim3(128), 0, st, T, betas, ldb, rotmat, s.A, s.Jp, s.J, s.pf);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(lbs_pose_kernel, dim3(B, 1, Rp.n), dim3(128), 0, st, T, betas, ldb, rotmat, s.A, s.Jp, s.J, s.pf, Rp);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_skin_kernel, dim3(LBS_NBLK, B), dim3(256), 0, st, T, betas, ldb, (const float*)s.A,
-                     (const float*)s.pf, verts, s.vposed, s.extra_part);
+  hipLaunchKernelGGL(lbs_skin_kernel, dim3(LBS_NBLK, B, Rp.n), dim3(256), 0, st, T, betas, ldb, (const float*)s.A,
+                     (const float*)s.pf, verts, s.vposed, s.extra_part, Rp);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(64), 0, st, T, (const float*)s.extra_part, (const float*)s.Jp,
-                     (const float*)verts, joints49);
+  hipLaunchKernelGGL(lbs_joints_kernel, dim3(B, 1, Rp.n), dim3(64), 0, st, T, (const float*)s.extra_part, (const float*)s.Jp,
+                     (const float*)verts, joints49, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -367,7 +383,9 @@ extern "C" int dyb_lbs_fwd(const float* const* tables_f, const int* const* table
 // LBS backward
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lbs_bwd_scatter_kernel(SmplTables T, const float* __restrict__ dj49,
-                                                             float* __restrict__ dj54) {
+                                                             float* __restrict__ dj54, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, dj49); DYB_RB(Rp, dj54);
   const int b = blockIdx.x, t = threadIdx.x;
   if (t >= NJ54) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -464,7 +482,9 @@ __device__ __forceinline__ void fill_dpf(float (&vals)[64], const float* __restr
 __global__ __launch_bounds__(64) void lbs_bwd_skin_kernel(SmplTables T, const float* __restrict__ A,
                                                           const float* __restrict__ vposed,
                                                           const float* __restrict__ dverts,
-                                                          const float* __restrict__ dj54, float* __restrict__ part) {
+                                                          const float* __restrict__ dj54, float* __restrict__ part, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, A); DYB_RB(Rp, vposed); DYB_RB(Rp, dverts); DYB_RB(Rp, dj54); DYB_RB(Rp, part);
   __shared__ float sA[NJ * 12], sDj[NJ54 * 3];
   __shared__ int sVj[NVJ];
   const int b = blockIdx.y, lane = threadIdx.x;
@@ -553,7 +573,9 @@ __global__ __launch_bounds__(64) void lbs_bwd_skin_kernel(SmplTables T, const fl
 __global__ __launch_bounds__(64) void lbs_bwd_chain_kernel(SmplTables T, const float* __restrict__ part,
                                                            const float* __restrict__ dj54, const float* __restrict__ rot,
                                                            const float* __restrict__ A, const float* __restrict__ Jrest,
-                                                           float* __restrict__ drot, float* __restrict__ dbetas, int lddb) {
+                                                           float* __restrict__ drot, float* __restrict__ dbetas, int lddb, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, part); DYB_RB(Rp, dj54); DYB_RB(Rp, rot); DYB_RB(Rp, A); DYB_RB(Rp, Jrest); DYB_RB(Rp, drot); DYB_RB(Rp, dbetas);
   __shared__ float sTot[NRED], sR[NJ * 9], sGR[NJ * 9], sJ[NJ * 3];
   __shared__ float dGR[NJ * 9], dGt[NJ * 3], dJ[NJ * 3], dR[NJ * 9];
   __shared__ int sPar[NJ];
@@ -643,13 +665,14 @@ extern "C" int dyb_lbs_bwd(const float* const* tables_f, const int* const* table
   LbsSaved s = carve_saved(const_cast<float*>(saved), B);
   float* dj54 = reinterpret_cast<float*>(ws);
   float* part = dj54 + (size_t)B * NJ54 * 3;
-  hipLaunchKernelGGL(lbs_bwd_scatter_kernel, dim3(B), dim3(64), 0, st, T, djoints49, dj54);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(lbs_bwd_scatter_kernel, dim3(B, 1, Rp.n), dim3(64), 0, st, T, djoints49, dj54, Rp);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_bwd_skin_kernel, dim3(LBS_NBLK, B), dim3(64), 0, st, T, (const float*)s.A,
-                     (const float*)s.vposed, dverts, (const float*)dj54, part);
+  hipLaunchKernelGGL(lbs_bwd_skin_kernel, dim3(LBS_NBLK, B, Rp.n), dim3(64), 0, st, T, (const float*)s.A,
+                     (const float*)s.vposed, dverts, (const float*)dj54, part, Rp);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lbs_bwd_chain_kernel, dim3(B), dim3(64), 0, st, T, (const float*)part, (const float*)dj54, rotmat,
-                     (const float*)s.A, (const float*)s.J, drot, dbetas, lddb);
+  hipLaunchKernelGGL(lbs_bwd_chain_kernel, dim3(B, 1, Rp.n), dim3(64), 0, st, T, (const float*)part, (const float*)dj54, rotmat,
+                     (const float*)s.A, (const float*)s.J, drot, dbetas, lddb, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -657,7 +680,9 @@ extern "C" int dyb_lbs_bwd(const float* const* tables_f, const int* const* table
 // joints[b][j][:] = sum_v reg[j][v] * verts[b][v][:]   (H36M 17-joint regressor of the metric path,
 // reference dynaboa_benchmark.py:220-233).  grid (nj, B), block 256.
 __global__ __launch_bounds__(256) void regress_joints_kernel(const float* __restrict__ reg, const float* __restrict__ verts,
-                                                             float* __restrict__ out, int nj) {
+                                                             float* __restrict__ out, int nj, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, verts); DYB_RB(Rp, out);
   __shared__ float sm[4][3];
   const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -673,7 +698,8 @@ __global__ __launch_bounds__(256) void regress_joints_kernel(const float* __rest
 }
 extern "C" int dyb_regress_joints(const float* reg, const float* verts, float* out, int nj, int B, hipStream_t st) {
   DYB_REQUIRE(reg && verts && out && nj > 0 && B > 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(regress_joints_kernel, dim3(nj, B), dim3(256), 0, st, reg, verts, out, nj);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(regress_joints_kernel, dim3(nj, B, Rp.n), dim3(256), 0, st, reg, verts, out, nj, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -40,12 +40,20 @@ def supported(o) -> Optional[str]:
 
 
 class NativeStepper:
-    def __init__(self, adaptor, nframes: int):
+    """One stepper for ONE adaptor, or - `adaptors` a list of S > 1 adaptors with identical options - for S independent
+    sequence replicas stepped in lockstep: every launch of the chain covers all of them (csrc/dyb_common.h), each replica
+    keeping its own weights / Adam state / records.  Their parameter arenas and Adam moments are moved into stacked
+    [S][n] tensors (the adaptors' Parameters / optimizer state become views of the stacks)."""
+
+    def __init__(self, adaptors, nframes: int):
         lib = self.lib = _lib.load()
+        ads = list(adaptors) if isinstance(adaptors, (list, tuple)) else [adaptors]
+        self.adaptors = ads
+        S = self.S = len(ads)
+        adaptor = ads[0]
         o = adaptor.options
         hmr = adaptor.model.module
-        theta = hmr.theta
-        dev = theta.device
+        dev = hmr.theta.device
         self.device = dev
         B = int(getattr(o, "batch_size", 1))
         self.B, self.K = B, int(o.inner_step)
@@ -61,18 +69,43 @@ class NativeStepper:
         def sp(k, t):
             self._keep.append(t)
             check(lib.dyb_stepper_set_p(h, k.encode(), t.data_ptr()), f"set_p {k}")
+        si("replicas", S)
         si("inner_step", self.K); si("eval_lower", self.eval_lower); si("n_iter", 3)
-        si("use_side", 1 if getattr(adaptor, "_side", None) is not None else 0)
+        self.use_side = 1 if (S == 1 and getattr(adaptor, "_side", None) is not None) else 0
+        si("use_side", self.use_side)
         for k in ("lr", "beta1", "beta2", "fastlr", "s2dloss_weight", "shape_prior_weight", "pose_prior_weight"):
             sf(k, getattr(o, k))
-        opt = adaptor.optimizer
-        sf("eps", opt.param_groups[0]["eps"])
-        st = opt.state.get(theta)
-        if st is None:
-            st = opt.state[theta] = dict(step=0, exp_avg=torch.zeros_like(theta), exp_avg_sq=torch.zeros_like(theta))
-        self._adam = st
-        si("adam_step", st["step"])
-        sp("theta", theta.data); sp("adam_m", st["exp_avg"]); sp("adam_v", st["exp_avg_sq"])
+        sf("eps", adaptor.optimizer.param_groups[0]["eps"])
+        # parameters and Adam moments: one [S][n] stack each; replica r's Parameter / optimizer state alias row r
+        n = hmr.theta.numel()
+        steps = []
+        for a in ads:
+            st = a.optimizer.state.get(a.model.module.theta)
+            steps.append(0 if st is None else int(st["step"]))
+        if len(set(steps)) != 1:
+            raise ValueError("replicas must have taken the same number of Adam steps")
+        if S == 1:
+            theta = hmr.theta
+            st = adaptor.optimizer.state.get(theta)
+            if st is None:
+                st = adaptor.optimizer.state[theta] = dict(step=0, exp_avg=torch.zeros_like(theta), exp_avg_sq=torch.zeros_like(theta))
+            self.theta, self.m, self.v = theta.data, st["exp_avg"], st["exp_avg_sq"]
+            self._adam = [st]
+        else:
+            self.theta = torch.empty(S, n, device=dev)
+            self.m, self.v = torch.zeros(S, n, device=dev), torch.zeros(S, n, device=dev)
+            self._adam = []
+            for r, a in enumerate(ads):
+                p = a.model.module.theta
+                self.theta[r].copy_(p.data)
+                old = a.optimizer.state.get(p)
+                if old is not None:
+                    self.m[r].copy_(old["exp_avg"]); self.v[r].copy_(old["exp_avg_sq"])
+                p.data = self.theta[r]
+                a.optimizer.state[p] = dict(step=steps[r], exp_avg=self.m[r], exp_avg_sq=self.v[r])
+                self._adam.append(a.optimizer.state[p])
+        si("adam_step", steps[0])
+        sp("theta", self.theta); sp("adam_m", self.m); sp("adam_v", self.v)
         sp("init_state", hmr.make_init_state(B))
         prior = adaptor.gmm_f
         sp("gmm_means", prior.means); sp("gmm_precisions", prior.precisions); sp("gmm_log_weights", prior.log_nll_weights)
@@ -87,15 +120,15 @@ class NativeStepper:
         self.rec_floats = int(lib.dyb_stepper_get_i(h, b"record_floats"))
         self.loss_floats = int(lib.dyb_stepper_get_i(h, b"loss_floats"))
         self.slots_per_frame = (self.K if self.eval_lower else 0) + 1
-        self.records = torch.zeros(max(1, nframes) * self.slots_per_frame, self.rec_floats, device=dev)
-        self.loss_log = torch.zeros(max(1, nframes), self.loss_floats, device=dev)
-        si("record_capacity", self.records.shape[0]); si("loss_capacity", self.loss_log.shape[0])
+        cap = max(1, nframes)
+        self.records = torch.zeros(S, cap * self.slots_per_frame, self.rec_floats, device=dev)
+        self.loss_log = torch.zeros(S, cap, self.loss_floats, device=dev)
+        si("record_capacity", cap * self.slots_per_frame); si("loss_capacity", cap)
         sp("records", self.records); sp("loss_log", self.loss_log)
         nbytes = int(lib.dyb_stepper_workspace_bytes(h))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(lib.dyb_stepper_bind_workspace(h, self.ws.data_ptr(), nbytes, stream_of(theta)), "dyb_stepper_bind_workspace")
+        check(lib.dyb_stepper_bind_workspace(h, self.ws.data_ptr(), nbytes, stream_of(self.theta)), "dyb_stepper_bind_workspace")
         self.frame = 0
-        self._theta = theta
         # the weight-gradient stream is this stepper's own: several steppers (sequence replicas on one GPU) must not
         # serialise on one shared auxiliary stream
         self._aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -108,36 +141,76 @@ class NativeStepper:
         except Exception:      # noqa: BLE001
             pass
 
-    def adapt_frame(self, batch: Dict[str, torch.Tensor], side_stream=None):
-        """-> (frame index, first record slot).  Inputs must be contiguous fp32 (gender int64) device tensors."""
+    def adapt_frames(self, batches, side_stream=None):
+        """One frame per replica (`batches`: list of S batch dicts).  -> (frame index, first record slot)."""
         f = self.frame
-        if f >= self.loss_log.shape[0]:
+        if f >= self.loss_log.shape[1]:
             raise RuntimeError("native stepper: more frames than reset_records() announced")
-        img, kp = batch["image"].contiguous().float(), batch["smpl_j2d"].contiguous().float()
-        pose, betas = batch["pose"].contiguous().float(), batch["betas"].contiguous().float()
-        gender = batch["gender"].contiguous().long()
-        keep = (img, kp, pose, betas, gender)
-        slot0 = f * self.slots_per_frame
-        side = side_stream.cuda_stream if side_stream is not None else None
-        if side_stream is not None:
+        if len(batches) != self.S:
+            raise ValueError(f"{self.S} replicas, {len(batches)} batches")
+        cols = [[], [], [], [], []]
+        for b in batches:
+            for k, (key, conv) in enumerate((("image", torch.Tensor.float), ("smpl_j2d", torch.Tensor.float), ("pose", torch.Tensor.float),
+                                             ("betas", torch.Tensor.float), ("gender", torch.Tensor.long))):
+                cols[k].append(conv(b[key].contiguous()))
+        keep = [t for c in cols for t in c]
+        if side_stream is not None and self.use_side:
             for t in keep:
                 if t.is_cuda:
                     t.record_stream(side_stream)
-        check(self.lib.dyb_stepper_adapt_frame(self.h, img.data_ptr(), kp.data_ptr(), pose.data_ptr(), betas.data_ptr(), gender.data_ptr(),
-                                               slot0, f, stream_of(self._theta), self._aux.cuda_stream if self._aux is not None else None, side),
-              "dyb_stepper_adapt_frame")
-        self._adam["step"] = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
+        slot0 = f * self.slots_per_frame
+        side = side_stream.cuda_stream if (side_stream is not None and self.use_side) else None
+        ptrs = (ctypes.c_void_p * (5 * self.S))(*[t.data_ptr() for t in keep])
+        check(self.lib.dyb_stepper_adapt_frames(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, stream_of(self.theta),
+                                                self._aux.cuda_stream if self._aux is not None else None, side),
+              "dyb_stepper_adapt_frames")
+        t = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
+        for st in self._adam:
+            st["step"] = t
         self.frame += 1
         return f, slot0
 
+    def adapt_frame(self, batch: Dict[str, torch.Tensor], side_stream=None):
+        return self.adapt_frames([batch], side_stream)
+
     def join(self):
-        check(self.lib.dyb_stepper_join(self.h, stream_of(self._theta)), "dyb_stepper_join")
+        check(self.lib.dyb_stepper_join(self.h, stream_of(self.theta)), "dyb_stepper_join")
 
-    def record_views(self, slot: int):
+    def record_views(self, slot: int, r: int = 0):
         B = self.B
-        r = self.records[slot]
-        return dict(pred=r[:B * 42].view(B, 14, 3), gt=r[B * 42:B * 84].view(B, 14, 3), mpjpe=r[B * 84:B * 85], pve=r[B * 85])
+        rec = self.records[r, slot]
+        return dict(pred=rec[:B * 42].view(B, 14, 3), gt=rec[B * 42:B * 84].view(B, 14, 3), mpjpe=rec[B * 84:B * 85], pve=rec[B * 85])
 
-    def losses(self, frame: int, level: int):
+    def losses(self, frame: int, level: int, r: int = 0):
         """(s2d, shape prior, pose prior, weighted total) of level `level` (0..inner_step-1 lower, inner_step = upper)."""
-        return self.loss_log[frame, 4 * level:4 * level + 4]
+        return self.loss_log[r, frame, 4 * level:4 * level + 4]
+
+
+class ReplicaGroup:
+    """S independent sequences adapted on ONE GPU in lockstep (the shard axis of SURVEY 8e inside a device): S adaptors
+    with identical options, one native stepper whose launches cover all of them.  ``step(batches)`` = one
+    ``Adaptor.adaptation`` per replica, each on its own frame; records / losses land in each adaptor as if it had run
+    alone (and its weights ARE what it would have computed alone: bit-identical, tests assert it)."""
+
+    def __init__(self, adaptors, nframes: int):
+        why = supported(adaptors[0].options)
+        if why:
+            raise ValueError(f"replica groups need a configuration the native stepper covers ({why})")
+        for a in adaptors:
+            a.reset_records(nframes)
+            a._native_why = ""
+        self.adaptors = list(adaptors)
+        self.stepper = NativeStepper(self.adaptors, nframes)
+        for r, a in enumerate(self.adaptors):
+            a._native, a._native_replica = self.stepper, r
+
+    def step(self, batches, global_step: int):
+        for a, b in zip(self.adaptors, batches):
+            a.global_step = global_step
+            a.fit_losses = {}
+            a.save_hist(b["image"], b["smpl_j2d"])
+        f, slot = self.stepper.adapt_frames(batches)
+        return [a._native_bookkeeping(f, slot) for a in self.adaptors]
+
+    def flush_metrics(self):
+        return [a.flush_metrics() for a in self.adaptors]

@@ -270,7 +270,7 @@ int dyb_hmr_backward(void* plan, const float* params, const float* acts, const f
  * Steppers are independent: several may run on different streams from different host threads (sequence replicas
  * sharing one GPU).  Keys:
  *   set_i: n_iter, inner_step, eval_lower (metric record after every inner step), use_side, metrics, adam_step,
- *          record_capacity, loss_capacity
+ *          record_capacity, loss_capacity, replicas
  *   set_f: lr, beta1, beta2, eps, fastlr, s2dloss_weight, shape_prior_weight, pose_prior_weight
  *   set_p: theta, adam_m, adam_v, init_state [B][160], gmm_means, gmm_precisions, gmm_log_weights, j_regressor_h36m
  *          [17][6890], j14 (device int32[14]), records, loss_log, smpl_{neutral,male,female}_{0..6} and
@@ -293,6 +293,14 @@ int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes, dyb_stream
 int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
                             const long long* gender, int record_slot, int loss_slot, dyb_stream_t stream, dyb_stream_t aux,
                             dyb_stream_t side);
+/* The same step for `replicas` (set_i key, 1..16, before sizing the workspace) independent sequences in lockstep: every
+ * launch of the chain covers all replicas (replica = a grid dimension; pointer arguments inside a replica's arenas are
+ * rebased in the kernels), each replica with its own weights / Adam moments / workspace / records: theta, adam_m, adam_v are
+ * [replicas][param floats], records [replicas][record_capacity][record_floats], loss_log [replicas][loss_capacity]
+ * [loss_floats].  inputs: HOST array of 5 x replicas device pointers, kind-major: image[r], kp2d[r], gt_pose[r],
+ * gt_betas[r], gender[r].  Results per replica are those of dyb_stepper_adapt_frame on that replica alone. */
+int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs, int record_slot, int loss_slot, dyb_stream_t stream,
+                             dyb_stream_t aux, dyb_stream_t side);
 int dyb_stepper_join(void* stepper, dyb_stream_t stream);
 const float* dyb_stepper_output(const void* stepper, int which);
 

@@ -502,3 +502,40 @@ def test_native_stepper_immediate_metrics_and_batch():
     for k in ("mpjpe", "pampjpe", "pve"):
         np.testing.assert_allclose(np.ravel(np.array(outs[0][1][k], np.float64)), np.ravel(np.array(outs[1][1][k], np.float64)), rtol=2e-5)
     np.testing.assert_allclose(np.ravel(np.array(outs[0][2], np.float64)), np.ravel(np.array(outs[1][2], np.float64)), rtol=2e-5)
+
+
+def test_replica_group_is_bit_identical_to_single_sequences():
+    """S = 3 independent sequences stepped in lockstep by one native stepper (every launch covers all replicas;
+    csrc/dyb_common.h) against the same three sequences adapted one at a time: per replica identical weights / Adam state,
+    metric records equal to rounding.  Different checkpoints and frames per replica, so a pointer left on replica 0's
+    arena would show."""
+    from dynaboa_amd import assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    S, NF = 3, 3
+
+    def mk(r):
+        o = DB.frame_only_options(inner_step=3)
+        o.deferred_metrics = 1
+        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cuda:0")
+    frames = [[{k: v.to("cuda:0") for k, v in assets.make_frame(100 * r + s, 1, seed=22).items()} for s in range(NF)] for r in range(S)]
+    singles = []
+    for r in range(S):
+        ad = mk(r)
+        res = ad.excute(frames[r], nframes=NF)
+        st = ad.optimizer.state[ad.model.module.theta]
+        singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), res))
+    ads = [mk(r) for r in range(S)]
+    grp = NS.ReplicaGroup(ads, NF)
+    for s in range(NF):
+        grp.step([frames[r][s] for r in range(S)], s)
+    fl = grp.flush_metrics()
+    for r in range(S):
+        a = ads[r]
+        st = a.optimizer.state[a.model.module.theta]
+        assert st["step"] == NF
+        assert torch.equal(a.model.module.theta.detach(), singles[r][0]), r
+        assert torch.equal(st["exp_avg"], singles[r][1]) and torch.equal(st["exp_avg_sq"], singles[r][2]), r
+        for k in ("mpjpe", "pampjpe", "pve"):
+            np.testing.assert_allclose(np.ravel(np.array(fl[r][k], np.float64)), np.ravel(np.array(singles[r][3][k], np.float64)), rtol=2e-5)
+    # the replicas really differ from each other
+    assert not torch.equal(ads[0].model.module.theta.detach(), ads[1].model.module.theta.detach())

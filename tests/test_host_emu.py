@@ -223,3 +223,31 @@ def test_native_stepper_coverage_rules(emu_lib):
     assert NS.supported(DB.parser.parse_args([])) is not None                       # the full default term set: autograd path
     assert NS.supported(DB.frame_only_options(second_order=1)) == "second order"
     assert NS.supported(DB.frame_only_options(share_forwards=0)) is not None
+
+
+@pytest.mark.slow
+def test_replica_group_matches_single_sequences_on_emulator(emu_lib):
+    """Two sequence replicas stepped by ONE chain of launches (replica = a grid dimension, csrc/dyb_common.h) against
+    the same two sequences adapted alone: identical weights / Adam moments per replica."""
+    from dynaboa_amd import assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+
+    def mk(r):
+        o = DB.frame_only_options(inner_step=1)
+        o.deferred_metrics = 1
+        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=True, randomize_norm=True), device="cpu")
+    frames = [[assets.make_frame(100 * r, 1, seed=22)] for r in range(2)]
+    singles = []
+    for r in range(2):
+        ad = mk(r)
+        ad.excute(frames[r], nframes=1)
+        st = ad.optimizer.state[ad.model.module.theta]
+        singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()))
+    ads = [mk(r) for r in range(2)]
+    grp = NS.ReplicaGroup(ads, 1)
+    grp.step([frames[r][0] for r in range(2)], 0)
+    grp.flush_metrics()
+    for r in range(2):
+        st = ads[r].optimizer.state[ads[r].model.module.theta]
+        assert torch.equal(ads[r].model.module.theta.detach(), singles[r][0]), r
+        assert torch.equal(st["exp_avg"], singles[r][1]) and torch.equal(st["exp_avg_sq"], singles[r][2]), r
