@@ -154,17 +154,54 @@ def build_adaptor(device, batch, inner_step, full_losses=0, second_order=0, shar
     return DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=device)
 
 
-def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
-    """warmup untimed frames, then `steps` frames between barrier + device synchronise on both sides; the metric tail of
-    the last frames (side-stream worker) and flush_metrics() - the Procrustes launch + the device-to-host transfer of the
-    per-frame errors the reference performs inside every inference() - are INSIDE the clock.  per_frame: a HIP event after
-    every frame on the issuing stream gives the per-frame completion intervals (p50 / p99)."""
-    def run(lo, hi, evs=None):
-        for s in range(lo, hi):
+class Runner:
+    """What is timed: `seqs` independent sequences on this GPU, one frame step at a time.  seqs = 1: one Adaptor walking
+    its stream (adaptation() per frame); seqs > 1: a ReplicaGroup - every sequence owns its weights / Adam state / records
+    and its own frames, the native stepper issues ONE chain of launches per step covering all of them (per-sequence
+    results bit-identical to running alone, tests)."""
+
+    def __init__(self, device, seqs, batch, inner_step, nframes, rank=0, frame_base=0, **kw):
+        from dynaboa_amd import assets
+        self.S, self.batch, self.device = seqs, batch, device
+        mk = lambda r, s: {k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + r * 7_000 + frame_base + s, batch, seed=22).items()}
+        self.frames = [[mk(r, s) for s in range(nframes)] for r in range(seqs)]      # resident in HBM before any clock starts
+        if seqs == 1:
+            self.ad = build_adaptor(device, batch, inner_step, **kw)
+            self.ad.reset_records(nframes)
+            self.grp = None
+        else:
+            from dynaboa_amd import native_step as NS
+            kw = dict(kw, overlap=0)
+            self.ads = [build_adaptor(device, batch, inner_step, **kw) for _ in range(seqs)]
+            self.grp = NS.ReplicaGroup(self.ads, nframes)
+            self.ad = self.ads[0]
+
+    def step(self, s):
+        if self.grp is None:
+            ad = self.ad
             ad.global_step = s
             ad.fit_losses = {}
             ad.model.eval()
-            ad.adaptation(frames[s])
+            ad.adaptation(self.frames[0][s])
+        else:
+            self.grp.step([self.frames[r][s] for r in range(self.S)], s)
+
+    def flush(self):
+        """-> list of per-sequence metric dicts"""
+        return [self.ad.flush_metrics()] if self.grp is None else self.grp.flush_metrics()
+
+    def native(self):
+        return all(a._native is not None for a in ([self.ad] if self.grp is None else self.ads))
+
+
+def timed_stream(runner, warmup, steps, stream, dist=None, per_frame=False):
+    """warmup untimed steps, then `steps` steps between barrier + device synchronise on both sides; the metric tail of
+    the last frames and flush_metrics() - the Procrustes launch + the device-to-host transfer of the per-frame errors the
+    reference performs inside every inference() - are INSIDE the clock.  per_frame: a HIP event after every step on the
+    issuing stream gives the per-step completion intervals (p50 / p99)."""
+    def run(lo, hi, evs=None):
+        for s in range(lo, hi):
+            runner.step(s)
             if evs is not None:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record(stream)
@@ -172,7 +209,7 @@ def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
         run(0, warmup)
-        ad.flush_metrics()
+        runner.flush()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -186,7 +223,7 @@ def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
             evs.append(e0)
         run(warmup, warmup + steps, evs)
         t_issue = time.perf_counter() - t0          # host finished issuing; GPU may still be draining
-        metrics = ad.flush_metrics()                # joins the side worker / stream, Procrustes launch, D2H of the scalars
+        metrics = runner.flush()                    # joins side work, Procrustes launch, D2H of the scalars
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -194,57 +231,31 @@ def timed_stream(ad, frames, warmup, steps, stream, dist=None, per_frame=False):
     dt = time.perf_counter() - t0
     out = dict(dt=dt, t_issue=t_issue, metrics=metrics, run=run)
     if evs is not None:
-        ft = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
-        out["frame_ms"] = ft
+        out["frame_ms"] = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
     return out
 
 
-def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, dist=None, **kw):
-    """S independent sequence replicas on ONE GPU (the shard axis of SURVEY 8e inside a device): every replica owns its
-    weights, Adam state, workspace and records and walks its own frames; the native stepper issues ONE chain of launches
-    per frame step, each launch covering all replicas (replica = a grid dimension, csrc/dyb_common.h) - per-replica results
-    are bit-identical to running alone (tests).  -> frames/s over all replicas, same clock discipline as the main run."""
-    from dynaboa_amd import assets, native_step as NS
-    ads = [build_adaptor(device, batch, inner_step, overlap=0, **kw) for _ in range(S)]
-    frs = [[{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + (r + 1) * 7_000 + s, batch, seed=22).items()}
-            for s in range(warmup + steps)] for r in range(S)]
-    grp = NS.ReplicaGroup(ads, warmup + steps)
-    stream = torch.cuda.Stream(device=device)
+def pa_mean(metrics):
+    v = [np.atleast_1d(x) for m in metrics for x in m["pampjpe"]]
+    return float(np.mean(np.concatenate(v))) if v else None
 
-    def phase(lo, hi):
-        with torch.cuda.stream(stream):
-            for s in range(lo, hi):
-                grp.step([frs[r][s] for r in range(S)], s)
-            return grp.flush_metrics()
-    torch.cuda.synchronize()
-    phase(0, warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    metrics = phase(warmup, warmup + steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    pa = float(np.mean([np.mean(np.concatenate([np.atleast_1d(x) for x in m["pampjpe"]])) for m in metrics]))
-    return dict(value=S * steps * batch / dt, unit="adapted frames/s", replicas=S, steps_per_replica=steps, warmup=warmup,
-                ms_per_group_step=dt * 1e3 / steps, pa_mpjpe_mm_synthetic_mean=pa, dt=dt, group=grp)
+
+def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
+    """Aggregate frames/s of S sequences in lockstep on one GPU (a short side run: see Runner)."""
+    rn = Runner(device, S, batch, inner_step, warmup + steps, rank=rank, frame_base=3_000, **kw)
+    r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device))
+    return dict(value=S * steps * batch / r["dt"], unit="adapted frames/s", seqs=S, steps=steps, warmup=warmup,
+                ms_per_step=r["dt"] * 1e3 / steps, pa_mpjpe_mm_synthetic_mean=pa_mean(r["metrics"]))
 
 
 def sub_record(device, name, steps, warmup, batch, inner_step, note, **kw):
     """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each."""
-    from dynaboa_amd import assets
     try:
-        ad = build_adaptor(device, batch, inner_step, **kw)
-        frames = [{k: v.to(device) for k, v in assets.make_frame(500_000 + s, batch, seed=22).items()} for s in range(warmup + steps)]
-        ad.reset_records(warmup + steps)
-        st = torch.cuda.Stream(device=device)
-        r = timed_stream(ad, frames, warmup, steps, st)
+        rn = Runner(device, 1, batch, inner_step, warmup + steps, frame_base=500_000, **kw)
+        r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device))
         return dict(value=steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
-                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps, config=note)
+                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
+                    native_stepper=rn.native(), config=note)
     except Exception as e:      # noqa: BLE001
         return dict(value=None, error=f"{type(e).__name__}: {e}", config=note)
 
@@ -267,10 +278,11 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
-    ap.add_argument("--replicas", type=str, default="2,4,8,16",
-                    help="comma list: also measure S independent sequence replicas sharing the GPU (own weights / Adam state / "
-                         "records each; every launch of the chain covers all S) and report their aggregate frames/s beside the "
-                         "single-sequence value")
+    ap.add_argument("--seqs", type=int, default=1,
+                    help="independent sequences per GPU in the timed run (each with its own weights / Adam state / records, batch "
+                         "--batch each), stepped in lockstep by one chain of launches; 1 = the single-sequence latency configuration")
+    ap.add_argument("--replicas", type=str, default="1,2,4,8,16",
+                    help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--cpu_baseline_only", action="store_true")
     args = ap.parse_args()
@@ -301,22 +313,21 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
-    from dynaboa_amd import assets
-    ad = build_adaptor(device, args.batch, args.inner_step, args.full_losses, args.second_order, args.share_forwards,
-                       args.overlap, args.schedule)
+    seqs = args.seqs
+    simple = not (args.second_order or args.full_losses)
+    if seqs > 1 and not simple:
+        raise SystemExit("bench.py: --seqs > 1 needs a configuration the native stepper covers (first order, frame-loss set)")
     total = args.warmup + args.steps
-    n_roof = 0 if args.no_roofline else 4           # extra frames for the instrumented roofline pass (outside the clock)
+    n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
-    # this rank's shard of the synthetic stream, resident in HBM before the clock starts
     nfr = total + n_roof + n_pct
-    frames = [{k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + s, args.batch, seed=22).items()}
-              for s in range(nfr)]
-    ad.reset_records(nfr)
+    rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, full_losses=args.full_losses,
+                second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule)
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream
     main_stream = torch.cuda.Stream(device=device)
-    res = timed_stream(ad, frames, args.warmup, args.steps, main_stream, dist, per_frame=(args.steps >= 200))
+    res = timed_stream(rn, args.warmup, args.steps, main_stream, dist, per_frame=(args.steps >= 200))
     dt, t_issue, metrics, run = res["dt"], res["t_issue"], res["metrics"], res["run"]
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -324,12 +335,12 @@ def main():
         dt = float(t.item())
         # end-of-stream gather of the per-frame errors over RCCL (the path's only collective)
         from dynaboa_amd.sharding import gather_frame_metrics
-        pa = torch.tensor(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]) if metrics["pampjpe"] else np.zeros(0),
-                          device=device, dtype=torch.float32)
+        v = [np.atleast_1d(x) for m in metrics for x in m["pampjpe"]]
+        pa = torch.tensor(np.concatenate(v) if v else np.zeros(0), device=device, dtype=torch.float32)
         gathered = gather_frame_metrics(pa)
     else:
         gathered = None
-    frames_done = args.steps * args.batch * world
+    frames_done = args.steps * args.batch * seqs * world
     value = frames_done / dt
 
     if rank == 0:
@@ -337,51 +348,55 @@ def main():
         # with forward sharing the identical-weight repeats (feature forward, per-inner-step inference) reuse a level forward
         fwd_pf = (args.inner_step + 2) if (args.share_forwards and not args.full_losses) else fwd_ref
         order = "second-order" if args.second_order else "first-order"
-        out = {"metric": "adapted frames/sec, whole job (%d inner + 1 outer step, bs=%d, %s; synthetic 224x224 stream, no 3DPW "
+        how = ("%d independent sequences per GPU stepped in lockstep by one chain of launches (own weights / Adam state / records "
+               "each, batch %d each; per-sequence results bit-identical to running alone)" % (seqs, args.batch)) if seqs > 1 else \
+              "one sequence per GPU"
+        out = {"metric": "adapted frames/sec, whole job (%d inner + 1 outer step, bs=%d per sequence, %s; synthetic 224x224 stream, no 3DPW "
                          "assets in the image: PA-MPJPE on 3DPW not measured)" % (args.inner_step, args.batch, order),
                "value": value, "unit": "adapted frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt * 1e3 / args.steps, "host_issue_ms_per_step": t_issue * 1e3 / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
-                                      "inner_step=%d + 1 outer, %s, %s; schedule=%s: every output of the reference's "
-                                      "%d-forward schedule is produced (metrics after each inner step when faithful), "
-                                      "%d HMR forwards + %d backwards executed per frame%s; metric tails / remaining no-grad forwards %s; "
+                                      "inner_step=%d + 1 outer, %s, %s; %s; a step = one frame of every sequence; schedule=%s: every "
+                                      "output of the reference's %d-forward schedule is produced (metrics after each inner step when "
+                                      "faithful), %d HMR forwards + %d backwards executed per frame%s; native frame stepper: %s; "
                                       "metric flush (Procrustes + D2H) inside the clock" %
                                       (args.batch, args.inner_step,
                                        "second-order (finite-difference Hessian-vector products: +2 forward+backward per inner step)"
                                        if args.second_order else "first-order (reference parity mode)",
-                                       "reference default loss set" if args.full_losses else "frame losses only",
+                                       "reference default loss set" if args.full_losses else "frame losses only", how,
                                        args.schedule, fwd_ref, fwd_pf, args.inner_step + 1,
                                        " (forwards the reference repeats with identical weights and input are shared - bit-identical results)"
-                                       if fwd_pf != fwd_ref else "",
-                                       {0: "in line", 1: "overlapped on a side HIP stream",
-                                        2: "overlapped on a side HIP stream issued by a second host thread"}[args.overlap]),
-                          "global_batch": args.batch * world, "parallelism": f"replicas{world} (stream sharded by sequence)",
+                                       if fwd_pf != fwd_ref else "", rn.native()),
+                          "sequences_per_gpu": seqs, "global_batch": args.batch * seqs * world,
+                          "parallelism": f"replicas{world} x {seqs} sequences (stream sharded by sequence)",
                           "per_gpu_frames_per_s": value / world,
-                          "pa_mpjpe_mm_synthetic_mean": float(np.mean(np.concatenate([np.atleast_1d(x) for x in metrics["pampjpe"]]))) if metrics["pampjpe"] else None,
+                          "pa_mpjpe_mm_synthetic_mean": pa_mean(metrics),
                           "gathered_frames": int(gathered.numel()) if gathered is not None else None,
                           "engine_graphs": __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(args.batch).graph_stats()}}
         if not args.no_roofline:
             lo = total
             torch.cuda.synchronize()
             r = conv_roofline(run, lo, lo + n_roof, main_stream)
-            ad.flush_metrics()
+            rn.flush()
         if not args.no_roofline and r is not None:
             tr = pmc_traffic()
+            fr = n_roof * seqs
             out["roofline"] = {"bound": "mfma", "achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": tr["bytes"] if tr else None,
                                "traffic_note": tr["note"] if tr else "no PMC summary under profiles/",
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                                "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad, +/- GroupNorm loaders> + igemm_k4_{fwd,dgrad}_kernel: every conv "
-                                         "launch of the adaptation chain (main + weight-gradient streams), timed on its own dispatch inside the path",
-                               "sample_frames": r["sample_frames"],
-                               "avg_launch_us": r["avg_launch_us"], "launches_per_frame": r["launches_per_frame"],
-                               "conv_ms_per_frame": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"],
-                               "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3,
-                               "whole_frame_frac": MIN_SCHEDULE_GFLOP * args.batch * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS}
-        # per-frame completion intervals (HIP events on the issuing stream): from the timed run itself when it has >= 200
-        # frames, else from an extra pass of `percentile_frames` frames of the same loop
+                                         "launch of the adaptation chain (main + weight-gradient streams; a launch covers all sequences "
+                                         "of the step), timed on its own dispatch inside the path",
+                               "sample_steps": r["sample_frames"], "sample_frames": fr,
+                               "avg_launch_us": r["avg_launch_us"], "launches_per_step": r["launches_per_frame"],
+                               "conv_ms_per_step": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"] / seqs,
+                               "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * value / world / 1e3,
+                               "whole_frame_frac": MIN_SCHEDULE_GFLOP * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS}
+        # per-step completion intervals (HIP events on the issuing stream): from the timed run itself when it has >= 200
+        # steps, else from an extra pass of `percentile_frames` steps of the same loop
         ft = res.get("frame_ms")
         if ft is None and n_pct:
             evs = []
@@ -391,31 +406,32 @@ def main():
                 e0.record(main_stream)
                 evs.append(e0)
                 run(total + n_roof, total + n_roof + n_pct, evs)
-                ad.flush_metrics()
+                rn.flush()
             torch.cuda.synchronize()
             ft = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
         if ft is not None and len(ft):
-            out["frame_time_ms"] = {"frames": int(len(ft)), "mean": float(ft.mean()), "p50": float(np.percentile(ft, 50)),
+            out["frame_time_ms"] = {"steps": int(len(ft)), "mean": float(ft.mean()), "p50": float(np.percentile(ft, 50)),
                                     "p99": float(np.percentile(ft, 99)), "max": float(ft.max()),
-                                    "how": "HIP event after every frame on the issuing stream; intervals between consecutive events"}
-        if world == 1 and not args.no_sub_records and not (args.second_order or args.full_losses or args.batch != 1):
-            del ad, frames
+                                    "how": "HIP event after every step (one frame of each of the %d sequences) on the issuing stream; "
+                                           "intervals between consecutive events = time from a sequence's frame to its next" % seqs}
+        if world == 1 and not args.no_sub_records and simple and args.batch == 1:
+            del rn, run, res
             torch.cuda.empty_cache()
             reps = {}
             for S in [int(x) for x in args.replicas.split(",") if x.strip()]:
+                if S == seqs:
+                    continue
                 try:
-                    r = replica_run(device, S, max(20, args.steps // 2), 6, args.batch, args.inner_step)
-                    r.pop("dt"); r.pop("group")
-                    reps[f"S{S}"] = r
+                    reps[f"S{S}"] = replica_run(device, S, max(20, args.steps // 2), 6, args.batch, args.inner_step)
                 except Exception as e:      # noqa: BLE001
                     reps[f"S{S}"] = dict(value=None, error=f"{type(e).__name__}: {e}")
                 torch.cuda.empty_cache()
-            out["sequence_replicas_per_gpu"] = dict(
-                note="S independent sequences adapted in lockstep on this ONE GPU (batch 1 each, own weights / Adam state / records; "
-                     "every launch of the per-frame chain covers all S - the single-sequence chain leaves most of the chip "
-                     "idle): aggregate frames/s; per-replica results are bit-identical to running alone; `value` above is S = 1", **reps)
+            out["sequences_per_gpu_sweep"] = dict(
+                note="aggregate frames/s with S independent sequences adapted in lockstep on this ONE GPU (batch 1 each, own weights / "
+                     "Adam state / records; every launch of the per-frame chain covers all S); S1 = one sequence alone (the latency "
+                     "configuration); the headline `value` uses S = %d" % seqs, **reps)
             out["second_order"] = sub_record(device, "second_order", 24, 4, 1, args.inner_step,
-                                             "configs[1] second-order arm: same stream, second_order=1 (finite-difference Hessian-vector "
+                                             "configs[1] second-order arm: one sequence, second_order=1 (finite-difference Hessian-vector "
                                              "products, +2 forward+backward per inner step)", second_order=1)
             out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 16, 4, 8, args.inner_step,
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "

@@ -59,6 +59,11 @@ class BaseAdaptor:
         self.global_step = 0
         if options.retrieval:
             self.load_h36_cluster_res()
+            if self.bundle is None:
+                # the exemplar set retrieval() draws from (reference base_adaptor.py:55)
+                from . import datasets as D
+                self.h36m_dataset = D.SourceDataset('data/retrieval_res/h36m_random_sample_center_10_10.pt',
+                                                    img_dir=getattr(options, "h36m_root", None) or D.H36M_ROOT, device=self.device)
         self.set_model_optim()
         if options.use_meanteacher:
             self.set_teacher()
@@ -106,7 +111,19 @@ class BaseAdaptor:
         self.teacher.eval()
 
     def set_dataloader(self):
-        self.dataloader = self.bundle.dataloader if self.bundle is not None else None
+        """reference base_adaptor.py:130-137: the 3DPW test stream in sequence order, batch_size frames at a time, decoded
+        ahead on 8 host threads; crop / resize / normalise on the GPU (datasets.py).  With a synthetic bundle the stream
+        is whatever the caller iterates."""
+        if self.bundle is not None:
+            self.dataloader = self.bundle.dataloader
+            return
+        from . import datasets as D
+        if getattr(self.options, "dataset", "3dpw") != "3dpw":
+            raise NotImplementedError("the 'internet' demo dataset (reference boa_dataset/internet_data.py) is out of scope "
+                                      "(SURVEY 2); pass frames to excute() yourself")
+        self.imgdir = getattr(self.options, "pw3d_root", None) or D.PW3D_ROOT
+        ds = D.PW3D(self.options, img_dir=self.imgdir, device=self.device)
+        self.dataloader = D.FrameLoader(ds, batch_size=self.options.batch_size, workers=8) if len(ds) else None
 
     def set_criterion(self):
         folder = self.bundle.gmm_folder if self.bundle is not None else "data/spin_data"
@@ -128,22 +145,32 @@ class BaseAdaptor:
 
     # ------------------------------------------------------------------ retrieval (base_adaptor.py:74-96)
     def load_h36_cluster_res(self):
+        """reference base_adaptor.py:74-80: cluster centres of the base model's Human3.6M features + member indices."""
         self.centers = None
         if self.bundle is None:
             import joblib
-            res = joblib.load("data/retrieval_res/cluster_res_random_sample_center_10_10_potocol2.pt")
-            self.centers = torch.from_numpy(res["centers"]).float().to(self.device)
+            res = self.h36m_cluster_res = joblib.load("data/retrieval_res/cluster_res_random_sample_center_10_10_potocol2.pt")
+            self.centers = torch.from_numpy(np.asarray(res["centers"])).float().to(self.device)
             self.index = res["index"]
 
+    def get_h36m_data(self, indice):
+        return dict(self.h36m_dataset[indice])
+
     def retrieval(self, feature):
+        """reference base_adaptor.py:82-96: nearest cluster by cosine distance of features[5] (the pooled 2048-vector) to
+        the centres, `sample_num` members drawn with the seeded `random` module, their items concatenated along dim 0.
+        The cluster index is the one host synchronisation of the level (the reference's `.item()`)."""
         if self.bundle is not None:
             batch = self.bundle.exemplars(self.global_step, self.options.sample_num)
         else:
             dists = 1 - F.cosine_similarity(feature, self.centers)
-            cluster = int(torch.argsort(dists)[0])
-            picks = random.sample(self.index[cluster], self.options.sample_num)
-            items = [self.h36m_dataset[i] for i in picks]
-            batch = {k: torch.cat([it[k] for it in items], 0) for k in items[0] if torch.is_tensor(items[0][k])}
+            pos_cluster = torch.argsort(dists)[0].item()
+            pos_indices = random.sample(self.index[pos_cluster], self.options.sample_num)
+            items = [self.get_h36m_data(i) for i in pos_indices]
+            batch = items[0]
+            for it in items[1:]:
+                for k, v in it.items():
+                    batch[k] = torch.cat([batch[k], v], dim=0) if torch.is_tensor(v) else batch[k]
         return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
     # ------------------------------------------------------------------ geometry helpers

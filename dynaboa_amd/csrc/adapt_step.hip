@@ -445,11 +445,12 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     // tail, which still reads the buffers)
     hipStream_t gs = side ? side : st;
     RUN(gt_meshes(S, gt_pose, gt_betas, gs));
-    if (side) {
-      HIPOK(hipEventRecord(S.e_gt, side));
-      HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
-    }
+    if (side) HIPOK(hipEventRecord(S.e_gt, side));
   }
+  // the main stream waits for the meshes only where it first reads them (the record after inner step 0): at the top of
+  // the frame the side stream is still busy with the previous frame's final forward, and waiting there stalled the main
+  // chain for that whole tail (1.1 ms per frame in the kernel trace)
+  bool gt_waited = !(metrics && side);
   const float* cur = S.theta;                    // clone(): the learner starts as an alias of theta
   for (int i = 0; i <= K; ++i) {                 // i < K: lower level + adapt; i == K: upper level
     RUN(pass_forward(S, S.main, cur, image, st));
@@ -460,7 +461,13 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
       DYB_CHECK_LAUNCH();
     }
     // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
-    if (metrics && S.eval_lower && i > 0) RUN(record_metrics(S, S.main, gender, slot++, st));
+    if (metrics && S.eval_lower && i > 0) {
+      if (!gt_waited) {
+        HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
+        gt_waited = true;
+      }
+      RUN(record_metrics(S, S.main, gender, slot++, st));
+    }
     RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
     if (i < K) {
       RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, n, st));

@@ -1052,15 +1052,17 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // ---- run-time switches ------------------------------------------------------------------------------------
 // Read from the environment ONCE (first use), never on the dispatch path; dyb_set_option changes one afterwards
 // (tests / A-B runs).  Names: "k4" (single-launch 1x1 forward + statistics), "k4_bwd" (1x1 data gradient carries the
-// producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit).
+// producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit), "rep_split"
+// (split-K depth chosen for the replica-multiplied grid).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
     k4_bwd = env("DYB_K4_BWD", 1);
     k4_batch = env("DYB_K4_BATCH", 1);
     k4_maxc = env("DYB_K4_MAXC", 1024);
+    rep_split = env("DYB_REP_SPLIT", 0);
   }
 };
 static DybSwitches& switches() {
@@ -1074,6 +1076,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "k4_bwd")) return &s.k4_bwd;
   if (!strcmp(name, "k4_batch")) return &s.k4_batch;
   if (!strcmp(name, "k4_maxc")) return &s.k4_maxc;
+  if (!strcmp(name, "rep_split")) return &s.rep_split;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1096,6 +1099,10 @@ static int choose_split(const IgemmArgs& g, size_t ws_floats, int mode, bool raw
                      fwd_slab_us = env_float("DYB_FWD_SLAB_US", 0.15f);
   static const int grid_cap = (int)env_float("DYB_GRID_CAP", 1024.f), min_steps = (int)env_float("DYB_MIN_STEPS", 2.f);
   int tiles = dyb_cdiv(g.M, BM) * dyb_cdiv(g.Ncols, BN);
+  // rep_split = 1: a launch covering n sequence replicas already has n x the workgroups, so the grid cap counts them and
+  // the K loop is split less (fewer slabs to write and fold).  Off by default: the split depth fixes the summation order,
+  // and with it off a replica's results are bit-identical to the same sequence running alone.
+  if (switches().rep_split.load(std::memory_order_relaxed)) tiles *= dyb_rep_current().n;
   int maxs = g.ktiles / (min_steps > 0 ? min_steps : 1);
   if (maxs < 1) maxs = 1;
   int gridcap = grid_cap / tiles;

@@ -260,6 +260,17 @@ int dyb_hmr_forward(void* plan, const float* params, const float* image_nchw, co
 int dyb_hmr_backward(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
                      int n_iter, float* grads, void* ws, size_t ws_bytes, dyb_stream_t stream, dyb_stream_t aux_stream);
 
+/* ---- frame preprocessing: bounding-box crop + anti-aliased bilinear resize + /255 + Normalize + HWC->CHW ----------------
+ * reference utils/dataprocess.py:48-96 crop() (test-time path: rot = 0) as called by boa_dataset/pw3d.py:131-136 and
+ * base_adaptor.py:529-533, with skimage.transform.resize 0.17.2 semantics (Gaussian anti-aliasing sigma = (in/out - 1)/2,
+ * 'mirror' boundary, bilinear warp at (j + 0.5) * in/out - 0.5), then pw3d.py:121-123.  img: decoded frame [H][W][3] uint8
+ * RGB (device); (ul, br): box corners in frame pixels as the reference's transform(..., invert=1) gives them (may lie
+ * outside the frame: zero fill); out: [3][res][res] fp32.  ws: dyb_crop_workspace_bytes(br_y - ul_y, br_x - ul_x). */
+size_t dyb_crop_workspace_bytes(int box_h, int box_w);
+int dyb_crop_resize_normalize(const uint8_t* img, int H, int W, int ul_x, int ul_y, int br_x, int br_y, float* out, int res,
+                              float mean0, float mean1, float mean2, float std0, float std1, float std2, void* ws,
+                              size_t ws_bytes, dyb_stream_t stream);
+
 /* ---- native frame stepper: Adaptor.adaptation (reference dynaboa_benchmark.py:126-193) as ONE call per frame --------
  * The first-order bilevel schedule with the frame-loss set - clone, inner_step x [lower-level loss
  * (base_adaptor.py:222-268) -> learner.adapt -> inference], upper-level loss (:270-317) through the fast weights,

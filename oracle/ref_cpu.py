@@ -12,7 +12,11 @@ cites the reference lines it follows.  Pinning (see tools/make_golden.py, tests/
   * the two third-party pieces the reference only *calls* (smplx LBS, learn2learn MAML) are
     absent from /root/reference and not installable here.  They are restated from their
     published algorithms and pinned by first-principles known-answer
-    tests only -> for those two, PARITY IS UNPINNED BY THE REFERENCE.
+    tests only -> for those two, PARITY IS UNPINNED BY THE REFERENCE;
+  * frame preprocessing: the box / keypoint arithmetic of utils/dataprocess.py is pinned by golden g7 (the reference's own
+    crop() / transform() run here); the resize inside crop() is scikit-image 0.17.2's, not installed here: it is restated
+    from its published defaults on scipy.ndimage (skimage_resize below) and g7 was generated with that restatement plugged
+    into the reference's crop() -> the RESIZE is unpinned by the reference (known-answer tests only).
 """
 from __future__ import annotations
 
@@ -476,3 +480,97 @@ def eval_metrics(pred_verts, gt_verts_gendered, gt_verts_neutral, J_h36m, j14: S
     pa = np.sqrt(((procrustes_align(p.numpy(), g.numpy()) - g.numpy()) ** 2).sum(-1)).mean(-1)
     pve = float((gt_verts_neutral - pred_verts).norm(dim=-1).mean())
     return mpjpe * 1000, pa * 1000, pve * 1000
+
+
+# ----------------------------------------------------------------------------------------
+# Frame preprocessing (reference utils/dataprocess.py:12-96, boa_dataset/pw3d.py:117-156, base_adaptor.py:510-533)
+# ----------------------------------------------------------------------------------------
+def get_transform(center, scale, res):
+    """utils/dataprocess.py:12-37 with rot = 0."""
+    h = 200 * scale
+    t = np.zeros((3, 3))
+    t[0, 0] = float(res[1]) / h
+    t[1, 1] = float(res[0]) / h
+    t[0, 2] = res[1] * (-float(center[0]) / h + .5)
+    t[1, 2] = res[0] * (-float(center[1]) / h + .5)
+    t[2, 2] = 1
+    return t
+
+
+def transform_pt(pt, center, scale, res, invert=0):
+    """utils/dataprocess.py:39-46: pixel location to / from the crop frame (1-based in, truncation, 1-based out)."""
+    t = get_transform(center, scale, res)
+    if invert:
+        t = np.linalg.inv(t)
+    new_pt = np.dot(t, np.array([pt[0] - 1, pt[1] - 1, 1.]).T)
+    return new_pt[:2].astype(int) + 1
+
+
+def crop_box(center, scale, res):
+    """Upper-left / bottom-right corner of the crop box in frame pixels (utils/dataprocess.py:51-54)."""
+    ul = np.array(transform_pt([1, 1], center, scale, res, invert=1)) - 1
+    br = np.array(transform_pt([res[0] + 1, res[1] + 1], center, scale, res, invert=1)) - 1
+    return ul, br
+
+
+def skimage_resize(image: np.ndarray, output_shape) -> np.ndarray:
+    """skimage.transform.resize(image, output_shape) of scikit-image 0.17.2 (reference requirements.txt:19) with its
+    defaults, restated - the package is not installed here, so THIS restatement is unpinned by the reference: order 1,
+    mode 'reflect' (scipy 'mirror'), anti_aliasing on: ndimage.gaussian_filter with sigma = max(0, (in/out - 1)/2) per axis
+    (0 along channels), then warp() by the axis-aligned affine map  in = (out + 0.5) * in/out - 0.5  with bilinear
+    interpolation (floor / ceil neighbours, mirror boundary)."""
+    from scipy import ndimage as ndi
+    image = np.asarray(image, np.float64)
+    out_shape = tuple(output_shape) + (image.shape[-1],) if len(output_shape) == image.ndim - 1 else tuple(output_shape)
+    factors = np.asarray(image.shape, float) / np.asarray(out_shape, float)
+    sigma = np.maximum(0, (factors - 1) / 2)
+    image = ndi.gaussian_filter(image, sigma, cval=0, mode="mirror")
+
+    def mirror(i, n):
+        if n == 1:
+            return np.zeros_like(i)
+        p = 2 * (n - 1)
+        i = np.mod(i, p)
+        return np.where(i < n, i, p - i)
+    rows, cols = out_shape[0], out_shape[1]
+    r = factors[0] * (np.arange(rows) + 0.5) - 0.5
+    c = factors[1] * (np.arange(cols) + 0.5) - 0.5
+    r0, r1 = np.floor(r).astype(int), np.ceil(r).astype(int)
+    c0, c1 = np.floor(c).astype(int), np.ceil(c).astype(int)
+    dr, dc = (r - r0)[:, None, None], (c - c0)[None, :, None]
+    R0, R1, C0, C1 = mirror(r0, image.shape[0]), mirror(r1, image.shape[0]), mirror(c0, image.shape[1]), mirror(c1, image.shape[1])
+    top = (1 - dc) * image[R0][:, C0] + dc * image[R0][:, C1]
+    bot = (1 - dc) * image[R1][:, C0] + dc * image[R1][:, C1]
+    return (1 - dr) * top + dr * bot
+
+
+def crop(img: np.ndarray, center, scale, res) -> np.ndarray:
+    """utils/dataprocess.py:48-96 with rot = 0: paste the box (zero outside the frame), resize to `res`."""
+    ul, br = crop_box(center, scale, res)
+    new_shape = [br[1] - ul[1], br[0] - ul[0], img.shape[2]]
+    new_img = np.zeros(new_shape)
+    new_x = max(0, -ul[0]), min(br[0], len(img[0])) - ul[0]
+    new_y = max(0, -ul[1]), min(br[1], len(img)) - ul[1]
+    old_x = max(0, ul[0]), min(len(img[0]), br[0])
+    old_y = max(0, ul[1]), min(len(img), br[1])
+    new_img[new_y[0]:new_y[1], new_x[0]:new_x[1]] = img[old_y[0]:old_y[1], old_x[0]:old_x[1]]
+    return skimage_resize(new_img, res)
+
+
+IMG_NORM_MEAN, IMG_NORM_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # reference constants.py:15-16
+
+
+def rgb_processing(rgb_img: np.ndarray, center, scale, res=224) -> np.ndarray:
+    """boa_dataset/pw3d.py:131-136 + :121-123 (test time): crop, HWC->CHW, /255, Normalize.  -> (3, res, res) float32."""
+    x = crop(rgb_img.copy(), center, scale, [res, res])
+    x = np.transpose(x.astype("float32"), (2, 0, 1)) / 255.0
+    return ((x - np.array(IMG_NORM_MEAN, np.float32)[:, None, None]) / np.array(IMG_NORM_STD, np.float32)[:, None, None]).astype(np.float32)
+
+
+def j2d_processing(kp: np.ndarray, center, scale, res=224) -> np.ndarray:
+    """boa_dataset/pw3d.py:138-151 (test time: no flip): keypoints into the crop frame, then to [-1, 1]."""
+    kp = kp.copy()
+    for i in range(kp.shape[0]):
+        kp[i, 0:2] = transform_pt(kp[i, 0:2] + 1, center, scale, [res, res])
+    kp[:, :-1] = 2. * kp[:, :-1] / res - 1.
+    return kp.astype("float32")

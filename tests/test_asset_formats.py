@@ -120,3 +120,26 @@ def test_adaptor_from_reference_tree(emu_lib, data_tree, monkeypatch):
     verts, j49 = O.smpl_forward(T, betas, rot[:, 1:], rot[:, :1], pose2rot=False)
     assert rel_err(out.vertices.numpy(), verts.numpy()) < 1e-5
     assert rel_err(out.joints.numpy(), j49.numpy()) < 1e-5
+
+
+@pytest.mark.slow
+def test_adaptor_real_data_path_one_frame(emu_lib, data_tree, monkeypatch):
+    """The reference's CLI path end to end with NO synthetic bundle: Adaptor(options) builds the 3DPW loader and the exemplar
+    set from a reference-style data tree (default flags: retrieval=1, labelled exemplars, teacher, dynamic loop), excute()
+    walks the first frame - decode, device crop, lower level with a retrieved exemplar, upper level, Adam, metrics."""
+    from test_preprocess import populate_stream
+    from dynaboa_amd import benchmark as DB
+    tree = populate_stream(data_tree["root"])
+    monkeypatch.chdir(data_tree["root"])
+    o = DB.parser.parse_args([])
+    o.model_file, o.pw3d_root, o.h36m_root = "data/basemodel.pt", tree["imgroot"], tree["h36root"]
+    o.expdir = str(data_tree["root"] / "exps")
+    ad = DB.Adaptor(o, None, device="cpu")
+    assert len(ad.dataloader) == 9 and len(ad.h36m_dataset) == 12 and tuple(ad.centers.shape) == (3, 2048)
+    first = next(iter(ad.dataloader))
+    theta0 = ad.model.module.theta.detach().clone()
+    res = ad.excute([first], nframes=1)
+    assert np.isfinite(res["mpjpe"][0]).all() and np.isfinite(res["pampjpe"][0]).all()
+    assert float((ad.model.module.theta.detach() - theta0).abs().max()) > 0
+    assert "ll/labled_loss" in ad.last_summaries and "teacher/loss" in ad.last_summaries and len(ad.optim_step_record) == 1
+    assert os.path.exists(os.path.join(o.expdir, o.expname, "seq_order.record"))

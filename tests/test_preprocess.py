@@ -1,0 +1,224 @@
+"""Frame preprocessing (crop + anti-aliased resize + normalise on the device), the 3DPW / exemplar datasets in the
+reference's on-disk formats, and the real retrieval path - on the kernel emulator here, on cuda:0 under `-m gpu`.
+
+Pins: golden g7 = the reference's own utils/dataprocess.py crop() / transform() run in the build container (with the
+oracle's restatement of scikit-image 0.17.2 `resize` plugged in, skimage being absent: tools/make_golden.py g7), plus
+first-principles known answers for that restatement."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+
+MEAN = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
+STD = np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    from emu.build_emu import build
+    from dynaboa_amd import _abi, _lib
+    lib = _abi.bind(ctypes.CDLL(build()))
+    saved = _lib._lib
+    _lib.use_library(lib)
+    yield lib
+    _lib._lib = saved
+
+
+# ---------------------------------------------------------------------------- oracle vs the reference's crop()
+def test_oracle_crop_matches_reference_golden():
+    from oracle import ref_cpu as O
+    g = golden("g7_preprocess.npz")
+    img = g["img"].astype(np.float32)
+    for i in range(int(g["ncases"])):
+        c, s, res = g[f"c{i}_center"], float(g[f"c{i}_scale"]), int(g[f"c{i}_res"])
+        ul, br = O.crop_box(c, s, [res, res])
+        assert np.array_equal(ul, g[f"c{i}_ul"]) and np.array_equal(br, g[f"c{i}_br"]), i        # the reference's box arithmetic
+        out = O.crop(img.copy(), c, s, [res, res])
+        assert np.abs(out - g[f"c{i}_out"]).max() < 1e-3, i
+    kp = O.j2d_processing(g["kp"], g["c1_center"], float(g["c1_scale"]))
+    assert np.array_equal(kp, g["kp_out"])
+
+
+def test_resize_restatement_known_answers():
+    """skimage.transform.resize (0.17.2 defaults) restated: constants stay constant, same-size is the identity, an
+    upscaled linear ramp stays that ramp away from the mirrored border, a 2x box downscale of a smooth field is close to
+    its area average (the anti-aliasing filter is on)."""
+    from oracle import ref_cpu as O
+    assert np.allclose(O.skimage_resize(np.full((37, 53, 3), 7.5), (20, 30)), 7.5, atol=1e-12)
+    x = np.random.default_rng(0).random((16, 24, 3))
+    assert np.allclose(O.skimage_resize(x, (16, 24)), x, atol=1e-12)
+    ramp = np.tile(np.arange(20, dtype=float)[None, :, None], (10, 1, 1))
+    up = O.skimage_resize(ramp, (10, 40))
+    expect = 0.5 * (np.arange(40) + 0.5) - 0.5
+    assert np.allclose(up[5, 4:-4, 0], expect[4:-4], atol=1e-9)
+    yy, xx = np.mgrid[0:64, 0:64]
+    f = np.sin(xx / 9.0)[..., None] + np.cos(yy / 7.0)[..., None]
+    dn = O.skimage_resize(f, (32, 32))
+    box = f.reshape(32, 2, 32, 2, 1).mean((1, 3))
+    assert np.abs(dn - box)[3:-3, 3:-3].max() < 2e-2
+
+
+# ---------------------------------------------------------------------------- the HIP kernels vs golden / oracle
+def _check_crop_kernel(device):
+    from dynaboa_amd import datasets as D
+    g = golden("g7_preprocess.npz")
+    img = torch.from_numpy(g["img"]).to(device)
+    for i in range(int(g["ncases"])):
+        c, s, res = g[f"c{i}_center"], float(g[f"c{i}_scale"]), int(g[f"c{i}_res"])
+        out = D.preprocess_frame(img, c, s, res=res).cpu().numpy()
+        want = (np.transpose(g[f"c{i}_out"], (2, 0, 1)) / 255.0 - MEAN) / STD
+        assert out.shape == (3, res, res)
+        assert np.abs(out - want).max() < 2e-4, (i, np.abs(out - want).max())          # normalised units, range ~[-2.2, 2.7]
+    with pytest.raises(ValueError):
+        D.preprocess_frame(img.float(), g["c0_center"], 0.5)
+
+
+def test_crop_kernel_matches_reference_golden(emu_lib):
+    _check_crop_kernel("cpu")
+
+
+@pytest.mark.gpu
+def test_crop_kernel_matches_reference_golden_gpu():
+    _check_crop_kernel("cuda:0")
+
+
+@pytest.mark.gpu
+def test_crop_kernel_real_frame_size_gpu():
+    """A 1080 x 1920 frame (3DPW's size) with a 600 px box (downscale 2.7, 11-tap filter) against the oracle."""
+    from dynaboa_amd import datasets as D
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:1080, 0:1920]
+    img = np.stack([xx % 256, yy % 256, (xx // 3 + yy // 2) % 256], -1).astype(np.uint8)
+    img = (img.astype(np.int32) + rng.integers(-15, 15, img.shape)).clip(0, 255).astype(np.uint8)
+    c, s = np.array([1700.0, 300.0]), 3.0                  # the box leaves the frame on two sides
+    out = D.preprocess_frame(torch.from_numpy(img).to("cuda:0"), c, s).cpu().numpy()
+    want = O.rgb_processing(img.astype(np.float32), c, s)
+    assert np.abs(out - want).max() < 3e-4
+
+
+# ---------------------------------------------------------------------------- datasets in the reference's formats
+def _write_png(path, arr):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+@pytest.fixture(scope="module")
+def stream_tree(tmp_path_factory):
+    return populate_stream(tmp_path_factory.mktemp("stream"))
+
+
+def populate_stream(root):
+    """A reference-style tree: data/dataset_extras/3dpw_<seq>_<pid>.npz (boa_dataset/pw3d.py:179-196 keys), the frames they
+    name, the retrieval files of base_adaptor.py:76-80,55 (joblib) and the exemplar frames."""
+    import joblib
+    rng = np.random.default_rng(11)
+    imgroot, h36root = root / "pw3d_images", root / "h36m_images"
+    extras = root / "data" / "dataset_extras"
+    extras.mkdir(parents=True, exist_ok=True)
+    frames = {}
+    specs = [("3dpw_10_0.npz", 3, "m"), ("3dpw_2_1.npz", 2, "f"), ("3dpw_2_0.npz", 4, "m")]     # written out of order on purpose
+    for fname, n, gd in specs:
+        names = []
+        for i in range(n):
+            rel = f"imageFiles/{fname[:-4]}/image_{i:05d}.png"
+            img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+            _write_png(str(imgroot / rel), img)
+            frames[rel] = img
+            names.append(rel)
+        np.savez(extras / fname, imgname=np.array(names), scale=rng.uniform(0.3, 0.7, n), center=rng.uniform(30, 90, (n, 2)),
+                 pose=rng.normal(0, 0.2, (n, 72)), shape=rng.normal(0, 0.5, (n, 10)),
+                 j2d=np.concatenate([rng.uniform(0, 120, (n, 49, 2)), (rng.random((n, 49, 1)) < 0.8).astype(float)], 2),
+                 op_j2d=np.concatenate([rng.uniform(0, 120, (n, 25, 2)), rng.random((n, 25, 1))], 2), gender=np.array([gd] * n))
+    # exemplar set + clusters
+    M = 12
+    names = []
+    for i in range(M):
+        rel = f"S1/img_{i:04d}.png"
+        _write_png(str(h36root / rel), rng.integers(0, 256, (80, 80, 3), dtype=np.uint8))
+        names.append(rel)
+    rr = root / "data" / "retrieval_res"
+    rr.mkdir(parents=True, exist_ok=True)
+    src = dict(imgname=np.array(names), scale=rng.uniform(0.25, 0.4, M), center=rng.uniform(30, 50, (M, 2)), pose=rng.normal(0, 0.2, (M, 72)),
+               shape=rng.normal(0, 0.5, (M, 10)), S=np.concatenate([rng.normal(0, 0.3, (M, 24, 3)), np.ones((M, 24, 1))], 2),
+               part=np.concatenate([rng.uniform(0, 80, (M, 24, 2)), (rng.random((M, 24, 1)) < 0.8).astype(float)], 2))
+    joblib.dump(src, rr / "h36m_random_sample_center_10_10.pt")
+    centers = rng.normal(0, 1, (3, 2048)).astype(np.float32)
+    joblib.dump(dict(centers=centers, index=[[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]), rr / "cluster_res_random_sample_center_10_10_potocol2.pt")
+    return dict(root=root, imgroot=str(imgroot), h36root=str(h36root), frames=frames, src=src, centers=centers)
+
+
+def _check_pw3d(stream_tree, device):
+    from dynaboa_amd import datasets as D, sharding
+    from oracle import ref_cpu as O
+    ds = D.PW3D(None, npz_dir=str(stream_tree["root"] / "data" / "dataset_extras"), img_dir=stream_tree["imgroot"], device=device)
+    assert [os.path.basename(f) for f in ds.files] == ["3dpw_2_0.npz", "3dpw_2_1.npz", "3dpw_10_0.npz"]       # int(seq)*10+int(pid)
+    assert len(ds) == 9 and [s["frames"] for s in ds.sequences] == [4, 2, 3] and [s["first"] for s in ds.sequences] == [0, 4, 6]
+    it = ds[5]
+    d = np.load(ds.files[1])
+    c, s = d["center"][1], float(d["scale"][1])
+    frame = stream_tree["frames"][str(d["imgname"][1])]
+    assert it["imgname"] == str(d["imgname"][1]) and int(it["gender"]) == 1 and it["dataset_name"] == "3dpw"
+    assert np.abs(it["image"].cpu().numpy() - O.rgb_processing(frame.astype(np.float32), c, s)).max() < 3e-4
+    assert np.array_equal(it["smpl_j2d"].cpu().numpy(), O.j2d_processing(d["j2d"][1], c, s))
+    assert np.array_equal(it["op_j2d"].cpu().numpy(), O.j2d_processing(d["op_j2d"][1], c, s))
+    assert np.allclose(it["pose"].cpu().numpy(), d["pose"][1].astype(np.float32)) and tuple(it["j3d"].shape) == (24, 4)
+    assert np.allclose(it["bbox"].cpu().numpy(), [c[0], c[1], s * 200])
+    # batches with the reference loader's shapes; a rank's shard walks whole sequences
+    batches = list(D.FrameLoader(ds, batch_size=2, workers=2))
+    assert len(batches) == 5 and tuple(batches[0]["image"].shape) == (2, 3, 224, 224) and tuple(batches[0]["smpl_j2d"].shape) == (2, 49, 3)
+    assert tuple(batches[-1]["image"].shape) == (1, 3, 224, 224) and batches[0]["gender"].dtype == torch.long
+    assert torch.equal(batches[2]["image"][1], it["image"])
+    mine = sharding.shard_stream(ds.sequences, 1, 2)
+    idx = [i for sq in mine for i in range(sq["first"], sq["first"] + sq["frames"])]
+    assert idx == [4, 5, 6, 7, 8]                                     # LPT: rank 0 gets the 4-frame sequence, rank 1 the other two
+    assert len(list(D.FrameLoader(ds, 1, workers=1, indices=idx))) == 5
+
+
+def test_pw3d_dataset_reference_format(emu_lib, stream_tree):
+    _check_pw3d(stream_tree, "cpu")
+
+
+@pytest.mark.gpu
+def test_pw3d_dataset_reference_format_gpu(stream_tree):
+    _check_pw3d(stream_tree, "cuda:0")
+
+
+def test_source_dataset_and_real_retrieval(emu_lib, stream_tree, monkeypatch):
+    """SourceDataset items (base_adaptor.py:476-506) and BaseAdaptor.retrieval with NO synthetic bundle: nearest centre by
+    cosine distance -> seeded random.sample of that cluster's indices -> items concatenated (base_adaptor.py:82-96)."""
+    from dynaboa_amd import benchmark as DB, datasets as D
+    from dynaboa_amd.base_adaptor import BaseAdaptor
+    from oracle import ref_cpu as O
+    src = stream_tree["src"]
+    ds = D.SourceDataset(str(stream_tree["root"] / "data" / "retrieval_res" / "h36m_random_sample_center_10_10.pt"),
+                         img_dir=stream_tree["h36root"], device="cpu")
+    assert len(ds) == 12
+    it = ds[7]
+    assert tuple(it["keypoints"].shape) == (1, 49, 3) and tuple(it["img"].shape) == (1, 3, 224, 224)
+    assert tuple(it["pose"].shape) == (1, 72) and tuple(it["betas"].shape) == (1, 10) and tuple(it["pose_3d"].shape) == (1, 24, 4)
+    kp = np.concatenate([np.zeros((25, 3)), src["part"][7]], 0)
+    assert np.array_equal(it["keypoints"][0].numpy(), O.j2d_processing(kp, src["center"][7], float(src["scale"][7])))
+    assert float(it["keypoints"][0, :25, 2].abs().sum()) == 0.0                # the 25 OpenPose slots carry zero confidence
+    # the adaptor's own retrieval(): only the pieces it touches are set up (no model needed)
+    monkeypatch.chdir(stream_tree["root"])
+    a = BaseAdaptor.__new__(BaseAdaptor)
+    a.options = DB.parser.parse_args([])
+    a.options.sample_num = 2
+    a.device, a.bundle, a.global_step = torch.device("cpu"), None, 0
+    a.load_h36_cluster_res()
+    a.h36m_dataset = ds
+    feat = torch.from_numpy(stream_tree["centers"][1:2] * 0.7 + 0.01)          # closest (cosine) to centre 1
+    random.seed(5)
+    batch = a.retrieval(feat)
+    random.seed(5)
+    want = random.sample([4, 5, 6, 7], 2)
+    assert tuple(batch["img"].shape) == (2, 3, 224, 224) and tuple(batch["pose_3d"].shape) == (2, 24, 4)
+    for j, i in enumerate(want):
+        assert torch.equal(batch["pose"][j], ds[i]["pose"][0]) and torch.equal(batch["img"][j], ds[i]["img"][0])

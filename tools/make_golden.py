@@ -414,9 +414,47 @@ def g6(out):
     print("g6 ok")
 
 
+# ---------------------------------------------------------------------------- G7 crop / keypoint preprocessing
+def g7(out):
+    """utils/dataprocess.py crop() + transform() and boa_dataset/pw3d.py j2d_processing arithmetic, run from the reference's
+    own module.  skimage is not installed: its `resize` (imported by name into dataprocess) is replaced by the oracle's
+    restatement of scikit-image 0.17.2's defaults, so the fixtures pin the box / paste / keypoint arithmetic to the reference
+    and the resize to the restatement."""
+    dp = load_file("ref_dataprocess", "utils/dataprocess.py")
+    dp.resize = O.skimage_resize
+    rng = np.random.default_rng(707)
+    H, W = 150, 200
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) * 3 % 256)], -1).astype(np.uint8)
+    img = (img.astype(np.int32) + rng.integers(-20, 20, img.shape)).clip(0, 255).astype(np.uint8)
+    cases = [  # center (x, y), scale (box = 200 * scale px), res
+        ((100.0, 75.0), 0.5, 64),       # 100 px box inside the frame: downscale 1.56
+        ((100.0, 75.0), 0.9, 64),       # 180 px box, sticks out top / bottom: downscale 2.8
+        ((20.0, 130.0), 0.6, 64),       # mostly outside (left / bottom)
+        ((120.5, 60.25), 0.2, 64),      # 40 px box: upscale (no anti-aliasing)
+        ((90.0, 70.0), 0.62, 224),      # the real output size, 124 px box: upscale 1.8
+    ]
+    payload = dict(img=img)
+    for i, (c, s, res) in enumerate(cases):
+        o = dp.crop(img.astype(np.float32).copy(), np.array(c), s, [res, res])
+        ul = np.array(dp.transform([1, 1], np.array(c), s, [res, res], invert=1)) - 1
+        br = np.array(dp.transform([res + 1, res + 1], np.array(c), s, [res, res], invert=1)) - 1
+        payload.update({f"c{i}_center": np.array(c), f"c{i}_scale": np.array(s), f"c{i}_res": np.array(res),
+                        f"c{i}_ul": ul, f"c{i}_br": br, f"c{i}_out": o.astype(np.float32)})
+    payload["ncases"] = np.array(len(cases))
+    kp = np.concatenate([rng.uniform(0, 200, (49, 2)), (rng.random((49, 1)) < 0.8).astype(float)], 1)
+    kpo = kp.copy()
+    for i in range(kpo.shape[0]):
+        kpo[i, 0:2] = dp.transform(kpo[i, 0:2] + 1, np.array(cases[1][0]), cases[1][1], [224, 224], rot=0)
+    kpo[:, :-1] = 2. * kpo[:, :-1] / 224 - 1.
+    payload.update(kp=kp, kp_out=kpo.astype(np.float32))
+    np.savez_compressed(os.path.join(out, "g7_preprocess.npz"), **payload)
+    print("g7 ok", {k: v.shape for k, v in payload.items() if k.endswith("_out")})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
