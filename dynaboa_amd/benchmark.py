@@ -81,6 +81,9 @@ parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
                          'concurrently with the next adaptation step (same arithmetic, same results); 2 = also issue '
                          'them from a second host thread')
+parser.add_argument('--teacher_dropout', type=int, default=0, choices=[0, 1],
+                    help='1: leave the mean teacher in train() mode like the reference does (base_adaptor.py:151-158 never calls '
+                         'teacher.eval()): live Dropout(0.5) after fc1 / fc2 in the teacher forward; 0: deterministic teacher')
 parser.add_argument('--native_step', type=int, default=1, choices=[0, 1],
                     help='1: configurations the native frame stepper covers (first order, frame-loss set; csrc/adapt_step.hip) '
                          'run as ONE C call per frame - same kernels, same order, identical weights; 0: always the '

@@ -111,6 +111,7 @@ struct HmrPlan {
   size_t fc1_w, fc1_b, fc2_w, fc2_b, dec_w, dec_b;
   // activation arena
   size_t a_x4, a_pool, a_poolidx, a_xc[MAX_ITER], a_h1[MAX_ITER], a_h2[MAX_ITER], a_state, a_rot;
+  size_t a_h1d[MAX_ITER], a_h2d[MAX_ITER];      // train mode only: the hidden vectors after nn.Dropout (model/hmr.py:165,169)
   size_t act_floats;
   int poolH, poolW;            // max-pool output
   int featHW;                  // spatial size of the last feature map (7*7)
@@ -213,6 +214,8 @@ static HmrPlan* build_plan(int B, int H, int W) {
     P.a_xc[t] = aoff; aoff = align64(aoff + (size_t)B * FC1_IN_PAD);
     P.a_h1[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
     P.a_h2[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
+    P.a_h1d[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
+    P.a_h2d[t] = aoff; aoff = align64(aoff + (size_t)B * HID);
   }
   P.a_state = aoff; aoff = align64(aoff + (size_t)B * STATE_LD);
   P.a_rot = aoff; aoff = align64(aoff + (size_t)B * 24 * 9);
@@ -324,7 +327,13 @@ extern "C" int dyb_hmr_tensor_info(const void* plan, int i, char* name, int name
 // Activation-arena locations of the 15 "features" of HMR.forward(need_feature=True)
 // (reference model/hmr.py:139-168).  which: 0 = conv1 output, 1..4 = layer1..4 outputs (NHWC),
 // 5 = pooled vector (row stride 2208), 6+3t / 7+3t = fc1 output of iteration t, 8+3t = fc2 output.
+extern "C" int dyb_hmr_feature_info_ex(const void* plan, int which, int train, long long* offset, int* dims4, int* row_stride);
 extern "C" int dyb_hmr_feature_info(const void* plan, int which, long long* offset, int* dims4, int* row_stride) {
+  return dyb_hmr_feature_info_ex(plan, which, 0, offset, dims4, row_stride);
+}
+// train != 0: features 7+3t are the fc1 outputs AFTER drop1 (model/hmr.py:165-166); in eval mode Dropout is the identity and
+// they alias features 6+3t
+extern "C" int dyb_hmr_feature_info_ex(const void* plan, int which, int train, long long* offset, int* dims4, int* row_stride) {
   const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
   DYB_REQUIRE(P && offset && dims4 && row_stride && which >= 0 && which < 15, DYB_ERR_ARG);
   dims4[0] = P->B; dims4[1] = dims4[2] = dims4[3] = 0;
@@ -338,7 +347,7 @@ extern "C" int dyb_hmr_feature_info(const void* plan, int which, long long* offs
     *offset = (long long)P->a_xc[0]; dims4[1] = FEAT; *row_stride = FC1_IN_PAD;
   } else {
     int t = (which - 6) / 3, r = (which - 6) % 3;
-    *offset = (long long)(r == 2 ? P->a_h2[t] : P->a_h1[t]); dims4[1] = HID; *row_stride = HID;
+    *offset = (long long)(r == 2 ? P->a_h2[t] : ((r == 1 && train) ? P->a_h1d[t] : P->a_h1[t])); dims4[1] = HID; *row_stride = HID;
   }
   return DYB_OK;
 }
@@ -350,6 +359,53 @@ extern "C" long long dyb_hmr_act_offset_state(const void* plan) { return (long l
     int rc__ = (x);             \
     if (rc__ != DYB_OK) return rc__; \
   } while (0)
+
+// ---- nn.Dropout(p = 0.5) of the regressor (reference model/hmr.py:84,86,165,169), train mode only ------------------------
+// Counter-based (Philox-4x32-10): the keep mask of element i of stream s is a pure function of (seed, offset, s, i), so
+// the backward pass regenerates it instead of storing it.  y = x * keep / (1 - p).
+struct DropCfg {
+  int on;
+  unsigned long long seed, offset;
+  float p;
+};
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// y[i] = x[i] * keep(i) / (1 - p); y may alias x (backward: the gradient is masked in place).  n % 4 == 0.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int n4, DropCfg d,
+                                                      unsigned stream_id, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, x); DYB_RB(R, y);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  unsigned r[4];
+  philox4x32_10((unsigned)i, stream_id, (unsigned)d.offset, (unsigned)(d.offset >> 32) + (unsigned)dyb_rep * 0x632BE5ABu,
+                (unsigned)d.seed, (unsigned)(d.seed >> 32), r);
+  const float scale = 1.f / (1.f - d.p);
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  float4 o;
+  // uniform in [0, 1) from the top 24 bits; keep with probability 1 - p
+  o.x = ((r[0] >> 8) * (1.f / 16777216.f) >= d.p) ? v.x * scale : 0.f;
+  o.y = ((r[1] >> 8) * (1.f / 16777216.f) >= d.p) ? v.y * scale : 0.f;
+  o.z = ((r[2] >> 8) * (1.f / 16777216.f) >= d.p) ? v.z * scale : 0.f;
+  o.w = ((r[3] >> 8) * (1.f / 16777216.f) >= d.p) ? v.w * scale : 0.f;
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+static int dropout_launch(const float* x, float* y, int n, const DropCfg& d, unsigned stream_id, hipStream_t st) {
+  DYB_REQUIRE(n % 4 == 0, DYB_ERR_UNSUPPORTED);
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(dropout_kernel, dim3(dyb_cdiv(n / 4, 256), 1, R.n), dim3(256), 0, st, x, y, n / 4, d, stream_id, R);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+static const DropCfg kNoDrop = {0, 0, 0, 0.f};
 
 struct WsCarve {
   char *conv, *conv_aux, *lin;
@@ -460,7 +516,7 @@ static int run_cached(HmrPlan& P, std::unordered_map<GKey, GEntry, GKeyHash>& ca
 // image: [B][3][H][W] fp32 (NCHW, as the reference's dataloader produces it); init_state:
 // [B][160] = init_pose | init_shape | init_cam | 0.  Results land in the activation arena.
 static int forward_body(const HmrPlan& P, const float* params, const float* init_state, int n_iter, float* acts,
-                        const WsCarve& w, hipStream_t st);
+                        const WsCarve& w, hipStream_t st, const DropCfg& drop = kNoDrop);
 
 extern "C" int dyb_hmr_forward(void* plan, const float* params, const float* image, const float* init_state,
                                int n_iter, float* acts, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -478,7 +534,7 @@ extern "C" int dyb_hmr_forward(void* plan, const float* params, const float* ima
 }
 
 static int forward_body(const HmrPlan& P, const float* params, const float* init_state, int n_iter, float* acts,
-                        const WsCarve& w, hipStream_t st) {
+                        const WsCarve& w, hipStream_t st, const DropCfg& drop) {
   const int B = P.B;
   const ConvL& stem = P.convs[0];
   int nA = 0, nB = 0, nD = 0;                 // partial counts behind w.gn[0], [1], [2]
@@ -515,12 +571,21 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
     const float* xc = acts + P.a_xc[t];
     RUN(dyb_linear_fwd(xc, FC1_IN_PAD, params + P.fc1_w, FC1_IN_PAD, params + P.fc1_b, nullptr, 0, acts + P.a_h1[t], HID, B,
                        FC1_IN_PAD, HID, st));
-    RUN(dyb_linear_fwd(acts + P.a_h1[t], HID, params + P.fc2_w, HID, params + P.fc2_b, nullptr, 0, acts + P.a_h2[t], HID, B,
-                       HID, HID, st));
+    // train mode: xc = drop1(fc1(xc)); xc = drop2(fc2(xc)) (model/hmr.py:163-169); eval: Dropout is the identity
+    const float* h1 = acts + P.a_h1[t];
+    if (drop.on) {
+      RUN(dropout_launch(h1, acts + P.a_h1d[t], B * HID, drop, 2u * t, st));
+      h1 = acts + P.a_h1d[t];
+    }
+    RUN(dyb_linear_fwd(h1, HID, params + P.fc2_w, HID, params + P.fc2_b, nullptr, 0, acts + P.a_h2[t], HID, B, HID, HID, st));
+    const float* h2 = acts + P.a_h2[t];
+    if (drop.on) {
+      RUN(dropout_launch(h2, acts + P.a_h2d[t], B * HID, drop, 2u * t + 1u, st));
+      h2 = acts + P.a_h2d[t];
+    }
     float* nxt = (t + 1 < n_iter) ? acts + P.a_xc[t + 1] + FEAT : acts + P.a_state;
     int ldn = (t + 1 < n_iter) ? FC1_IN_PAD : STATE_LD;
-    RUN(dyb_linear_fwd(acts + P.a_h2[t], HID, params + P.dec_w, HID, params + P.dec_b, xc + FEAT, FC1_IN_PAD, nxt, ldn, B,
-                       HID, STATE_LD, st));
+    RUN(dyb_linear_fwd(h2, HID, params + P.dec_w, HID, params + P.dec_b, xc + FEAT, FC1_IN_PAD, nxt, ldn, B, HID, STATE_LD, st));
   }
   RUN(dyb_rot6d_fwd(acts + P.a_state, STATE_LD, acts + P.a_rot, B, st));
   return DYB_OK;
@@ -635,7 +700,8 @@ static int layer_dgrad_k4(HmrPlan& P, int ci, int pi, const float* params, const
 // aux_stream (may be NULL): a second stream the weight-gradient convolutions are issued on; the call
 // returns with `stream` already waiting for them, so callers keep ordering on `stream` only.
 static int backward_body(HmrPlan& P, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
-                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E);
+                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E,
+                         const DropCfg& drop = kNoDrop);
 
 // the same call with the caller's own event set and no graph cache: what the native frame stepper issues (several chains
 // of one plan may be in flight on different streams, each with its own workspace and events)
@@ -662,6 +728,34 @@ int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, c
   return forward_body(*Pp, params, init_state, n_iter, acts, w, st);
 }
 
+// train-mode variants: nn.Dropout(0.5) after fc1 / fc2 of every regressor iteration (reference model/hmr.py:84,86,165,169).
+// (seed, offset) select the masks; the backward of a forward must be given the same pair.  No graph cache.
+extern "C" int dyb_hmr_forward_train(void* plan, const float* params, const float* image, const float* init_state, int n_iter,
+                                     float* acts, void* ws, size_t ws_bytes, unsigned long long seed, unsigned long long offset,
+                                     float p, hipStream_t st) {
+  HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && image && init_state && acts && ws && p >= 0.f && p < 1.f, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(ws_bytes >= Pp->ws_total && Pp->featHW == 49, DYB_ERR_WORKSPACE);
+  WsCarve w = carve(*Pp, ws);
+  RUN(dyb_nchw3_to_nhwc4(image, acts + Pp->a_x4, Pp->B, Pp->H, Pp->W, st));
+  const DropCfg d{1, seed, offset, p};
+  return forward_body(*Pp, params, init_state, n_iter, acts, w, st, d);
+}
+extern "C" int dyb_hmr_backward_train(void* plan, const float* params, const float* acts, const float* d_rotmat,
+                                      const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes,
+                                      unsigned long long seed, unsigned long long offset, float p, hipStream_t st, hipStream_t aux) {
+  HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
+  DYB_REQUIRE(Pp && params && acts && d_rotmat && d_state && grads && ws && p >= 0.f && p < 1.f, DYB_ERR_ARG);
+  DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(ws_bytes >= Pp->ws_total, DYB_ERR_WORKSPACE);
+  if (aux == st) aux = nullptr;
+  if (aux) RUN(ensure_events(*Pp));
+  WsCarve w = carve(*Pp, ws);
+  const DropCfg d{1, seed, offset, p};
+  return backward_body(*Pp, params, acts, d_rotmat, d_state, n_iter, grads, w, st, aux, Pp->ev, d);
+}
+
 extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* acts, const float* d_rotmat,
                                 const float* d_state, int n_iter, float* grads, void* ws, size_t ws_bytes,
                                 hipStream_t st, hipStream_t aux) {
@@ -680,7 +774,8 @@ extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* ac
 }
 
 static int backward_body(HmrPlan& P, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
-                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E) {
+                         int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E,
+                         const DropCfg& drop) {
   const int B = P.B;
   float* d_st[MAX_ITER + 1];
   float *d_h2[MAX_ITER], *d_h1[MAX_ITER];
@@ -697,17 +792,19 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   for (int t = n_iter - 1; t >= 0; --t) {
     RUN(dyb_linear_bwd_dx(d_st[t + 1], STATE_LD, params + P.dec_w, HID, B, HID, STATE_LD, d_h2[t], HID, 0, HID, nullptr, 0,
                           nullptr, 0, w.lin, P.ws_lin, st));
+    if (drop.on) RUN(dropout_launch(d_h2[t], d_h2[t], B * HID, drop, 2u * t + 1u, st));       // through drop2: same mask, same scale
     RUN(dyb_linear_bwd_dx(d_h2[t], HID, params + P.fc2_w, HID, B, HID, HID, d_h1[t], HID, 0, HID, nullptr, 0, nullptr, 0,
                           w.lin, P.ws_lin, st));
+    if (drop.on) RUN(dropout_launch(d_h1[t], d_h1[t], B * HID, drop, 2u * t, st));            // through drop1
     RUN(dyb_linear_bwd_dx(d_h1[t], HID, params + P.fc1_w, FC1_IN_PAD, B, FC1_IN_PAD, HID, d_xf, FC1_IN_PAD,
                           t < n_iter - 1 ? 1 : 0, FEAT, d_st[t], STATE_LD, d_st[t + 1], STATE_LD, w.lin, P.ws_lin, st));
   }
   {
     const float *dys[MAX_ITER], *xs[MAX_ITER];
     int ldd[MAX_ITER], ldx[MAX_ITER];
-    for (int t = 0; t < n_iter; ++t) { dys[t] = d_st[t + 1]; ldd[t] = STATE_LD; xs[t] = acts + P.a_h2[t]; ldx[t] = HID; }
+    for (int t = 0; t < n_iter; ++t) { dys[t] = d_st[t + 1]; ldd[t] = STATE_LD; xs[t] = acts + (drop.on ? P.a_h2d[t] : P.a_h2[t]); ldx[t] = HID; }
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, HID, STATE_LD, grads + P.dec_w, HID, grads + P.dec_b, st));
-    for (int t = 0; t < n_iter; ++t) { dys[t] = d_h2[t]; ldd[t] = HID; xs[t] = acts + P.a_h1[t]; ldx[t] = HID; }
+    for (int t = 0; t < n_iter; ++t) { dys[t] = d_h2[t]; ldd[t] = HID; xs[t] = acts + (drop.on ? P.a_h1d[t] : P.a_h1[t]); ldx[t] = HID; }
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, HID, HID, grads + P.fc2_w, HID, grads + P.fc2_b, st));
     for (int t = 0; t < n_iter; ++t) { dys[t] = d_h1[t]; ldd[t] = HID; xs[t] = acts + P.a_xc[t]; ldx[t] = FC1_IN_PAD; }
     RUN(dyb_linear_bwd_dw(dys, ldd, xs, ldx, n_iter, B, FC1_IN_PAD, HID, grads + P.fc1_w, FC1_IN_PAD, grads + P.fc1_b, st));

@@ -137,7 +137,8 @@ def level_forward(model, smpl, prior, image, kp2d, w2d, wshape, wpose, n_iter: i
     if theta is None:
         theta = hmr.theta
     if hmr.training:
-        raise NotImplementedError("the adaptation path runs model.eval() (dynaboa_benchmark.py:89)")
+        raise NotImplementedError("the fused level node is the eval-mode path (the adaptation loop runs model.eval(), "
+                                  "dynaboa_benchmark.py:89); in train() mode use fused_level=0 / the HMR module directly")
     st0 = hmr.make_init_state(image.shape[0])
     out = _LevelFunction.apply(theta, image, st0, kp2d, smpl, prior, w2d, wshape, wpose, n_iter, need_feature)
     return out[0], out[1], out[2], out[3], out[4], out[5], out[6], list(out[7:])

@@ -82,12 +82,13 @@ def get_bwd_stage(L: HmrLayout, device: torch.device) -> dict:
     return st
 
 
-def _feature_views(L: HmrLayout, acts: torch.Tensor, n_iter: int):
+def _feature_views(L: HmrLayout, acts: torch.Tensor, n_iter: int, train: bool = False):
     """The reference's feature list (model/hmr.py:139-168) as views of the activation arena.
     Spatial maps are exposed NCHW-shaped (channels-last strides) so shapes match the reference."""
     out = []
+    feats = L.features_train if train else L.features
     for i in range(6 + 3 * n_iter):
-        f = L.features[i]
+        f = feats[i]
         d = [x for x in f["dims"] if x > 0]
         if len(d) == 4:
             v = acts[f["offset"]:f["offset"] + d[0] * d[1] * d[2] * d[3]].view(d[0], d[1], d[2], d[3]).permute(0, 3, 1, 2)
@@ -97,9 +98,19 @@ def _feature_views(L: HmrLayout, acts: torch.Tensor, n_iter: int):
     return out
 
 
+_DROP_CALLS = [0]
+
+
+def next_dropout_key():
+    """(seed, offset) of the next train-mode forward: torch's global seed and a per-process call counter, so that
+    torch.manual_seed() reproduces a run and every forward draws fresh masks."""
+    _DROP_CALLS[0] += 1
+    return int(torch.initial_seed()) & ((1 << 64) - 1), _DROP_CALLS[0]
+
+
 class _HMRFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, theta, image, init_state, n_iter, need_feature):
+    def forward(ctx, theta, image, init_state, n_iter, need_feature, drop=None):
         lib = _lib.load()
         B, _, H, W = image.shape
         L = get_layout(B, H, W)
@@ -109,15 +120,20 @@ class _HMRFunction(torch.autograd.Function):
         init_state = init_state.contiguous().float()
         acts = torch.empty(L.act_floats, dtype=torch.float32, device=theta.device)
         ws = get_workspace(L, theta.device)
-        check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter,
-                                  acts.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
-        ctx.L, ctx.n_iter = L, n_iter
+        if drop is None:
+            check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter,
+                                      acts.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
+        else:       # train mode: nn.Dropout after fc1 / fc2 (reference model/hmr.py:165,169)
+            check(lib.dyb_hmr_forward_train(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter, acts.data_ptr(),
+                                            ws.data_ptr(), L.ws_bytes, drop[0], drop[1], float(drop[2]), stream_of(theta)),
+                  "dyb_hmr_forward_train")
+        ctx.L, ctx.n_iter, ctx.drop = L, n_iter, drop
         ctx.save_for_backward(theta, acts)
         # outputs are views of the activation arena (kept alive by them; nobody writes it afterwards)
         rot = acts[L.off_rotmat:L.off_rotmat + B * 216].view(B, 24, 3, 3)
         st = acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD)
         shape, cam = st[:, 144:154], st[:, 154:157]
-        feats = tuple(_feature_views(L, acts, n_iter)) if need_feature else ()
+        feats = tuple(_feature_views(L, acts, n_iter, train=drop is not None)) if need_feature else ()
         ctx.mark_non_differentiable(*feats)
         return (rot, shape, cam) + feats
 
@@ -142,16 +158,23 @@ class _HMRFunction(torch.autograd.Function):
         else:
             d_rot_s.zero_()
         ws = get_workspace(L, theta.device)
-        check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot_s.data_ptr(), d_state.data_ptr(),
-                                   ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta),
-                                   aux_stream_of(theta)),
-              "dyb_hmr_backward")
-        return grads.clone(), None, None, None, None
+        if ctx.drop is None:
+            check(lib.dyb_hmr_backward(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot_s.data_ptr(), d_state.data_ptr(),
+                                       ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, stream_of(theta),
+                                       aux_stream_of(theta)),
+                  "dyb_hmr_backward")
+        else:
+            d = ctx.drop
+            check(lib.dyb_hmr_backward_train(L.plan, theta.data_ptr(), acts.data_ptr(), d_rot_s.data_ptr(), d_state.data_ptr(),
+                                             ctx.n_iter, grads.data_ptr(), ws.data_ptr(), L.ws_bytes, d[0], d[1], float(d[2]),
+                                             stream_of(theta), aux_stream_of(theta)), "dyb_hmr_backward_train")
+        return grads.clone(), None, None, None, None, None
 
 
-def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False):
-    """Functional form used by the MAML learner: forward with an explicit parameter arena."""
-    out = _HMRFunction.apply(theta, image, init_state, n_iter, need_feature)
+def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False, drop=None):
+    """Functional form used by the MAML learner: forward with an explicit parameter arena.  drop = (seed, offset, p):
+    train mode (Dropout after fc1 / fc2)."""
+    out = _HMRFunction.apply(theta, image, init_state, n_iter, need_feature, drop)
     if need_feature:
         return out[0], out[1], out[2], list(out[3:])
     return out[0], out[1], out[2]
@@ -159,6 +182,7 @@ def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False):
 
 class HMR(nn.Module):
     """SMPL iterative regressor with ResNet-50(GroupNorm) backbone; parameters live in one arena."""
+    dropout_p = 0.5        # nn.Dropout() default, reference model/hmr.py:84,86
 
     def __init__(self, smpl_mean_params, seed: Optional[int] = None):
         super().__init__()
@@ -223,12 +247,10 @@ class HMR(nn.Module):
         return st
 
     def forward(self, x, need_feature=False, init_pose=None, init_shape=None, init_cam=None, n_iter=3, theta=None):
-        if self.training:
-            raise NotImplementedError(
-                "HMR.forward in train() mode would need the two nn.Dropout layers of model/hmr.py:84,86; the "
-                "adaptation path always runs model.eval() (dynaboa_benchmark.py:89). Call .eval() first.")
         st = self.make_init_state(x.shape[0], init_pose, init_shape, init_cam)
-        return hmr_apply(self.theta if theta is None else theta, x, st, n_iter, need_feature)
+        # train(): the two nn.Dropout() layers of reference model/hmr.py:84,86 are live (p = 0.5, fresh masks per call)
+        drop = next_dropout_key() + (self.dropout_p,) if self.training else None
+        return hmr_apply(self.theta if theta is None else theta, x, st, n_iter, need_feature, drop)
 
 
 def hmr(smpl_mean_params, pretrained: bool = False, **kwargs) -> HMR:

@@ -46,6 +46,12 @@ class HmrLayout:
             lib.dyb_hmr_feature_info(plan, w, ctypes.cast(ctypes.pointer(off), ctypes.c_void_p),
                                      ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(ctypes.pointer(rs), ctypes.c_void_p))
             self.features.append(dict(offset=off.value, dims=list(dims), row_stride=rs.value))
+        # train mode: features 7+3t are the hidden vectors AFTER drop1 (reference model/hmr.py:165-166)
+        self.features_train: List[dict] = []
+        for w in range(15):
+            lib.dyb_hmr_feature_info_ex(plan, w, 1, ctypes.cast(ctypes.pointer(off), ctypes.c_void_p),
+                                        ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(ctypes.pointer(rs), ctypes.c_void_p))
+            self.features_train.append(dict(offset=off.value, dims=list(dims), row_stride=rs.value))
         # whole-call hipGraph caching inside the engine.  OFF by default: measured on MI355X / ROCm 7.2 with a
         # 97 % replay rate the host needs MORE time per frame (19.1 ms vs 15.2 ms eager) - hipGraphLaunch of a
         # 180-330-node graph is slower than the engine's own C++ launch loop.  DYB_GRAPHS=1 enables it.

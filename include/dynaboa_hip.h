@@ -315,6 +315,18 @@ int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs, int recor
 int dyb_stepper_join(void* stepper, dyb_stream_t stream);
 const float* dyb_stepper_output(const void* stepper, int which);
 
+/* HMR in train() mode: nn.Dropout(p) after fc1 / fc2 of every regressor iteration (reference model/hmr.py:84,86,165,169 -
+ * the reference's mean teacher runs like this, base_adaptor.py:151-158 never calls teacher.eval()).  Masks are
+ * counter-based (Philox-4x32-10) functions of (seed, offset, iteration, element): a backward regenerates them from the same
+ * pair.  dyb_hmr_feature_info_ex(train = 1) locates the post-dropout hidden vectors (features 7+3t). */
+int dyb_hmr_forward_train(void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
+                          float* acts, void* ws, size_t ws_bytes, unsigned long long seed, unsigned long long offset, float p,
+                          dyb_stream_t stream);
+int dyb_hmr_backward_train(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
+                           int n_iter, float* grads, void* ws, size_t ws_bytes, unsigned long long seed,
+                           unsigned long long offset, float p, dyb_stream_t stream, dyb_stream_t aux_stream);
+int dyb_hmr_feature_info_ex(const void* plan, int which, int train, long long* offset, int* dims4, int* row_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,8 +186,15 @@ def test_hmr_forward_explicit_init_and_n_iter_vs_reference(ckpt_rand):
     assert rel_err(s.cpu().numpy(), g["alt_shape"]) < 1e-5 and rel_err(c.cpu().numpy(), g["alt_cam"]) < 1e-5
     assert len(feats) == 15 and list(feats[1].shape) == [1, 256, 56, 56] and list(feats[12].shape) == [1, 1024]
     assert rel_err(r3.cpu().numpy(), g["rotmat"][:1]) < 1e-5
-    with pytest.raises(NotImplementedError):
-        m.train()(img)
+    # train(): live Dropout after fc1 / fc2 (model/hmr.py:165,169) - fresh masks per call, finite, different from eval
+    m.train()
+    with torch.no_grad():
+        ra, sa, ca = m(img)
+        rb, sb, cb = m(img)
+    assert torch.isfinite(ra).all() and not torch.equal(sa, sb) and not torch.equal(sa, s3)
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(img)[1], s3)
 
 
 def test_batch4_frame_matches_oracle(gmm_t, smpl_tabs):
@@ -539,3 +546,52 @@ def test_replica_group_is_bit_identical_to_single_sequences():
             np.testing.assert_allclose(np.ravel(np.array(fl[r][k], np.float64)), np.ravel(np.array(singles[r][3][k], np.float64)), rtol=2e-5)
     # the replicas really differ from each other
     assert not torch.equal(ads[0].model.module.theta.detach(), ads[1].model.module.theta.detach())
+
+
+def test_train_mode_dropout_matches_reference_distribution(ckpt_rand):
+    """HMR.train() against the reference module left in train() mode (golden g8: 512 forwards of one frame with live
+    nn.Dropout(0.5), what the reference's mean teacher does - base_adaptor.py:151-158).  RNG streams cannot be matched, the
+    distribution can: the regressor is linear downstream of the masks, so the mean equals the eval output and the
+    per-output standard deviation is fixed by the weights."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr import hmr
+    g = golden("g8_dropout.npz")
+    mp = assets.make_smpl_mean_params(identity_pose=False, seed=3)
+    m = hmr(mp, seed=1).to("cuda:0")
+    m.load_state_dict(ckpt_rand, strict=True)
+    img = assets.make_frame(0, 1, seed=22)["image"].to("cuda:0")
+    N = 1024
+    m.train()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        o = torch.stack([torch.cat([x.flatten() for x in m(img)]) for _ in range(N)]).double().cpu()
+    mean, std = o.mean(0).numpy(), o.std(0).numpy()
+    ref_mean, ref_std = g["mean"], g["std"]
+    big = ref_std > 0.2 * ref_std.max()
+    assert big.sum() > 20
+    ratio = std[big] / ref_std[big]
+    print("dropout std ratio: median %.3f min %.3f max %.3f" % (np.median(ratio), ratio.min(), ratio.max()))
+    assert 0.9 < np.median(ratio) < 1.1 and ratio.min() > 0.75 and ratio.max() < 1.3        # two Monte-Carlo estimates (512 / 1024 draws)
+    se = np.sqrt(ref_std ** 2 / int(g["n"]) + std ** 2 / N)
+    assert (np.abs(mean - ref_mean)[big] < 6 * se[big]).all()
+    m.eval()
+    with torch.no_grad():
+        e = torch.cat([x.flatten() for x in m(img)]).cpu().numpy()
+    assert rel_err(e, g["eval"]) < 1e-4
+
+
+def test_teacher_dropout_option_runs_reference_teacher_mode():
+    """--teacher_dropout 1: the mean teacher stays in train() mode like the reference's; the teacher term becomes noisy
+    (two identical runs with different seeds disagree in it) while --teacher_dropout 0 is deterministic."""
+    from dynaboa_amd import assets
+    frames = [{k: v.to("cuda:0") for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(2)]
+    vals = {}
+    for td in (0, 1):
+        for seed in (1, 2):
+            ad, _ = make_adaptor(dict(STREAMS["fo_inner1_full"][0], teacher_dropout=td, dynamic_boa=0), False)
+            torch.manual_seed(seed)
+            ad.excute(frames, nframes=2)
+            assert ad.teacher.training == bool(td)
+            vals[(td, seed)] = float(ad.last_summaries["teacher/loss"])
+    assert vals[(0, 1)] == vals[(0, 2)]
+    assert vals[(1, 1)] != vals[(1, 2)] and np.isfinite(vals[(1, 1)]) and vals[(1, 1)] > vals[(0, 1)]

@@ -452,9 +452,28 @@ def g7(out):
     print("g7 ok", {k: v.shape for k, v in payload.items() if k.endswith("_out")})
 
 
+# ---------------------------------------------------------------------------- G8 train-mode Dropout statistics
+def g8(out):
+    """The reference HMR left in train() mode (what its mean teacher is: base_adaptor.py:151-158 never calls .eval()): 512
+    forwards of one frame with live nn.Dropout(0.5) after fc1 / fc2.  RNG streams cannot be matched across
+    implementations, so the fixture is the DISTRIBUTION: per-output mean and standard deviation, plus the eval output."""
+    model, sd = build_ref_hmr()
+    img = assets.make_frame(0, 1, seed=22)["image"]
+    with torch.no_grad():
+        re, se, ce = model.eval()(img)
+        model.train()
+        torch.manual_seed(808)
+        N = 512
+        outs = [torch.cat([x.flatten() for x in model(img)]) for _ in range(N)]
+    o = torch.stack(outs).double()
+    np.savez_compressed(os.path.join(out, "g8_dropout.npz"), n=np.array(N), mean=o.mean(0).numpy(), std=o.std(0).numpy(),
+                        eval=torch.cat([re.flatten(), se.flatten(), ce.flatten()]).numpy())
+    print("g8 ok", float(o.std(0).mean()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7,g8")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
