@@ -30,6 +30,7 @@ F_GFLOP = 8.195           # one HMR forward, B=1 (SURVEY 8 header)
 B_GFLOP = 16.15           # dgrad + wgrad
 MIN_SCHEDULE_GFLOP = 4 * (F_GFLOP + B_GFLOP) + F_GFLOP      # 105.6: algorithmic work per adapted frame
 PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0                               # dense bf16 MFMA, same guide
 
 # the 53 convolutions as (count, H, W, Cin, Cout, k, stride, pad)
 RESNET_CONVS = [
@@ -248,14 +249,25 @@ def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
                 ms_per_step=r["dt"] * 1e3 / steps, pa_mpjpe_mm_synthetic_mean=pa_mean(r["metrics"]))
 
 
-def sub_record(device, name, steps, warmup, batch, inner_step, note, **kw):
-    """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each."""
+def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, **kw):
+    """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each; with
+    roofline_peak (TFLOP/s) also the conv family's in-path achieved rate against that peak (2 extra steps)."""
     try:
-        rn = Runner(device, 1, batch, inner_step, warmup + steps, frame_base=500_000, **kw)
-        r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device))
-        return dict(value=steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
-                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
-                    native_stepper=rn.native(), config=note)
+        extra = 2 if roofline_peak else 0
+        rn = Runner(device, 1, batch, inner_step, warmup + steps + extra, frame_base=500_000, **kw)
+        st = torch.cuda.Stream(device=device)
+        r = timed_stream(rn, warmup, steps, st)
+        out = dict(value=steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
+                   warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
+                   native_stepper=rn.native(), config=note)
+        if roofline_peak:
+            c = conv_roofline(r["run"], warmup + steps, warmup + steps + extra, st)
+            rn.flush()
+            if c is not None:
+                out["roofline"] = dict(bound="mfma", achieved=c["achieved"], peak=roofline_peak, unit="TFLOP/s",
+                                       frac=c["achieved"] / roofline_peak, avg_launch_us=c["avg_launch_us"],
+                                       conv_ms_per_step=c["conv_ms_per_frame"])
+        return out
     except Exception as e:      # noqa: BLE001
         return dict(value=None, error=f"{type(e).__name__}: {e}", config=note)
 
@@ -437,6 +449,13 @@ def main():
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
                                                  upper_level_mixtrain=1, sample_num=8)
+            out["batch16_fp32_vs_bf16"] = dict(
+                fp32=sub_record(device, "b16_fp32", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, "
+                                "fp32 MFMA (exact)", roofline_peak=PEAK_FP32_MFMA_TFLOPS),
+                bf16=sub_record(device, "b16_bf16", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, "
+                                "bf16 MFMA for the convolutions (fp32 master weights / activations / statistics / accumulators)",
+                                roofline_peak=PEAK_BF16_MFMA_TFLOPS, bf16_mfma=1))
+            __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(16).set_bf16(False)
             out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)

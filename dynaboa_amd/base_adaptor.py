@@ -97,6 +97,12 @@ class BaseAdaptor:
             self.model = model.to(self.device)
             self.model.load_state_dict({k.replace("module.", ""): v for k, v in ck.items()}, strict=True)
         self.optimizer = Adam(self.model.parameters(), lr=self.options.lr, betas=(self.options.beta1, self.options.beta2))
+        # precision of the backbone convolutions is a property of the engine plan (one per batch size, shared by every
+        # model of the process): set explicitly both ways so that a bf16 run does not leak into a later fp32 one
+        from .hmr import get_layout
+        want = bool(getattr(self.options, "bf16_mfma", 0))
+        for b in {1, int(getattr(self.options, "batch_size", 1)), int(getattr(self.options, "sample_num", 1))}:
+            get_layout(b).set_bf16(want)
 
     def set_teacher(self):
         teacher = hmr(self._mean_params(), seed=0)

@@ -81,6 +81,10 @@ parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '
                          'concurrently with the next adaptation step (same arithmetic, same results); 2 = also issue '
                          'them from a second host thread')
+parser.add_argument('--bf16_mfma', type=int, default=0, choices=[0, 1],
+                    help='1: the backbone convolutions run on the bf16 matrix cores (fp32 master weights, fp32 activations, '
+                         'GroupNorm statistics and accumulators; operand tiles rounded to bf16 as they are staged) - the '
+                         'fp32-vs-bf16 arm of BASELINE configs[4]; 0 (default): exact fp32, the parity mode')
 parser.add_argument('--teacher_dropout', type=int, default=0, choices=[0, 1],
                     help='1: leave the mean teacher in train() mode like the reference does (base_adaptor.py:151-158 never calls '
                          'teacher.eval()): live Dropout(0.5) after fc1 / fc2 in the teacher forward; 0: deterministic teacher')

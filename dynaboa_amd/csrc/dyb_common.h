@@ -26,6 +26,12 @@
   } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));          // A / B fragment of v_mfma_f32_32x32x16_bf16
+// fp32 -> bf16 bits, round to nearest even (NaN payloads are not preserved; the path never produces them)
+__device__ __forceinline__ unsigned dyb_f2bf(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int dyb_ilog2(int v) {
@@ -88,6 +94,14 @@ struct DybRepScope {
   DybRep saved;
   explicit DybRepScope(const DybRep& r);
   ~DybRepScope();
+};
+
+// bf16 matrix-core mode of the calling host thread (igemm_conv.hip)
+bool dyb_bf16_current();
+struct DybBf16Scope {
+  bool saved;
+  explicit DybBf16Scope(bool on);
+  ~DybBf16Scope();
 };
 
 // ---- cross-file internals (not part of the C ABI) ----------------------------------------

@@ -121,6 +121,7 @@ struct HmrPlan {
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
   int graph_mode;
+  int bf16;                    // convolutions of this plan run on the bf16 matrix cores (operands rounded when staged; fp32 everywhere else)
   int fold_in_reduce;          // leave data-gradient split-K slabs for the next GroupNorm-backward reduce to fold
   long g_hits, g_eager, g_captures, g_fail_begin, g_fail_body, g_fail_end, g_fail_inst, g_fail_launch;
   // cross-stream ordering for the weight-gradient convolutions (created on first use): the plan's own set serves the
@@ -224,6 +225,7 @@ static HmrPlan* build_plan(int B, int H, int W) {
   size_t wc = 0, wg = 0, maxact = 0, dyoff = 0, gnboff = 0;
   P.events_ready = false;
   P.graph_mode = 0;
+  P.bf16 = 0;
   {
     const char* e = getenv("DYB_FOLD_IN_REDUCE");
     P.fold_in_reduce = e ? atoi(e) : 1;     // measured 1.55 vs 1.75 ms per backward
@@ -441,6 +443,15 @@ static int conv_stats(const HmrPlan& P, const ConvL& c, const float* params, flo
                                      P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, w.conv, P.ws_conv, st);
 }
 
+// bf16-MFMA variant (BASELINE configs[4]): master weights, activations, GroupNorm statistics and accumulators stay fp32; the
+// conv operand tiles are rounded to bf16 as they are staged for v_mfma_f32_32x32x16_bf16.  Per plan; default off (the parity
+// mode is fp32).
+extern "C" int dyb_hmr_set_bf16(void* plan, int on) {
+  HmrPlan* P = reinterpret_cast<HmrPlan*>(plan);
+  DYB_REQUIRE(P, DYB_ERR_ARG);
+  P->bf16 = on ? 1 : 0;
+  return DYB_OK;
+}
 extern "C" int dyb_hmr_set_graph_mode(void* plan, int on) {
   HmrPlan* P = reinterpret_cast<HmrPlan*>(plan);
   DYB_REQUIRE(P, DYB_ERR_ARG);
@@ -535,6 +546,7 @@ extern "C" int dyb_hmr_forward(void* plan, const float* params, const float* ima
 
 static int forward_body(const HmrPlan& P, const float* params, const float* init_state, int n_iter, float* acts,
                         const WsCarve& w, hipStream_t st, const DropCfg& drop) {
+  DybBf16Scope bf(P.bf16 != 0);
   const int B = P.B;
   const ConvL& stem = P.convs[0];
   int nA = 0, nB = 0, nD = 0;                 // partial counts behind w.gn[0], [1], [2]
@@ -776,6 +788,7 @@ extern "C" int dyb_hmr_backward(void* plan, const float* params, const float* ac
 static int backward_body(HmrPlan& P, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
                          int n_iter, float* grads, const WsCarve& w, hipStream_t st, hipStream_t aux, const DybEvents& E,
                          const DropCfg& drop) {
+  DybBf16Scope bf(P.bf16 != 0);
   const int B = P.B;
   float* d_st[MAX_ITER + 1];
   float *d_h2[MAX_ITER], *d_h1[MAX_ITER];

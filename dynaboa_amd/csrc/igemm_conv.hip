@@ -375,7 +375,14 @@ __device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, 
   __syncthreads();
 }
 
-template <int MODE, bool GB, bool FA>
+// BF: the bf16 matrix-core variant (BASELINE configs[4]).  Everything up to the staging store is the same fp32 code - operands
+// come from fp32 HBM tensors (master weights, fp32 activations), the GroupNorm arithmetic of the fused loaders and the
+// accumulators stay fp32 - but the operand tiles are rounded to bf16 (nearest-even) when they are staged and the product runs
+// on v_mfma_f32_32x32x16_bf16 (16x the fp32 rate).  LDS tiles are then row-major [row][k] (k contiguous, +8 pad): a fragment
+// (lane -> row lane&31, eight consecutive k at 8*(lane>>5)) is one 16-byte read, a "4 consecutive k of one row" source one
+// 8-byte store.  Never the parity default: selected per plan (dyb_hmr_set_bf16).
+#define BFK (BK + 8)
+template <int MODE, bool GB, bool FA, bool BF = false>
 __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse f, GnFwdFuse nf, DybRep R) {
   DYB_REP_PROLOGUE(R);
   if (dyb_rep) {
@@ -383,8 +390,32 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     if constexpr (GB) rebase(f, R, dyb_rep);
     if constexpr (FA) rebase(nf, R, dyb_rep);
   }
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As[BF ? 1 : 2][BF ? 1 : BK][BF ? 4 : LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BF ? 1 : 2][BF ? 1 : BK][BF ? 4 : LDS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? 2 : 1][BF ? BM : 1][BF ? BFK : 8];
+  __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? 2 : 1][BF ? BN : 1][BF ? BFK : 8];
+  __shared__ float s_gbh[BF ? 4 * 64 * 2 : 4];
+  // staging stores: `k4` = a thread's 4 consecutive k of tile row `row`; `col4` = one k, 4 consecutive tile rows / columns
+  auto put_k4 = [&](bool isA, int buf, int k, int row, float4 v) {
+    if constexpr (BF) {
+      uint2 pk;
+      pk.x = dyb_f2bf(v.x) | (dyb_f2bf(v.y) << 16);
+      pk.y = dyb_f2bf(v.z) | (dyb_f2bf(v.w) << 16);
+      *reinterpret_cast<uint2*>(isA ? &Ah[buf][row][k] : &Bh[buf][row][k]) = pk;
+    } else {
+      float(*T)[LDS_LD] = isA ? As[buf] : Bs[buf];
+      T[k + 0][row] = v.x; T[k + 1][row] = v.y; T[k + 2][row] = v.z; T[k + 3][row] = v.w;
+    }
+  };
+  auto put_col4 = [&](bool isA, int buf, int k, int col0, float4 v) {
+    if constexpr (BF) {
+      unsigned short(*T)[BFK] = isA ? Ah[buf] : Bh[buf];
+      T[col0 + 0][k] = (unsigned short)dyb_f2bf(v.x); T[col0 + 1][k] = (unsigned short)dyb_f2bf(v.y);
+      T[col0 + 2][k] = (unsigned short)dyb_f2bf(v.z); T[col0 + 3][k] = (unsigned short)dyb_f2bf(v.w);
+    } else {
+      *reinterpret_cast<float4*>(isA ? &As[buf][k][col0] : &Bs[buf][k][col0]) = v;
+    }
+  };
   __shared__ float s_coef[GB ? 64 * DYB_GN_GROUPS * 4 : 4];   // [n][g] -> mean, rstd, c1, c2
   __shared__ float s_raw[GB ? 64 * DYB_GN_GROUPS * 2 : 4];
   __shared__ float s_nrm[FA ? 64 * DYB_GN_GROUPS * 2 : 4];     // [n][g] -> mean, rstd of the producer
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         const float* st = &s_nrm[(n * DYB_GN_GROUPS + (wa.c >> logCg)) * 2];
         v = o.ok ? gnf_apply(o.d, wa_gamma, wa_beta, st[0], st[1], nf.relu) : zero4;
       }
-      *reinterpret_cast<float4*>(&As[buf][16 * h + d_k][d_q]) = v;
+      put_col4(true, buf, 16 * h + d_k, d_q, v);
     } else {
       float4 v = o.d;
       if constexpr (FA && MODE == MODE_FWD) {
@@ -498,18 +529,12 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         const int ko = (kt * BK + 16 * h + t_kq) & (g.K - 1);
         v = o.ok ? gnb_apply(o, &s_coef[(da.n * DYB_GN_GROUPS + (ko >> logKg)) * 4]) : zero4;
       }
-      As[buf][16 * h + t_kq + 0][t_row] = v.x;
-      As[buf][16 * h + t_kq + 1][t_row] = v.y;
-      As[buf][16 * h + t_kq + 2][t_row] = v.z;
-      As[buf][16 * h + t_kq + 3][t_row] = v.w;
+      put_k4(true, buf, 16 * h + t_kq, t_row, v);
     }
   };
   auto store_b = [&](int buf, int kt, int h, const Frag& o) {
     if constexpr (MODE == MODE_DGRAD) {
-      Bs[buf][16 * h + t_kq + 0][t_row] = o.d.x;
-      Bs[buf][16 * h + t_kq + 1][t_row] = o.d.y;
-      Bs[buf][16 * h + t_kq + 2][t_row] = o.d.z;
-      Bs[buf][16 * h + t_kq + 3][t_row] = o.d.w;
+      put_k4(false, buf, 16 * h + t_kq, t_row, o.d);
     } else {
       float4 v = o.d;
       if constexpr (GB && MODE == MODE_WGRAD) {
@@ -519,7 +544,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         t.ga = wg_gamma;
         v = o.ok ? gnb_apply(t, &s_coef[(n * DYB_GN_GROUPS + ((n0 + d_q) >> logKg)) * 4]) : zero4;
       }
-      *reinterpret_cast<float4*>(&Bs[buf][16 * h + d_k][d_q]) = v;
+      put_col4(false, buf, 16 * h + d_k, d_q, v);
     }
   };
 
@@ -559,11 +584,20 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       // the GroupNorm arithmetic of the fused loaders) may be scheduled above the MFMAs - its wait would expose the
       // whole memory latency instead of overlapping it with the matrix work
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF) {
 #pragma unroll
-      for (int k2 = 0; k2 < BK; k2 += 2) {
-        float a = As[buf][k2 + khalf][arow];
-        float b = Bs[buf][k2 + khalf][bcol];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int kb = 0; kb < BK; kb += 16) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ah[buf][arow][kb + 8 * khalf]);
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bh[buf][bcol][kb + 8 * khalf]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+          float a = As[buf][k2 + khalf][arow];
+          float b = Bs[buf][k2 + khalf][bcol];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
@@ -602,7 +636,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     // (image, chunk) range of the per-channel partials and meet in LDS (reusing the A stage)
     if (blockIdx.x == 0 && dyb_bz == 0) {
       __syncthreads();
-      float(*s_gb)[64][2] = reinterpret_cast<float(*)[64][2]>(&As[0][0][0]);
+      float(*s_gb)[64][2] = reinterpret_cast<float(*)[64][2]>(BF ? &s_gbh[0] : &As[0][0][0]);
       const int cl = tid & 63, part = tid >> 6;
       const int c = n0 + cl, C = g.K;
       float A = 0.f, B = 0.f;
@@ -1043,6 +1077,12 @@ static float env_float(const char* name, float dflt) {
   return v ? (float)atof(v) : dflt;
 }
 
+// ---- bf16 matrix-core mode of the calling host thread: set by the engine around a forward / backward of a plan that asked
+// for it (dyb_hmr_set_bf16); the single-launch 1x1 kernels have no bf16 form, the tiled kernel + statistics launch serve
+static thread_local bool t_bf16 = false;
+DybBf16Scope::DybBf16Scope(bool on) : saved(t_bf16) { t_bf16 = on; }
+DybBf16Scope::~DybBf16Scope() { t_bf16 = saved; }
+
 // ---- current replica set of the calling host thread (dyb_common.h) ------------------------------------------------
 static thread_local DybRep t_rep = {1, 0, {}, {}, {}};
 const DybRep& dyb_rep_current() { return t_rep; }
@@ -1055,7 +1095,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit), "rep_split"
 // (split-K depth chosen for the replica-multiplied grid).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1063,12 +1103,15 @@ struct DybSwitches {
     k4_batch = env("DYB_K4_BATCH", 1);
     k4_maxc = env("DYB_K4_MAXC", 1024);
     rep_split = env("DYB_REP_SPLIT", 0);
+    bf16 = 0;
   }
 };
 static DybSwitches& switches() {
   static DybSwitches* s = new DybSwitches();
   return *s;
 }
+// bf16 mode: the engine's scope for this thread, or the process-wide "bf16" switch (direct calls of the conv entry points)
+bool dyb_bf16_current() { return t_bf16 || switches().bf16.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int>* find_switch(const char* name) {
   if (!name) return nullptr;
   DybSwitches& s = switches();
@@ -1077,6 +1120,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "k4_batch")) return &s.k4_batch;
   if (!strcmp(name, "k4_maxc")) return &s.k4_maxc;
   if (!strcmp(name, "rep_split")) return &s.rep_split;
+  if (!strcmp(name, "bf16")) return &s.bf16;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1220,10 +1264,16 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   const dim3 blk(256);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1);
-#define DYB_IGEMM_LAUNCH(M_, GB_, FA_)                                                                          \
-  do {                                                                                                          \
-    if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf, R); \
-    else hipLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_>), grid, blk, 0, st, g, f, nf, R);                  \
+  const bool bf = dyb_bf16_current();
+#define DYB_IGEMM_LAUNCH1(M_, GB_, FA_, BF_)                                                                           \
+  do {                                                                                                                 \
+    if (ev0) hipExtLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_, BF_>), grid, blk, 0, st, ev0, ev1, 0, g, f, nf, R); \
+    else hipLaunchKernelGGL((igemm_mfma_kernel<M_, GB_, FA_, BF_>), grid, blk, 0, st, g, f, nf, R);                    \
+  } while (0)
+#define DYB_IGEMM_LAUNCH(M_, GB_, FA_)              \
+  do {                                              \
+    if (bf) DYB_IGEMM_LAUNCH1(M_, GB_, FA_, true);  \
+    else DYB_IGEMM_LAUNCH1(M_, GB_, FA_, false);    \
   } while (0)
   if (mode == MODE_FWD) {
     DYB_REQUIRE(!fuse, DYB_ERR_UNSUPPORTED);
@@ -1240,6 +1290,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     else DYB_IGEMM_LAUNCH(MODE_WGRAD, false, false);
   }
 #undef DYB_IGEMM_LAUNCH
+#undef DYB_IGEMM_LAUNCH1
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
@@ -1320,7 +1371,7 @@ bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
   const DybSwitches& sw = switches();                   // k4_bwd on: 1.40 -> 1.31 ms per backward
   const int enabled = sw.k4_bwd.load(std::memory_order_relaxed), max_k = sw.k4_maxc.load(std::memory_order_relaxed);
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
+  return enabled && !dyb_bf16_current() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
          d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
 }
 // dx of the 1x1 conv `d` (never materialised as such) -> dm / partials of the producer's GroupNorm; *nch, *ncolb = the
@@ -1384,7 +1435,7 @@ bool dyb_conv_k4_ok(const ConvDesc& d) {
   // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
   // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
+  return enabled && !dyb_bf16_current() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }
 // conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count

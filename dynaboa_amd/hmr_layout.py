@@ -58,6 +58,7 @@ class HmrLayout:
         import os
         self.graphs = os.environ.get("DYB_GRAPHS", "0") == "1"
         lib.dyb_hmr_set_graph_mode(plan, 1 if self.graphs else 0)
+        self.bf16 = False
         self.off_rotmat = int(lib.dyb_hmr_act_offset_rotmat(plan))
         self.off_state = int(lib.dyb_hmr_act_offset_state(plan))
 
@@ -66,6 +67,14 @@ class HmrLayout:
             self.lib.dyb_hmr_plan_destroy(self.plan)
         except Exception:
             pass
+
+    def set_bf16(self, on: bool):
+        """bf16 matrix-core variant of this plan's convolutions (fp32 master weights / activations / accumulators; operand
+        tiles rounded as they are staged).  Never the parity default."""
+        self.bf16 = bool(on)
+        rc = self.lib.dyb_hmr_set_bf16(self.plan, 1 if on else 0)
+        if rc != 0:
+            raise RuntimeError(f"dyb_hmr_set_bf16 failed ({rc})")
 
     def graph_stats(self):
         st = (ctypes.c_longlong * 10)()

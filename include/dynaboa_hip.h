@@ -252,6 +252,10 @@ long long dyb_hmr_act_offset_state(const void* plan);  /* [B][160] pose|shape|ca
 /* graph mode: whole forward / backward calls are captured into hipGraphs keyed by their pointer
  * arguments (second sighting of a key) and replayed; results are those of the eager path. */
 int dyb_hmr_set_graph_mode(void* plan, int on);
+/* bf16-MFMA variant of the plan's convolutions (BASELINE configs[4]; never the parity default): fp32 master weights, fp32
+ * activations / GroupNorm statistics / accumulators, operand tiles rounded to bf16 (nearest even) as they are staged for
+ * v_mfma_f32_32x32x16_bf16.  The option "bf16" (dyb_set_option) does the same for direct calls of the conv entry points. */
+int dyb_hmr_set_bf16(void* plan, int on);
 int dyb_hmr_graph_stats(const void* plan, long long* stats10); /* replays, eager, captures, fwd keys, bwd keys, 5 failure counters */
 int dyb_hmr_forward(void* plan, const float* params, const float* image_nchw, const float* init_state, int n_iter,
                     float* acts, void* ws, size_t ws_bytes, dyb_stream_t stream);

@@ -60,6 +60,7 @@ struct Wave {
   unsigned char xbuf[2][64][16];
   unsigned long long dep_gen[2][64];   // generation in which each lane last deposited (+1; 0 = never)
   float a[2][64], b[2][64];
+  float a8[2][64][8], b8[2][64][8];
 };
 
 static thread_local char* g_stacks = nullptr;
@@ -157,6 +158,29 @@ void mfma_32x32x2(float a, float b, float* c) {
     float acc = c[r];
     acc = fmaf(w.a[par][i], w.b[par][j], acc);
     acc = fmaf(w.a[par][i + 32], w.b[par][j + 32], acc);
+    c[r] = acc;
+  }
+}
+
+static inline float bf16_to_f32(unsigned short h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+void mfma_32x32x16_bf16(const unsigned short* a8, const unsigned short* b8, float* c) {
+  Fiber& f = g_f[g_cur];
+  Wave& w = g_w[f.wave];
+  int par = (int)(w.gen & 1);
+  for (int i = 0; i < 8; ++i) { w.a8[par][f.lane][i] = bf16_to_f32(a8[i]); w.b8[par][f.lane][i] = bf16_to_f32(b8[i]); }
+  wave_sync(w);
+  // A[i][k = 8*kb + e] is element e of lane i + 32*kb, B[k][j] element e of lane j + 32*kb; D as for every 32x32 shape
+  int j = f.lane & 31, hi = f.lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int kb = 0; kb < 2; ++kb)
+      for (int e = 0; e < 8; ++e) acc = fmaf(w.a8[par][i + 32 * kb][e], w.b8[par][j + 32 * kb][e], acc);
     c[r] = acc;
   }
 }

@@ -82,6 +82,7 @@ extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void syncthreads();
 void wave_exchange(const void* mine, void* theirs, int src_lane, int bytes);
 void mfma_32x32x2(float a, float b, float* c16);
+void mfma_32x32x16_bf16(const unsigned short* a8, const unsigned short* b8, float* c16);
 int lane_id();
 void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx);
 template <class F>
@@ -124,6 +125,30 @@ static inline T __shfl_down(T v, int d) {
     for (int emu_i_ = 0; emu_i_ < 16; ++emu_i_) emu_r_[emu_i_] = emu_c_[emu_i_];        \
     emu_r_;                                                                             \
   })
+
+// v_mfma_f32_32x32x16_bf16: A fragment = row lane&31, eight consecutive k at 8*(lane>>5); B likewise by column
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)                       \
+  ({                                                                                    \
+    float emu_c_[16];                                                                   \
+    unsigned short emu_a_[8], emu_b_[8];                                                \
+    __typeof__(a) emu_av_ = (a);                                                        \
+    __typeof__(b) emu_bv_ = (b);                                                        \
+    memcpy(emu_a_, &emu_av_, 16);                                                       \
+    memcpy(emu_b_, &emu_bv_, 16);                                                       \
+    for (int emu_i_ = 0; emu_i_ < 16; ++emu_i_) emu_c_[emu_i_] = (c)[emu_i_];           \
+    emu::mfma_32x32x16_bf16(emu_a_, emu_b_, emu_c_);                                    \
+    __typeof__(c) emu_r_;                                                               \
+    for (int emu_i_ = 0; emu_i_ < 16; ++emu_i_) emu_r_[emu_i_] = emu_c_[emu_i_];        \
+    emu_r_;                                                                             \
+  })
+struct uint2 {
+  unsigned x, y;
+};
+static inline unsigned __float_as_uint(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return u;
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

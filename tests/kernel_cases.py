@@ -21,7 +21,14 @@ def _rng(seed):
 
 
 # ---------------------------------------------------------------------------------------- conv
-def case_conv(be, N, H, W, C, K, R, stride, pad, seed=0, c_real=None):
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 (nearest even) -> fp32: what the bf16 matrix-core variant does to an operand tile as it is staged."""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def case_conv(be, N, H, W, C, K, R, stride, pad, seed=0, c_real=None, bf16=False):
+    """bf16=True: the entry points run with the option "bf16" on (operands rounded to bf16 when staged, fp32 accumulate);
+    the reference then convolves the ROUNDED operands in fp32, so only the summation order differs."""
     rng = _rng(seed)
     x = rng.standard_normal((N, H, W, C)).astype(np.float32)
     if c_real is not None:
@@ -30,10 +37,23 @@ def case_conv(be, N, H, W, C, K, R, stride, pad, seed=0, c_real=None):
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     dy = rng.standard_normal((N, Ho, Wo, K)).astype(np.float32)
     add = rng.standard_normal((N, H, W, C)).astype(np.float32)
-    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-    wt = torch.from_numpy(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    if bf16:
+        be.lib.dyb_set_option(b"bf16", 1)
+        try:
+            xr, wr, dyr = bf16_round(x), bf16_round(w), bf16_round(dy)
+            e = _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, xr, wr, dyr)
+        finally:
+            be.lib.dyb_set_option(b"bf16", 0)
+        return e
+    return _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, x, w, dy)
+
+
+def _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, xr, wr, dyr):
+    xt = torch.from_numpy(xr).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wt = torch.from_numpy(wr).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    dy_ref_in = dyr
     yt = F.conv2d(xt, wt, stride=stride, padding=pad)
-    gx, gw = torch.autograd.grad(yt, [xt, wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+    gx, gw = torch.autograd.grad(yt, [xt, wt], torch.from_numpy(dy_ref_in).permute(0, 3, 1, 2))
     y_ref = yt.detach().permute(0, 2, 3, 1).numpy()
     dx_ref = gx.permute(0, 2, 3, 1).numpy() + add
     dw_ref = gw.permute(2, 3, 1, 0).numpy()

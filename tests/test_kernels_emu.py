@@ -182,3 +182,10 @@ def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, k4_batch):
         K.case_hmr_engine(be, golden, ckpt_rand)
     finally:
         be.lib.dyb_set_option(b"k4_batch", 1)
+
+
+@pytest.mark.parametrize("cfg", [(1, 9, 9, 32, 64, 3, 1, 1), (2, 8, 8, 64, 32, 1, 1, 0), (1, 12, 12, 16, 64, 3, 2, 1), (1, 6, 6, 128, 128, 1, 2, 0)])
+def test_conv_bf16_variant(be, cfg):
+    """bf16 matrix-core variant of the tiled conv (forward / data gradient / weight gradient): equal to an fp32 convolution
+    of the bf16-rounded operands up to summation order."""
+    K.case_conv(be, *cfg, seed=sum(cfg), bf16=True)
