@@ -582,10 +582,17 @@ void dyb_gn_bwd_layout(int N, int HW, int C, int* nch, int* ncolb) {
   int TX = CQ < 256 ? CQ : 256;
   *ncolb = CQ / TX;
 }
+// Large enough for BOTH layouts a layer's partial block can have: the reduce kernel's (nch row chunks x ncolb column blocks
+// per image) and the one a single-launch 1x1 data gradient leaves when it performs the producer's reduce in its epilogue
+// (32-row tiles x 32-channel blocks per image, igemm_conv.hip) - at batch 16 the latter is the bigger one for 28x28 maps
+// (the reduce layout shrinks its chunk count with the batch, the tile count does not).
 extern "C" size_t dyb_groupnorm_bwd_partial_floats(int N, int HW, int C) {
   int nch, ncolb;
   dyb_gn_bwd_layout(N, HW, C, &nch, &ncolb);
-  return (size_t)N * nch * 2 * C + (size_t)N * nch * ncolb * G * 2;
+  const size_t a = (size_t)N * nch * 2 * C + (size_t)N * nch * ncolb * G * 2;
+  const int tch = dyb_cdiv(HW, 32), tcolb = dyb_cdiv(C, 32);
+  const size_t b = (size_t)N * tch * 2 * C + (size_t)N * tch * tcolb * G * 2;
+  return a > b ? a : b;
 }
 // dm = dout masked by the ReLU (relu == 0: dm may equal dout, nothing is written then); part receives
 // the per-channel and per-group partial sums ([N*nch][2][C] | [N][nch*ncolb][G][2]).  out == NULL with
