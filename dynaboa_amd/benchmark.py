@@ -241,7 +241,10 @@ class Adaptor(BaseAdaptor):
         """Whether frames of this run go through the native stepper (decided once per reset_records)."""
         if self._native_why is None:
             from . import native_step as NS
-            why = NS.supported(self.options) if getattr(self.options, "native_step", 1) else "native_step=0"
+            if getattr(self.options, "native_step", 1):
+                why = None if NS.mode(self.options, self.bundle is not None) else NS.reason
+            else:
+                why = "native_step=0"
             self._native_why = why or ""
         return self._native_why == ""
 
@@ -249,8 +252,67 @@ class Adaptor(BaseAdaptor):
         from . import native_step as NS
         if self._native is None:
             self._native, self._native_replica = NS.NativeStepper(self, self._nframes), 0
+        if self._native.full:
+            return self._adapt_native_full(batch)
         f, slot = self._native.adapt_frame(batch, side_stream=self._side)
         return self._native_bookkeeping(f, slot)
+
+    def _adapt_native_full(self, batch):
+        """The reference's full term set through the native stepper: one C call for the whole frame incl. the dynamic loop."""
+        o, ns = self.options, self._native
+        K = o.inner_step
+        hist = None
+        if o.use_motion and (self.global_step - o.interval) > 0 and (o.use_temporal_losses_upper or o.use_temporal_losses_lower):
+            hist = self.get_hist()
+        ex = None
+        if (o.lower_level_mixtrain or o.upper_level_mixtrain) and self.bundle is not None:
+            ex = self._last_h36m = self.retrieval(None)          # the synthetic bundle's exemplars depend on the step only
+        f, slot, extra = ns.adapt_frame_full(batch, hist, ex)
+        log = self.fit_losses
+        for i in range(K):
+            self.kp2dlosses_lower.append(ns.level_row(f, i)[0])
+        rows = ((("ll", K - 1, bool(o.use_temporal_losses_lower), bool(o.lower_level_mixtrain)),) if K > 0 else ()) + \
+               (("ul", K + min(extra, o.optim_steps if o.dynamic_boa else 0), bool(o.use_temporal_losses_upper), bool(o.upper_level_mixtrain)),)
+        for tag, row, temporal, mix in rows:
+            r = ns.level_row(f, row)
+            log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"], log[f"{tag}/unlabelloss"] = r[0], r[1], r[2], r[3]
+            if temporal and o.use_meanteacher:
+                for j, k in enumerate(("s2dloss", "s3dloss", "shape_loss", "pose_loss", "loss")):
+                    log[f"teacher/{k}"] = r[4 + j]
+            if temporal and o.use_motion and hist is not None:
+                log["ul/motion_loss"] = r[9]
+            if mix:
+                for j, k in enumerate(("labled_s2dloss", "labled_s3dloss", "labled_shape_loss", "labled_pose_loss", "labled_loss")):
+                    log[f"{tag}/{k}"] = r[10 + j]
+            log[f"{tag}/total"] = r[15]
+        self.kp2dlosses_upper[self.global_step] = ns.level_row(f, K)[0]
+        out = (None, None, None)
+        nfinal = 1 + (min(extra, o.optim_steps) if o.dynamic_boa else 0)
+        tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', k) for k in range(nfinal)]
+        stats_m, stats_p = [], []
+        for tag in tags:
+            v = ns.record_views(slot)
+            slot += 1
+            if o.deferred_metrics:
+                self._pending.append(dict(step=self.global_step, tag=tag, **v))
+                res = (v["mpjpe"], None, v["pve"])
+            else:
+                pa = pa_mpjpe_device(v["pred"], v["gt"]).cpu().numpy()
+                res = (v["mpjpe"].cpu().numpy() * 1000, pa * 1000, float(v["pve"]) * 1000)
+            if tag[0] == 'lower':
+                self.mpjpe_all_lower[tag[1]].append(res[0]); self.pampjpe_all_lower[tag[1]].append(res[1])
+            else:
+                out = res
+                stats_m.append(res[0]); stats_p.append(res[1])
+        if self.global_step < len(self.mpjpe_statistics):
+            self.mpjpe_statistics[self.global_step], self.pampjpe_statistics[self.global_step] = stats_m, stats_p
+        if o.dynamic_boa:
+            gl = ns.gate_log[f]
+            self.feat_sims[self.global_step] = [{i: {"cos": gl[k, i]} for i in range(15)} for k in range(nfinal)]
+            log["feat_sim/cos_sim"] = gl[nfinal - 1, :15].sum() / 14          # the reference divides by the last index (base_adaptor.py:218)
+            self.optimized_step = extra
+            self.optim_step_record.append(extra)
+        return out
 
     def _native_bookkeeping(self, f, slot):
         """What adaptation() leaves behind besides the weights: logged losses, metric records, per-step statistics - read

@@ -43,6 +43,12 @@ int dyb_head_grad_combine(const float*, const float*, const float*, const float*
                           const float*, const float*, float*, float*, int, hipStream_t);
 int dyb_fastweight_update(const float*, const float*, float*, float, size_t, hipStream_t);
 int dyb_adam_step(float*, const float*, float*, float*, float, float, float, float, float, size_t, hipStream_t);
+int dyb_ema_update(float*, const float*, float, size_t, hipStream_t);
+int dyb_axpby(const float*, float*, float, float, size_t, hipStream_t);
+int dyb_aux_loss_terms(int, int, int, float, const float*, const float*, int, const float*, int, const float*, const float*,
+                       const float*, int, const float*, int, const float*, const float*, const float*, const float*, const float*,
+                       const float*, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
+int dyb_hmr_feature_info(const void*, int, long long*, int*, int*);
 }
 
 #define STATE_LD 160
@@ -114,6 +120,59 @@ __global__ void copy4_kernel(const float* __restrict__ src, float* __restrict__ 
   DYB_RB(Rp, src); DYB_RB(Rp, dst);
   if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
 }
+// the 16-float log row of one level of the full loss set: frame {s2d, shape prior, pose prior, total} | teacher {s2d, s3d, shape,
+// pose, loss} | motion | labelled {s2d, s3d, shape, pose, loss} | level total = frame + wt*teacher + wm*motion + wl*labelled
+__global__ void level_log_kernel(const float* __restrict__ frame4, const float* __restrict__ teach5, const float* __restrict__ motion5,
+                                 const float* __restrict__ label5, float wt, float wm, float wl, float* __restrict__ row16) {
+  if (threadIdx.x != 0) return;
+  float total = frame4[3];
+  for (int i = 0; i < 4; ++i) row16[i] = frame4[i];
+  for (int i = 0; i < 5; ++i) row16[4 + i] = teach5 ? teach5[i] : 0.f;
+  row16[9] = motion5 ? motion5[4] : 0.f;
+  for (int i = 0; i < 5; ++i) row16[10 + i] = label5 ? label5[i] : 0.f;
+  if (teach5) total += wt * teach5[4];
+  if (motion5) total += wm * motion5[4];
+  if (label5) total += wl * label5[4];
+  row16[15] = total;
+}
+// cal_feature_diff (reference base_adaptor.py:211-219): cosine of each of the 15 feature pairs (flattened), one workgroup per
+// feature; out[f] = cos_f, and - workgroup 12, the gate feature - the sequence number `seq` into out[15] AFTER its cosine, so a
+// host that polls out[15] (device-visible pinned memory) reads a complete out[12].
+struct FeatCosArgs {
+  long long off[15];
+  int rows[15], cols[15], ld[15];
+};
+__global__ __launch_bounds__(1024) void feat_cos_kernel(const float* __restrict__ A, const float* __restrict__ Bp, FeatCosArgs fa,
+                                                        float eps, float* __restrict__ out_dev, volatile float* out_host, float seq) {
+  __shared__ float sm[16][3];
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* a = A + fa.off[f];
+  const float* b = Bp + fa.off[f];
+  const long long n = (long long)fa.rows[f] * fa.cols[f];
+  float ab = 0.f, aa = 0.f, bb = 0.f;
+  for (long long i = t; i < n; i += 1024) {
+    const long long r = i / fa.cols[f], c = i - r * fa.cols[f];
+    const float x = a[r * fa.ld[f] + c], y = b[r * fa.ld[f] + c];
+    ab += x * y; aa += x * x; bb += y * y;
+  }
+  ab = dyb_wave_sum(ab); aa = dyb_wave_sum(aa); bb = dyb_wave_sum(bb);
+  if (lane == 0) { sm[wave][0] = ab; sm[wave][1] = aa; sm[wave][2] = bb; }
+  __syncthreads();
+  if (t == 0) {
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int w = 0; w < 16; ++w) { x += sm[w][0]; y += sm[w][1]; z += sm[w][2]; }
+    const float cs = x / sqrtf(fmaxf(y * z, eps * eps));     // torch cosine_similarity: x.y / sqrt(clamp(|x|^2 |y|^2, eps^2))
+    out_dev[f] = cs;
+    if (out_host) {
+      out_host[f] = cs;
+      if (f == 12) {
+        __threadfence_system();
+        out_host[15] = seq;
+      }
+    }
+  }
+}
+
 // replica r's frame inputs (separate caller tensors) into its staging area inside the workspace, one launch for all replicas
 #define DYB_MAX_REPLICAS 16
 struct GatherArgs {
@@ -149,6 +208,24 @@ struct Stepper {
   size_t n_params = 0, act_floats = 0, ws_bytes = 0, off_rot = 0, off_state = 0, lbs_saved = 0, lbs_wsb = 0;
   // options (doubles: the Python floats, so host-side scalars round exactly as in dynaboa_amd/optim.py / maml.py)
   int n_iter = 3, inner_step = 1, eval_lower = 1, use_side = 0, metrics = 1;
+  // the full loss set (reference defaults): teacher / motion / labelled-exemplar terms, dynamic-BOA gate
+  int full = 0, temporal_lower = 0, temporal_upper = 1, use_teacher = 1, use_motion = 1, interval = 5, mix_lower = 1, mix_upper = 1,
+      dynamic = 1, optim_steps = 7;
+  double teacher_w = 0.1, motion_w = 0.8, label_w = 0.1, alpha = 0.1, cos_thr = 3.1e-4;
+  float* teacher = nullptr;           // teacher parameter arena (caller's)
+  volatile float* gate_host = nullptr;   // 16 floats of device-visible pinned host memory (caller's): 15 cosines + sequence number
+  float* gate_log = nullptr;          // device: [loss_capacity][1 + optim_steps][16] cosines of every gate evaluation
+  float* feat5_out = nullptr;         // [B][2048] the level's pooled feature for the retrieval callback
+  int (*retrieve)(void*, int, const void**) = nullptr;
+  void* retrieve_user = nullptr;
+  FeatCosArgs fca{};
+  float gate_seq = 0.f;
+  Pass lvl0{}, ex{}, hist{}, teach{};
+  float *grads2 = nullptr, *zeros = nullptr, *ex_rot = nullptr;
+  float *ext_rot = nullptr, *ext_shape = nullptr, *ext_cam = nullptr, *ext_joints = nullptr;     // aux-term gradients on the image pass
+  float *exg_rot = nullptr, *exg_shape = nullptr, *exg_cam = nullptr, *exg_joints = nullptr;     // ... on the exemplar pass
+  float *hg_cam = nullptr, *hg_joints = nullptr;                                                 // ... on the history pass
+  float *vals_t = nullptr, *vals_m = nullptr, *vals_l = nullptr;
   int nrep = 1;                       // sequence replicas stepped in lockstep by every launch (dyb_common.h)
   size_t blob = 0;                    // workspace bytes of ONE replica
   float* in_stage[5] = {};            // image, kp2d, gt_pose, gt_betas, gender staging (replica 0; nrep > 1 only)
@@ -224,6 +301,20 @@ static size_t carve(Stepper& S, char* base) {
   S.gt_saved = take_f(S.lbs_saved);
   S.gt17[0] = take_f(B * 51);
   S.gt17[1] = take_f(B * 51);
+  if (S.full) {
+    S.lvl0 = S.main;                           // level 0 keeps its own activation arena: its features gate the dynamic loop
+    S.lvl0.acts = take_f(S.act_floats);
+    pass(S.ex, true);
+    pass(S.hist, true);
+    pass(S.teach, false);
+    S.grads2 = take_f(S.n_params);
+    S.zeros = take_f(B * 216);
+    S.ex_rot = take_f(B * 216);
+    S.ext_rot = take_f(B * 216); S.ext_shape = take_f(B * 10); S.ext_cam = take_f(B * 3); S.ext_joints = take_f(B * NJ * 3);
+    S.exg_rot = take_f(B * 216); S.exg_shape = take_f(B * 10); S.exg_cam = take_f(B * 3); S.exg_joints = take_f(B * NJ * 3);
+    S.hg_cam = take_f(B * 3); S.hg_joints = take_f(B * NJ * 3);
+    S.vals_t = take_f(8); S.vals_m = take_f(8); S.vals_l = take_f(8);
+  }
   if (S.nrep > 1) {
     S.in_stage[0] = take_f(B * 3 * (size_t)S.H * S.W);
     S.in_stage[1] = take_f(B * NJ * 3);
@@ -276,6 +367,16 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") S->adam_t = v;
+  else if (k == "full") S->full = (int)v;
+  else if (k == "temporal_lower") S->temporal_lower = (int)v;
+  else if (k == "temporal_upper") S->temporal_upper = (int)v;
+  else if (k == "use_teacher") S->use_teacher = (int)v;
+  else if (k == "use_motion") S->use_motion = (int)v;
+  else if (k == "interval") S->interval = (int)v;
+  else if (k == "mix_lower") S->mix_lower = (int)v;
+  else if (k == "mix_upper") S->mix_upper = (int)v;
+  else if (k == "dynamic") S->dynamic = (int)v;
+  else if (k == "optim_steps") S->optim_steps = (int)v;
   else if (k == "replicas") {
     DYB_REQUIRE(v >= 1 && v <= DYB_MAX_REPLICAS && !S->bound, DYB_ERR_ARG);
     S->nrep = (int)v;
@@ -297,6 +398,11 @@ extern "C" int dyb_stepper_set_f(void* stepper, const char* key, double v) {
   else if (k == "s2dloss_weight") S->w2d = v;
   else if (k == "shape_prior_weight") S->wshape = v;
   else if (k == "pose_prior_weight") S->wpose = v;
+  else if (k == "teacherloss_weight") S->teacher_w = v;
+  else if (k == "motionloss_weight") S->motion_w = v;
+  else if (k == "labelloss_weight") S->label_w = v;
+  else if (k == "alpha") S->alpha = v;
+  else if (k == "cos_sim_threshold") S->cos_thr = v;
   else return DYB_ERR_ARG;
   return DYB_OK;
 }
@@ -317,6 +423,12 @@ extern "C" int dyb_stepper_set_p(void* stepper, const char* key, const void* p) 
   else if (k == "j14") S->j14 = (const int*)p;
   else if (k == "records") S->records = (float*)p;
   else if (k == "loss_log") S->loss_log = (float*)p;
+  else if (k == "teacher") S->teacher = (float*)p;
+  else if (k == "gate_host") S->gate_host = (volatile float*)p;
+  else if (k == "gate_log") S->gate_log = (float*)p;
+  else if (k == "feat5_out") S->feat5_out = (float*)p;
+  else if (k == "retrieve_fn") S->retrieve = (int (*)(void*, int, const void**))p;
+  else if (k == "retrieve_user") S->retrieve_user = (void*)p;
   else {
     for (int g = 0; g < 3; ++g) {
       const std::string pf = std::string("smpl_") + which[g] + "_", pi = std::string("smpli_") + which[g] + "_";
@@ -339,7 +451,8 @@ extern "C" long long dyb_stepper_get_i(const void* stepper, const char* key) {
   const std::string k(key);
   if (k == "adam_step") return S->adam_t;
   if (k == "record_floats") return (long long)a64((size_t)S->B * 85 + 1);
-  if (k == "loss_floats") return 4 * (long long)(S->inner_step + 1);
+  if (k == "loss_floats") return (S->full ? 16 : 4) * (long long)(S->inner_step + 1 + (S->full && S->dynamic ? S->optim_steps : 0));
+  if (k == "slots_per_frame") return (S->eval_lower ? S->inner_step : 0) + 1 + (S->full && S->dynamic ? S->optim_steps : 0);
   return -1;
 }
 extern "C" size_t dyb_stepper_workspace_bytes(void* stepper) {
@@ -361,6 +474,24 @@ extern "C" int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes,
   for (int r = 0; r < S->nrep; ++r) {
     HIPOK(hipMemsetAsync(reinterpret_cast<char*>(S->grads) + (size_t)r * S->blob, 0, S->n_params * sizeof(float), st));
     HIPOK(hipMemsetAsync(reinterpret_cast<char*>(S->main.d_state) + (size_t)r * S->blob, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+  }
+  if (S->full) {
+    DYB_REQUIRE(S->nrep == 1, DYB_ERR_UNSUPPORTED);
+    HIPOK(hipMemsetAsync(S->zeros, 0, (size_t)S->B * 216 * sizeof(float), st));
+    HIPOK(hipMemsetAsync(S->grads2, 0, S->n_params * sizeof(float), st));
+    HIPOK(hipMemsetAsync(S->ex.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+    HIPOK(hipMemsetAsync(S->hist.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+    for (int f = 0; f < 15; ++f) {
+      long long off = 0;
+      int dims[4] = {0, 0, 0, 0}, rs = 0;
+      RUN(dyb_hmr_feature_info(S->plan, f, &off, dims, &rs));
+      S->fca.off[f] = off;
+      if (dims[2] > 0) {                                  // [B][H][W][C] dense
+        S->fca.rows[f] = 1; S->fca.cols[f] = dims[0] * dims[1] * dims[2] * dims[3]; S->fca.ld[f] = S->fca.cols[f];
+      } else {                                            // [B][cols] with a row stride
+        S->fca.rows[f] = dims[0]; S->fca.cols[f] = dims[1]; S->fca.ld[f] = rs;
+      }
+    }
   }
   S->bound = true;
   return DYB_OK;
@@ -500,6 +631,189 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
   }
   return DYB_OK;
 }
+// ---- the full loss set -------------------------------------------------------------------------------------------------
+// gradient of (frame loss [+ external terms]) or of external terms alone w.r.t. theta through pass P
+static int pass_backward_ext(Stepper& S, Pass& P, const float* theta, float* grads, bool frame_loss, const float* e_rot,
+                             const float* e_shape, const float* e_cam, const float* e_joints, hipStream_t st, hipStream_t aux) {
+  const size_t nj = (size_t)S.B * NJ * 3;
+  if (frame_loss) RUN(dyb_scale_add(nullptr, P.djoints_l, e_joints, P.djoints, nj, st));
+  else RUN(dyb_scale_add(nullptr, e_joints, nullptr, P.djoints, nj, st));
+  RUN(dyb_lbs_bwd(S.smpl_f[0], S.smpl_i[0], P.acts + S.off_rot, P.saved, P.djoints, nullptr, P.drot_s, P.dbetas_s, 10, S.B, P.lbs_ws,
+                  S.lbs_wsb, st));
+  const float* z = S.zeros;
+  RUN(dyb_head_grad_combine(nullptr, frame_loss ? P.drot_l : z, P.drot_s, e_rot, frame_loss ? P.dshape_l : z, P.dbetas_s, e_shape,
+                            frame_loss ? P.dcam_l : z, e_cam, P.d_rot, P.d_state, S.B, st));
+  return dyb_hmr_backward_ev(S.plan, theta, P.acts, P.d_rot, P.d_state, S.n_iter, grads, P.ws, S.ws_bytes, st, aux, S.ev);
+}
+enum { IN_IMAGE = 0, IN_KP, IN_GT_POSE, IN_GT_BETAS, IN_GENDER, IN_HIST_IMAGE, IN_HIST_KP, IN_EX_IMG, IN_EX_KP, IN_EX_POSE,
+       IN_EX_BETAS, IN_EX_POSE3D, IN_COUNT };
+struct FullCtx {
+  const void* in[IN_COUNT];
+  float* losslog;       // this frame's rows
+  int level_row;
+};
+// one level (reference base_adaptor.py:222-317 lower / upper_level_adaptation) at weights `cur` through pass P: loss terms,
+// log row, and the gradient of the level total w.r.t. `cur` in S.grads
+static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool upper, int level_index, hipStream_t st, hipStream_t aux) {
+  const int B = S.B;
+  const float* image = (const float*)C.in[IN_IMAGE];
+  const float* kp = (const float*)C.in[IN_KP];
+  RUN(pass_forward(S, P, cur, image, st));
+  RUN(pass_frame_head(S, P, kp, st));
+  const float* rot = P.acts + S.off_rot;
+  const float* state = P.acts + S.off_state;
+  const bool temporal = upper ? S.temporal_upper != 0 : S.temporal_lower != 0;
+  const bool teacher = temporal && S.use_teacher && S.teacher;
+  const bool motion = temporal && S.use_motion && C.in[IN_HIST_IMAGE] && C.in[IN_HIST_KP];
+  const bool label = (upper ? S.mix_upper : S.mix_lower) != 0;
+  bool ext = false;
+  if (teacher) {
+    // teacher forward (no gradient): reference base_adaptor.py:324-329
+    RUN(pass_forward(S, S.teach, S.teacher, image, st));
+    const float* ts = S.teach.acts + S.off_state;
+    RUN(dyb_aux_loss_terms(0, B, 0, (float)S.teacher_w, rot, state + 144, STATE_LD, state + 154, STATE_LD, P.joints,
+                           S.teach.acts + S.off_rot, ts + 144, STATE_LD, ts + 154, STATE_LD, S.teach.joints, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, S.vals_t, S.ext_rot, S.ext_shape, S.ext_cam, S.ext_joints, nullptr, nullptr, st));
+    ext = true;
+  }
+  if (motion) {
+    // the history frame through the SAME weights, with gradient (base_adaptor.py:380-386)
+    RUN(pass_forward(S, S.hist, cur, (const float*)C.in[IN_HIST_IMAGE], st));
+    const float* hs = S.hist.acts + S.off_state;
+    RUN(dyb_aux_loss_terms(1, B, ext ? 1 : 0, (float)S.motion_w, rot, state + 144, STATE_LD, state + 154, STATE_LD, P.joints, nullptr,
+                           nullptr, 0, hs + 154, STATE_LD, S.hist.joints, kp, (const float*)C.in[IN_HIST_KP], nullptr, nullptr, nullptr,
+                           S.vals_m, S.ext_rot, S.ext_shape, S.ext_cam, S.ext_joints, S.hg_cam, S.hg_joints, st));
+    ext = true;
+  }
+  if (label) {
+    // retrieval (base_adaptor.py:82-96) happens on the host: hand it the pooled feature of this level's forward
+    if (S.retrieve) {
+      DYB_REQUIRE(S.feat5_out, DYB_ERR_ARG);
+      RUN(dyb_scale_add(nullptr, P.acts + S.fca.off[5], nullptr, S.feat5_out, (size_t)0 + (size_t)B * 2048, st));   // B == 1: contiguous
+      const void* exin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (S.retrieve(S.retrieve_user, level_index, exin) != 0) return DYB_ERR_ARG;
+      for (int k = 0; k < 5; ++k) C.in[IN_EX_IMG + k] = exin[k];
+    }
+    DYB_REQUIRE(C.in[IN_EX_IMG] && C.in[IN_EX_KP] && C.in[IN_EX_POSE] && C.in[IN_EX_BETAS] && C.in[IN_EX_POSE3D], DYB_ERR_ARG);
+    RUN(pass_forward(S, S.ex, cur, (const float*)C.in[IN_EX_IMG], st));
+    RUN(dyb_rodrigues_fwd((const float*)C.in[IN_EX_POSE], S.ex_rot, B * 24, st));          // utils/geometry.py:9-24 on the exemplar pose
+    const float* es = S.ex.acts + S.off_state;
+    RUN(dyb_aux_loss_terms(2, B, 0, (float)S.label_w, S.ex.acts + S.off_rot, es + 144, STATE_LD, es + 154, STATE_LD, S.ex.joints, nullptr,
+                           nullptr, 0, nullptr, 0, nullptr, (const float*)C.in[IN_EX_KP], nullptr, S.ex_rot,
+                           (const float*)C.in[IN_EX_BETAS], (const float*)C.in[IN_EX_POSE3D], S.vals_l, S.exg_rot, S.exg_shape, S.exg_cam,
+                           S.exg_joints, nullptr, nullptr, st));
+  }
+  if (C.losslog) {
+    hipLaunchKernelGGL(level_log_kernel, dim3(1), dim3(64), 0, st, (const float*)P.losses, teacher ? (const float*)S.vals_t : nullptr,
+                       motion ? (const float*)S.vals_m : nullptr, label ? (const float*)S.vals_l : nullptr, (float)S.teacher_w,
+                       (float)S.motion_w, (float)S.label_w, C.losslog + 16 * C.level_row);
+    DYB_CHECK_LAUNCH();
+    ++C.level_row;
+  }
+  // gradient of the level total: image pass (+ its external terms), history pass, exemplar pass
+  const size_t n = S.n_params;
+  RUN(pass_backward_ext(S, P, cur, S.grads, true, ext ? S.ext_rot : nullptr, ext ? S.ext_shape : nullptr, ext ? S.ext_cam : nullptr,
+                        ext ? S.ext_joints : nullptr, st, aux));
+  if (motion) {
+    RUN(pass_backward_ext(S, S.hist, cur, S.grads2, false, nullptr, nullptr, S.hg_cam, S.hg_joints, st, aux));
+    RUN(dyb_axpby(S.grads2, S.grads, 1.f, 1.f, n, st));
+  }
+  if (label) {
+    RUN(pass_backward_ext(S, S.ex, cur, S.grads2, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, st, aux));
+    RUN(dyb_axpby(S.grads2, S.grads, 1.f, 1.f, n, st));
+  }
+  return DYB_OK;
+}
+static int adam_and_teacher(Stepper& S, hipStream_t st) {
+  S.adam_t += 1;
+  const double t = (double)S.adam_t;
+  const double step_size = S.lr / (1.0 - pow(S.beta1, t));
+  const double bc2_sqrt = sqrt(1.0 - pow(S.beta2, t));
+  RUN(dyb_adam_step(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, (float)step_size, (float)bc2_sqrt,
+                    (float)S.eps, S.n_params, st));
+  if (S.use_teacher && S.teacher) RUN(dyb_ema_update(S.teacher, S.theta, (float)S.alpha, S.n_params, st));   // base_adaptor.py:193-201
+  return DYB_OK;
+}
+// features of two forwards -> 15 cosines (device log row + host-visible copy) ; returns cos[12] read from the host copy
+static int gate_cosine(Stepper& S, const float* actsA, const float* actsB, float* log_row, float* cos12, hipStream_t st) {
+  DYB_REQUIRE(S.gate_host, DYB_ERR_ARG);
+  S.gate_seq += 1.f;
+  hipLaunchKernelGGL(feat_cos_kernel, dim3(15), dim3(1024), 0, st, actsA, actsB, S.fca, 1e-12f, log_row, S.gate_host, S.gate_seq);
+  DYB_CHECK_LAUNCH();
+  // the one host wait of the dynamic loop (the reference's `.item()`, dynaboa_benchmark.py:165): a poll of pinned memory the
+  // kernel writes, no stream synchronise / device-to-host copy call
+  long spins = 0;
+  while (S.gate_host[15] != S.gate_seq) {
+    if (++spins > 2000000000L) return DYB_ERR_LAUNCH;
+    __builtin_ia32_pause();
+  }
+  *cos12 = S.gate_host[12];
+  return DYB_OK;
+}
+// Adaptor.adaptation with the reference's full term set (dynaboa_benchmark.py:126-193): inputs = HOST array of IN_COUNT device
+// pointers (image, kp2d, gt_pose, gt_betas, gender, hist_image, hist_kp, ex_img, ex_kp, ex_pose, ex_betas, ex_pose3d; the
+// history pair NULL while there is no frame `interval` steps back, the exemplar five NULL when a retrieval callback is set).
+// *extra_steps receives the number of dynamic-loop iterations taken.
+extern "C" int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
+                                            hipStream_t st, hipStream_t aux) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && inputs && extra_steps, DYB_ERR_ARG);
+  Stepper& S = *Sp;
+  RUN(check_ready(S));
+  DYB_REQUIRE(S.full && S.nrep == 1 && S.B <= 16, DYB_ERR_UNSUPPORTED);
+  FullCtx C{};
+  for (int i = 0; i < IN_COUNT; ++i) C.in[i] = inputs[i];
+  DYB_REQUIRE(C.in[IN_IMAGE] && C.in[IN_KP], DYB_ERR_ARG);
+  const bool metrics = S.metrics != 0;
+  DYB_REQUIRE(!metrics || (C.in[IN_GT_POSE] && C.in[IN_GT_BETAS] && C.in[IN_GENDER]), DYB_ERR_ARG);
+  const long long* gender = (const long long*)C.in[IN_GENDER];
+  const int K = S.inner_step;
+  const int rows = K + 1 + (S.dynamic ? S.optim_steps : 0);
+  C.losslog = (S.loss_log && loss_slot >= 0 && loss_slot < S.loss_capacity) ? S.loss_log + (size_t)loss_slot * 16 * rows : nullptr;
+  int slot = record_slot;
+  *extra_steps = 0;
+  if (metrics) RUN(gt_meshes(S, (const float*)C.in[IN_GT_POSE], (const float*)C.in[IN_GT_BETAS], st));
+  const float* cur = S.theta;
+  for (int i = 0; i <= K; ++i) {
+    Pass& P = (i == 0 && S.dynamic) ? S.lvl0 : S.main;
+    RUN(full_level(S, C, P, cur, i == K, i, st, aux));
+    // (the level's gradient is complete; the metric record of the previous inner step reads this level's forward)
+    if (metrics && S.eval_lower && i > 0) RUN(record_metrics(S, P, gender, slot++, st));
+    if (i < K) {
+      RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, S.n_params, st));
+      cur = S.theta_fast;
+    }
+  }
+  RUN(adam_and_teacher(S, st));
+  const float* image = (const float*)C.in[IN_IMAGE];
+  RUN(pass_forward(S, S.fin, S.theta, image, st));
+  if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
+  if (S.dynamic) {
+    // dynaboa_benchmark.py:161-192: compare features of the un-adapted and the adapted forward; while feature 12 still
+    // moves, repeat the upper level on the model itself (at most optim_steps times)
+    float* glog = (S.gate_log && loss_slot >= 0 && loss_slot < S.loss_capacity) ? S.gate_log + (size_t)loss_slot * (1 + S.optim_steps) * 16 : nullptr;
+    DYB_REQUIRE(glog, DYB_ERR_ARG);
+    const float* init_acts = (K > 0) ? S.lvl0.acts : nullptr;
+    if (!init_acts) {                                    // inner_step 0: the un-adapted feature forward is the upper level's own (lvl0)
+      init_acts = S.lvl0.acts;
+    }
+    float cos12 = 1.f;
+    RUN(gate_cosine(S, init_acts, S.fin.acts, glog, &cos12, st));
+    int step = 0;
+    while (1.f - cos12 > (float)S.cos_thr) {
+      ++step;
+      if (step > S.optim_steps) break;
+      RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
+      RUN(adam_and_teacher(S, st));
+      RUN(pass_forward(S, S.fin, S.theta, image, st));
+      RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, &cos12, st));
+      if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
+    }
+    *extra_steps = step > S.optim_steps ? S.optim_steps + 1 : step;
+  }
+  return DYB_OK;
+}
+
 extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose,
                                        const float* gt_betas, const long long* gender, int record_slot, int loss_slot,
                                        hipStream_t st, hipStream_t aux, hipStream_t side) {

@@ -544,3 +544,228 @@ extern "C" int dyb_pa_mpjpe(const float* pred, const float* gt, float* out, floa
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// The other terms of the level losses, value + gradient, one launch each (one workgroup; <= 16 samples):
+//   mode 0  mean-teacher consistency   reference base_adaptor.py:320-343 (cal_teacher_loss)
+//           5*mse(s2d, t_s2d) + 5*mse(t_s3d, s3d) + 0.001*mse(shape, t_shape) + mse(rotmat, t_rotmat)
+//   mode 1  motion                     :379-398 (cal_motion_loss): masked mse of (s2d - hist_s2d) against the keypoint motion,
+//           over the 24 GT-style joints, confidence = both frames' confidences are 1
+//   mode 2  labelled exemplar          :346-376 (adapt_on_labeled_data) + :412-422 (cal_s3d_loss, hip-centred):
+//           5*l2d + 5*l3d + 0.001*mse(shape, betas) + mse(rotmat, rodrigues(pose))
+// "s2d" is the [-1,1]-normalised projection of the 49 joints with the predicted camera (:160-170), formed here.  Gradients are
+// those of weight * term w.r.t. the student pass's rotmat / shape / cam / joints49 (dense [B][216], [B][10], [B][3], [B][147];
+// accumulate != 0: added to what is there - several terms attach to one pass) and, for the motion term, w.r.t. the history
+// pass's cam / joints49.  vals: mode 0 -> {s2d, s3d, shape, pose, loss}; mode 1 -> {motion}; mode 2 -> {s2d, s3d, shape, pose,
+// loss} (un-weighted, as the reference logs them).
+// ------------------------------------------------------------------------------------------
+#define AUX_MAXB 16
+struct AuxArgs {
+  int mode, B, accumulate;
+  float weight;
+  const float *rot, *shape, *cam, *joints;        // student pass (shape / cam rows have stride lds / ldc)
+  int lds, ldc;
+  const float *rot2, *shape2, *cam2, *joints2;    // teacher outputs (mode 0) / history-pass outputs (mode 1: cam2, joints2)
+  int lds2, ldc2;
+  const float *kp, *kp2;                          // [B][49][3]: frame (mode 1) or exemplar (mode 2) keypoints; history keypoints
+  const float *gt_rot, *gt_betas, *gt_s3d;        // mode 2: [B][216], [B][10], [B][24][4]
+  float *vals;                                    // [5]
+  float *d_rot, *d_shape, *d_cam, *d_joints;
+  float *d_cam2, *d_joints2;                      // mode 1
+};
+__device__ __forceinline__ void aux_project(const float* c, const float* p, float& u, float& v, float& x, float& y, float& z) {
+  const float tz = 2.f * FOCAL / (IMG_RES * c[0] + 1e-9f);
+  x = p[0] + c[1]; y = p[1] + c[2]; z = p[2] + tz;
+  u = FOCAL * (x / z) / (IMG_RES * 0.5f);
+  v = FOCAL * (y / z) / (IMG_RES * 0.5f);
+}
+// block reduction of one value per thread (256 threads) -> every thread gets the total
+__device__ __forceinline__ float aux_block_sum(float v, float* sred) {
+  v = dyb_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+__global__ __launch_bounds__(256) void aux_terms_kernel(AuxArgs a, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  if (dyb_rep) {
+    a.rot = dyb_rb(a.rot, Rp, dyb_rep); a.shape = dyb_rb(a.shape, Rp, dyb_rep); a.cam = dyb_rb(a.cam, Rp, dyb_rep);
+    a.joints = dyb_rb(a.joints, Rp, dyb_rep); a.rot2 = dyb_rb(a.rot2, Rp, dyb_rep); a.shape2 = dyb_rb(a.shape2, Rp, dyb_rep);
+    a.cam2 = dyb_rb(a.cam2, Rp, dyb_rep); a.joints2 = dyb_rb(a.joints2, Rp, dyb_rep); a.kp = dyb_rb(a.kp, Rp, dyb_rep);
+    a.kp2 = dyb_rb(a.kp2, Rp, dyb_rep); a.gt_rot = dyb_rb(a.gt_rot, Rp, dyb_rep); a.gt_betas = dyb_rb(a.gt_betas, Rp, dyb_rep);
+    a.gt_s3d = dyb_rb(a.gt_s3d, Rp, dyb_rep); a.vals = dyb_rb(a.vals, Rp, dyb_rep); a.d_rot = dyb_rb(a.d_rot, Rp, dyb_rep);
+    a.d_shape = dyb_rb(a.d_shape, Rp, dyb_rep); a.d_cam = dyb_rb(a.d_cam, Rp, dyb_rep); a.d_joints = dyb_rb(a.d_joints, Rp, dyb_rep);
+    a.d_cam2 = dyb_rb(a.d_cam2, Rp, dyb_rep); a.d_joints2 = dyb_rb(a.d_joints2, Rp, dyb_rep);
+  }
+  __shared__ float sG[AUX_MAXB * NJ49][3];          // projection-side gradient of every student joint (for the per-sample camera sum)
+  __shared__ float sG2[AUX_MAXB * NJ49][3];         // same for the history pass (mode 1)
+  __shared__ float sHip[AUX_MAXB][3];               // mode 2: sum over joints of the hip-centred 3-D gradient
+  __shared__ float sred[4];
+  const int t = threadIdx.x, B = a.B, NP = B * NJ49;
+  const float w = a.weight;
+  const float k2 = FOCAL / (IMG_RES * 0.5f);
+  float l2d = 0.f, l3d = 0.f, lsh = 0.f, lpo = 0.f;
+  const float n2d = (a.mode == 0) ? (float)(B * NJ49 * 2) : (float)(B * 24 * 2);
+  const float n3d = (a.mode == 0) ? (float)(B * NJ49 * 3) : (float)(B * 24 * 3);
+  if (a.mode == 2) {
+    // hip centres first: pred - (pred[2] + pred[3]) / 2 over the 24 GT-style joints (49-joint indices 25 + j)
+    for (int i = t; i < B * 3; i += 256) sHip[i / 3][i % 3] = 0.f;
+    __syncthreads();
+  }
+  for (int i = t; i < NP; i += 256) {
+    const int b = i / NJ49, j = i - b * NJ49;
+    const float* c = a.cam + (size_t)b * a.ldc;
+    const float* p = a.joints + (size_t)i * 3;
+    float u, v, x, y, z;
+    aux_project(c, p, u, v, x, y, z);
+    float gu = 0.f, gv = 0.f;                       // d(weighted term)/d(u, v) of the student
+    float g3[3] = {0.f, 0.f, 0.f};                  // direct 3-D part
+    float hu = 0.f, hv = 0.f, hx = 0.f, hy = 0.f, hz = 1.f;
+    if (a.mode == 0) {
+      float tu, tv, tx, ty, tzz;
+      aux_project(a.cam2 + (size_t)b * a.ldc2, a.joints2 + (size_t)i * 3, tu, tv, tx, ty, tzz);
+      const float du = u - tu, dv = v - tv;
+      l2d += du * du + dv * dv;
+      gu = w * 5.f * 2.f * du / n2d; gv = w * 5.f * 2.f * dv / n2d;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float d = p[k] - a.joints2[(size_t)i * 3 + k];
+        l3d += d * d;
+        g3[k] = w * 5.f * 2.f * d / n3d;
+      }
+    } else if (a.mode == 1) {
+      if (j >= 25) {
+        aux_project(a.cam2 + (size_t)b * a.ldc2, a.joints2 + (size_t)i * 3, hu, hv, hx, hy, hz);
+        const float* kc = a.kp + (size_t)i * 3;
+        const float* kh = a.kp2 + (size_t)i * 3;
+        const float conf = (kh[2] + kc[2] == 2.f) ? 1.f : 0.f;
+        const float eu = (u - hu) - (kc[0] - kh[0]), ev = (v - hv) - (kc[1] - kh[1]);
+        l2d += conf * (eu * eu + ev * ev);
+        gu = w * 2.f * conf * eu / n2d; gv = w * 2.f * conf * ev / n2d;
+      }
+    } else {
+      if (j >= 25) {
+        const float* kc = a.kp + (size_t)i * 3;
+        const float conf = kc[2];
+        const float du = u - kc[0], dv = v - kc[1];
+        l2d += conf * (du * du + dv * dv);
+        gu = w * 5.f * 2.f * conf * du / n2d; gv = w * 5.f * 2.f * conf * dv / n2d;
+        // hip-centred 3-D term: centres from joints 2, 3 of the 24 (49-joint indices 27, 28) and of the ground truth
+        const float* pj = a.joints + (size_t)(b * NJ49 + 27) * 3;
+        const float* gt = a.gt_s3d + (size_t)(b * 24 + (j - 25)) * 4;
+        const float* g2 = a.gt_s3d + (size_t)(b * 24 + 2) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float pc = 0.5f * (pj[k] + pj[3 + k]), gc = 0.5f * (g2[k] + g2[4 + k]);
+          const float d = (p[k] - pc) - (gt[k] - gc);
+          l3d += conf * d * d;
+          g3[k] = w * 5.f * 2.f * conf * d / n3d;
+        }
+      }
+    }
+    // through the projection: (gu, gv) -> (gx, gy, gz) of the point, summed per sample for the camera
+    const float gx = gu * k2 / z, gy = gv * k2 / z, gz = -(gx * x + gy * y) / z;
+    sG[i][0] = gx; sG[i][1] = gy; sG[i][2] = gz;
+    float* dj = a.d_joints + (size_t)i * 3;
+    const float o0 = gx + g3[0], o1 = gy + g3[1], o2 = gz + g3[2];
+    if (a.accumulate) { dj[0] += o0; dj[1] += o1; dj[2] += o2; }
+    else { dj[0] = o0; dj[1] = o1; dj[2] = o2; }
+    if (a.mode == 1) {
+      const float qx = -gu * k2 / hz, qy = -gv * k2 / hz, qz = -(qx * hx + qy * hy) / hz;
+      sG2[i][0] = qx; sG2[i][1] = qy; sG2[i][2] = qz;
+      float* d2 = a.d_joints2 + (size_t)i * 3;
+      d2[0] = qx; d2[1] = qy; d2[2] = qz;
+    }
+    if (a.mode == 2 && j >= 25) {                   // the two hip joints also receive -1/2 of every joint's centred gradient
+      // (serialised per sample through LDS below)
+      sG2[i][0] = g3[0]; sG2[i][1] = g3[1]; sG2[i][2] = g3[2];
+    }
+  }
+  __syncthreads();
+  // per-sample sums: camera gradients (and the hip correction of mode 2)
+  for (int i = t; i < B * 3; i += 256) {
+    const int b = i / 3, k = i % 3;
+    float s = 0.f, s2 = 0.f, sh = 0.f;
+    for (int j = 0; j < NJ49; ++j) {
+      s += sG[b * NJ49 + j][k];
+      if (a.mode == 1) s2 += sG2[b * NJ49 + j][k];
+      if (a.mode == 2 && j >= 25) sh += sG2[b * NJ49 + j][k];
+    }
+    sG[b * NJ49][k] = s;                            // reuse row 0 of the sample for its sums
+    if (a.mode == 1) sG2[b * NJ49][k] = s2;
+    if (a.mode == 2) sHip[b][k] = sh;
+  }
+  __syncthreads();
+  for (int b = t; b < B; b += 256) {
+    const float* c = a.cam + (size_t)b * a.ldc;
+    const float den = IMG_RES * c[0] + 1e-9f;
+    const float dc0 = sG[b * NJ49][2] * (-2.f * FOCAL * IMG_RES / (den * den)), dc1 = sG[b * NJ49][0], dc2 = sG[b * NJ49][1];
+    float* d = a.d_cam + (size_t)b * 3;
+    if (a.accumulate) { d[0] += dc0; d[1] += dc1; d[2] += dc2; }
+    else { d[0] = dc0; d[1] = dc1; d[2] = dc2; }
+    if (a.mode == 1) {
+      const float* c2 = a.cam2 + (size_t)b * a.ldc2;
+      const float den2 = IMG_RES * c2[0] + 1e-9f;
+      float* e = a.d_cam2 + (size_t)b * 3;
+      e[0] = sG2[b * NJ49][2] * (-2.f * FOCAL * IMG_RES / (den2 * den2));
+      e[1] = sG2[b * NJ49][0];
+      e[2] = sG2[b * NJ49][1];
+    }
+    if (a.mode == 2) {
+      for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < 3; ++k) a.d_joints[(size_t)(b * NJ49 + 27 + h) * 3 + k] -= 0.5f * sHip[b][k];
+    }
+  }
+  // rotmat / shape terms (teacher, labelled exemplar)
+  if (a.mode != 1) {
+    const float* rt = a.mode == 0 ? a.rot2 : a.gt_rot;
+    for (int i = t; i < B * 216; i += 256) {
+      const float d = a.rot[i] - rt[i];
+      lpo += d * d;
+      const float gq = w * 2.f * d / (float)(B * 216);
+      if (a.accumulate) a.d_rot[i] += gq; else a.d_rot[i] = gq;
+    }
+    for (int i = t; i < B * 10; i += 256) {
+      const int b = i / 10, k = i % 10;
+      const float tv = a.mode == 0 ? a.shape2[(size_t)b * a.lds2 + k] : a.gt_betas[i];
+      const float d = a.shape[(size_t)b * a.lds + k] - tv;
+      lsh += d * d;
+      const float gq = w * 0.001f * 2.f * d / (float)(B * 10);
+      if (a.accumulate) a.d_shape[i] += gq; else a.d_shape[i] = gq;
+    }
+  } else if (!a.accumulate) {
+    for (int i = t; i < B * 216; i += 256) a.d_rot[i] = 0.f;
+    for (int i = t; i < B * 10; i += 256) a.d_shape[i] = 0.f;
+  }
+  l2d = aux_block_sum(l2d, sred) / n2d;
+  l3d = aux_block_sum(l3d, sred) / n3d;
+  lsh = aux_block_sum(lsh, sred) / (float)(B * 10);
+  lpo = aux_block_sum(lpo, sred) / (float)(B * 216);
+  if (t == 0) {
+    if (a.mode == 1) {
+      a.vals[0] = l2d; a.vals[1] = a.vals[2] = a.vals[3] = 0.f; a.vals[4] = l2d;
+    } else {
+      a.vals[0] = l2d; a.vals[1] = l3d; a.vals[2] = lsh; a.vals[3] = lpo;
+      a.vals[4] = 5.f * l2d + 5.f * l3d + 0.001f * lsh + lpo;
+    }
+  }
+}
+// mode 0 teacher / 1 motion / 2 labelled exemplar (see above).  Unused pointers may be NULL.  B <= 16.
+extern "C" int dyb_aux_loss_terms(int mode, int B, int accumulate, float weight, const float* rot, const float* shape, int lds,
+                                  const float* cam, int ldc, const float* joints49, const float* rot2, const float* shape2,
+                                  int lds2, const float* cam2, int ldc2, const float* joints2, const float* kp, const float* kp2,
+                                  const float* gt_rot, const float* gt_betas, const float* gt_s3d, float* vals5, float* d_rot,
+                                  float* d_shape, float* d_cam, float* d_joints49, float* d_cam2, float* d_joints2, hipStream_t st) {
+  DYB_REQUIRE(mode >= 0 && mode <= 2 && B > 0 && B <= AUX_MAXB, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(rot && shape && cam && joints49 && vals5 && d_rot && d_shape && d_cam && d_joints49, DYB_ERR_ARG);
+  if (mode == 0) DYB_REQUIRE(rot2 && shape2 && cam2 && joints2, DYB_ERR_ARG);
+  if (mode == 1) DYB_REQUIRE(cam2 && joints2 && kp && kp2 && d_cam2 && d_joints2, DYB_ERR_ARG);
+  if (mode == 2) DYB_REQUIRE(kp && gt_rot && gt_betas && gt_s3d, DYB_ERR_ARG);
+  AuxArgs a{mode, B, accumulate, weight, rot, shape, cam, joints49, lds, ldc, rot2, shape2, cam2, joints2, lds2, ldc2, kp, kp2,
+            gt_rot, gt_betas, gt_s3d, vals5, d_rot, d_shape, d_cam, d_joints49, d_cam2, d_joints2};
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(aux_terms_kernel, dim3(1, 1, Rp.n), dim3(256), 0, st, a, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

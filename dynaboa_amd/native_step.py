@@ -17,26 +17,48 @@ from ._abi import check
 from .hmr import get_layout, stream_of
 
 
+def mode(o, have_bundle: bool = True) -> str:
+    """'frame' (first order, frame-loss set), 'full' (the reference's term set: teacher / motion / labelled exemplars /
+    dynamic loop) or '' with `reason` set when the stepper does not cover these options."""
+    g = lambda k, d=0: getattr(o, k, d)
+    global reason
+    reason = None
+    if not g("use_boa", 1):
+        reason = "use_boa=0"
+    elif g("second_order"):
+        reason = "second order"
+    elif not (g("use_frame_losses_lower", 1) and g("use_frame_losses_upper", 1)):
+        reason = "frame losses switched off"
+    elif g("dump_predictions"):
+        reason = "prediction dumps"
+    elif not g("share_forwards", 1) or not g("fused_level", 1):
+        reason = "unshared / unfused schedule requested"
+    if reason:
+        return ""
+    temporal = (g("use_temporal_losses_lower") or g("use_temporal_losses_upper")) and (g("use_meanteacher") or g("use_motion"))
+    mix = g("lower_level_mixtrain") or g("upper_level_mixtrain")
+    if not (temporal or mix or g("dynamic_boa") or g("use_meanteacher")):
+        return "frame"
+    B = int(g("batch_size", 1))
+    if B > 16:
+        reason = "full term set natively needs batch <= 16"
+    elif mix and not g("retrieval"):
+        reason = "labelled term without retrieval"
+    elif mix and int(g("sample_num", 1)) != B:
+        reason = "sample_num != batch_size"
+    elif mix and not have_bundle and B != 1:
+        reason = "feature-driven retrieval is batch 1"
+    elif g("teacher_dropout"):
+        reason = "train-mode teacher"
+    return "" if reason else "full"
+
+
+reason = None
+
+
 def supported(o) -> Optional[str]:
     """None if the stepper covers these options, else the reason it does not."""
-    g = lambda k, d=0: getattr(o, k, d)
-    if not g("use_boa", 1):
-        return "use_boa=0"
-    if g("second_order"):
-        return "second order"
-    if not (g("use_frame_losses_lower", 1) and g("use_frame_losses_upper", 1)):
-        return "frame losses switched off"
-    if g("use_temporal_losses_lower") or g("use_temporal_losses_upper"):
-        return "temporal terms"
-    if g("retrieval") or g("lower_level_mixtrain") or g("upper_level_mixtrain"):
-        return "labelled exemplars"
-    if g("dynamic_boa"):
-        return "dynamic loop"
-    if g("dump_predictions"):
-        return "prediction dumps"
-    if not g("share_forwards", 1) or not g("fused_level", 1):
-        return "unshared / unfused schedule requested"
-    return None
+    return None if mode(o) else reason
 
 
 class NativeStepper:
@@ -70,7 +92,21 @@ class NativeStepper:
             self._keep.append(t)
             check(lib.dyb_stepper_set_p(h, k.encode(), t.data_ptr()), f"set_p {k}")
         si("replicas", S)
+        self.mode = mode(o, getattr(adaptor, "bundle", None) is not None)
+        self.full = self.mode == "full"
+        if self.full and S != 1:
+            raise ValueError("replica groups cover the frame-loss configurations only")
         si("inner_step", self.K); si("eval_lower", self.eval_lower); si("n_iter", 3)
+        if self.full:
+            g = lambda k, d=0: getattr(o, k, d)
+            si("full", 1)
+            si("temporal_lower", g("use_temporal_losses_lower")); si("temporal_upper", g("use_temporal_losses_upper", 1))
+            si("use_teacher", g("use_meanteacher", 1)); si("use_motion", g("use_motion", 1)); si("interval", g("interval", 5))
+            si("mix_lower", g("lower_level_mixtrain", 1)); si("mix_upper", g("upper_level_mixtrain", 1))
+            si("dynamic", g("dynamic_boa", 1)); si("optim_steps", g("optim_steps", 7))
+            for k in ("teacherloss_weight", "motionloss_weight", "labelloss_weight", "alpha", "cos_sim_threshold"):
+                sf(k, getattr(o, k))
+            self.dynamic, self.optim_steps = int(g("dynamic_boa", 1)), int(g("optim_steps", 7))
         self.use_side = 1 if (S == 1 and getattr(adaptor, "_side", None) is not None) else 0
         si("use_side", self.use_side)
         for k in ("lr", "beta1", "beta2", "fastlr", "s2dloss_weight", "shape_prior_weight", "pose_prior_weight"):
@@ -120,11 +156,41 @@ class NativeStepper:
         self.rec_floats = int(lib.dyb_stepper_get_i(h, b"record_floats"))
         self.loss_floats = int(lib.dyb_stepper_get_i(h, b"loss_floats"))
         self.slots_per_frame = (self.K if self.eval_lower else 0) + 1
+        if self.full:
+            self.slots_per_frame = int(lib.dyb_stepper_get_i(h, b"slots_per_frame"))
         cap = max(1, nframes)
         self.records = torch.zeros(S, cap * self.slots_per_frame, self.rec_floats, device=dev)
         self.loss_log = torch.zeros(S, cap, self.loss_floats, device=dev)
         si("record_capacity", cap * self.slots_per_frame); si("loss_capacity", cap)
         sp("records", self.records); sp("loss_log", self.loss_log)
+        if self.full:
+            if o.use_meanteacher:
+                sp("teacher", adaptor.teacher.theta.data)
+            self.gate_host = torch.zeros(16).pin_memory() if dev.type == "cuda" else torch.zeros(16)
+            self.gate_log = torch.zeros(cap, 1 + self.optim_steps, 16, device=dev)
+            self.feat5 = torch.zeros(B, 2048, device=dev)
+            sp("gate_host", self.gate_host); sp("gate_log", self.gate_log); sp("feat5_out", self.feat5)
+            self._cb = None
+            if (o.lower_level_mixtrain or o.upper_level_mixtrain) and getattr(adaptor, "bundle", None) is None:
+                CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
+
+                def _retrieve(_user, _level, out):
+                    try:
+                        if dev.type == "cuda":
+                            torch.cuda.current_stream(dev).synchronize()          # feat5 of this level's forward is complete
+                        ex = adaptor.retrieval(self.feat5)                        # base_adaptor.py:82-96 (host: argmin + seeded sample)
+                        adaptor._last_h36m = ex
+                        keep = [ex["img"].contiguous().float(), ex["keypoints"].contiguous().float(), ex["pose"].contiguous().float(),
+                                ex["betas"].contiguous().float(), ex["pose_3d"].contiguous().float()]
+                        self._ex_keep = keep
+                        for i, t in enumerate(keep):
+                            out[i] = t.data_ptr()
+                        return 0
+                    except Exception as e:      # noqa: BLE001
+                        self._cb_error = e
+                        return 1
+                self._cb = CB(_retrieve)
+                check(lib.dyb_stepper_set_p(h, b"retrieve_fn", ctypes.cast(self._cb, ctypes.c_void_p)), "set_p retrieve_fn")
         nbytes = int(lib.dyb_stepper_workspace_bytes(h))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(lib.dyb_stepper_bind_workspace(h, self.ws.data_ptr(), nbytes, stream_of(self.theta)), "dyb_stepper_bind_workspace")
@@ -172,6 +238,37 @@ class NativeStepper:
 
     def adapt_frame(self, batch: Dict[str, torch.Tensor], side_stream=None):
         return self.adapt_frames([batch], side_stream)
+
+    def adapt_frame_full(self, batch, hist=None, exemplars=None):
+        """One frame of the full term set.  hist = (image, kp2d) of the frame `interval` steps back or None; exemplars = dict
+        (img, keypoints, pose, betas, pose_3d) or None when the retrieval callback supplies them.
+        -> (frame index, first record slot, extra dynamic-loop steps)."""
+        f = self.frame
+        if f >= self.loss_log.shape[1]:
+            raise RuntimeError("native stepper: more frames than reset_records() announced")
+        c = lambda t: t.contiguous().float()
+        keep = [c(batch["image"]), c(batch["smpl_j2d"]), c(batch["pose"]), c(batch["betas"]), batch["gender"].contiguous().long()]
+        keep += [c(hist[0]), c(hist[1])] if hist is not None else [None, None]
+        keep += [c(exemplars[k]) for k in ("img", "keypoints", "pose", "betas", "pose_3d")] if exemplars is not None else [None] * 5
+        ptrs = (ctypes.c_void_p * 12)(*[None if t is None else t.data_ptr() for t in keep])
+        extra = ctypes.c_int(0)
+        slot0 = f * self.slots_per_frame
+        self._cb_error = None
+        rc = self.lib.dyb_stepper_adapt_frame_full(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, ctypes.cast(ctypes.pointer(extra), ctypes.c_void_p),
+                                                   stream_of(self.theta), self._aux.cuda_stream if self._aux is not None else None)
+        if getattr(self, "_cb_error", None) is not None:
+            raise self._cb_error
+        check(rc, "dyb_stepper_adapt_frame_full")
+        t = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
+        for st in self._adam:
+            st["step"] = t
+        self.frame += 1
+        return f, slot0, int(extra.value)
+
+    def level_row(self, frame: int, row: int):
+        """16-float log row `row` of `frame` (full mode): frame {s2d, shape, pose, total} | teacher {s2d, s3d, shape, pose, loss} |
+        motion | labelled {s2d, s3d, shape, pose, loss} | level total."""
+        return self.loss_log[0, frame, 16 * row:16 * row + 16]
 
     def join(self):
         check(self.lib.dyb_stepper_join(self.h, stream_of(self.theta)), "dyb_stepper_join")

@@ -199,6 +199,20 @@ int dyb_frame_losses(const float* rotmat, const float* shape, int lds, const flo
                      float wshape, float wpose, float* losses_out, float* drot, float* dshape, int ldds, float* dcam,
                      int lddc, float* djoints49, int B, void* ws, size_t ws_bytes, dyb_stream_t stream);
 
+/* The other terms of the level losses, value + gradient in one launch each (B <= 16): mode 0 mean-teacher consistency
+ * (reference base_adaptor.py:320-343: 5 mse(s2d) + 5 mse(s3d) + 0.001 mse(shape) + mse(rotmat) against the teacher's outputs
+ * rot2 / shape2 / cam2 / joints2), mode 1 motion (:379-398: confidence-masked mse of the projected-keypoint motion between the
+ * frame and the history frame - cam2 / joints2 are the history pass's outputs, kp / kp2 the two frames' keypoints), mode 2
+ * labelled exemplar (:346-376 with the hip-centred 3-D loss of :412-422; kp / gt_rot / gt_betas / gt_s3d [B][24][4] are the
+ * exemplar's annotations).  s2d is the normalised projection (:160-170) formed inside.  Gradients of weight * term w.r.t. the
+ * student pass's rotmat [B][216] / shape [B][10] / cam [B][3] / joints49 [B][147] (accumulate != 0: added) and, mode 1, w.r.t.
+ * the history pass's cam / joints49.  vals5 = {s2d, s3d, shape, pose, loss} un-weighted (mode 1: {motion, 0, 0, 0, motion}). */
+int dyb_aux_loss_terms(int mode, int B, int accumulate, float weight, const float* rot, const float* shape, int lds,
+                       const float* cam, int ldc, const float* joints49, const float* rot2, const float* shape2, int lds2,
+                       const float* cam2, int ldc2, const float* joints2, const float* kp, const float* kp2,
+                       const float* gt_rot, const float* gt_betas, const float* gt_s3d, float* vals5, float* d_rot,
+                       float* d_shape, float* d_cam, float* d_joints49, float* d_cam2, float* d_joints2, dyb_stream_t stream);
+
 /* Gradient assembly of the fused HMR + SMPL + frame-loss node (one autograd node per adaptation level instead
  * of three plus glue): out = g*a (+ ext) with g a device scalar (NULL = 1), and the d_rotmat / d_state inputs of
  * dyb_hmr_backward from the dyb_frame_losses pieces (scaled by g), the dyb_lbs_bwd pieces and optional external
@@ -316,6 +330,20 @@ int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d
  * gt_betas[r], gender[r].  Results per replica are those of dyb_stepper_adapt_frame on that replica alone. */
 int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs, int record_slot, int loss_slot, dyb_stream_t stream,
                              dyb_stream_t aux, dyb_stream_t side);
+/* The reference's FULL term set (its default flags) as one call per frame: per level the frame losses + (upper level) the
+ * mean-teacher term with a no-grad teacher forward + the motion term with a second forward of the history frame + the
+ * labelled-exemplar term with a forward of the retrieved exemplars (dyb_aux_loss_terms), gradients of the passes summed, Adam,
+ * teacher EMA, final inference, and the dynamic-BOA loop (dynaboa_benchmark.py:161-192): the 15 feature cosines come from one
+ * launch that also writes them to device-visible pinned host memory, which the call polls - its only host wait, no stream
+ * synchronise - to decide on up to optim_steps further upper-level steps.  Enable with set_i "full" = 1 before sizing the
+ * workspace; further keys: set_i temporal_lower/upper, use_teacher, use_motion, interval, mix_lower/upper, dynamic, optim_steps;
+ * set_f teacherloss_weight, motionloss_weight, labelloss_weight, alpha, cos_sim_threshold; set_p teacher (parameter arena),
+ * gate_host (16 floats, pinned), gate_log ([loss_capacity][1 + optim_steps][16]), feat5_out ([2048]), retrieve_fn / retrieve_user
+ * (int fn(void* user, int level, const void** ex5): host retrieval of exemplars from feat5_out, batch 1).  inputs: HOST array of
+ * 12 device pointers: image, kp2d, gt_pose, gt_betas, gender, hist_image, hist_kp2d (NULL: no motion term), ex_img, ex_kp,
+ * ex_pose, ex_betas, ex_pose3d (NULL with a retrieval callback).  loss_log rows are 16 floats per level (adapt_step.hip). */
+int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
+                                 dyb_stream_t stream, dyb_stream_t aux);
 int dyb_stepper_join(void* stepper, dyb_stream_t stream);
 const float* dyb_stepper_output(const void* stepper, int which);
 

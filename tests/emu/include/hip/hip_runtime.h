@@ -59,6 +59,7 @@ typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+static inline void __threadfence_system() {}
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

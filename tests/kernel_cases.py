@@ -831,3 +831,98 @@ def case_dgrad_gn_reduce(be, H, W, C, Kc, mask_from_y, with_addend, seed=61, N=1
     e["dm one-vs-two launches"] = rel_err(res_out[1]["dm"], res_out[0]["dm"])
     assert max(e.values()) < 5e-4, e
     return dict(e, layouts=(res_out[1]["layout"], res_out[0]["layout"]))
+
+
+# ---------------------------------------------------------------------------------------- teacher / motion / labelled terms
+def _proj_t(cam, p3):
+    tz = 2 * 5000.0 / (224 * cam[:, 0] + 1e-9)
+    x, y, z = p3[..., 0] + cam[:, None, 1], p3[..., 1] + cam[:, None, 2], p3[..., 2] + tz[:, None]
+    return torch.stack([5000.0 * (x / z) / 112.0, 5000.0 * (y / z) / 112.0], -1)
+
+
+def case_aux_terms(be, B=3, seed=91):
+    """dyb_aux_loss_terms (teacher / motion / labelled-exemplar terms, value + gradient) against torch autograd of the
+    reference formulas (base_adaptor.py:320-343, :379-398, :346-376 + :412-422)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    L = be.lib
+
+    def student():
+        rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3)).clone().requires_grad_(True)
+        state = torch.zeros(B, 160)
+        state[:, 144:154] = rn(B, 10) * 0.5
+        state[:, 154:157] = torch.tensor([0.9, 0.02, -0.03]) + 0.05 * rn(B, 3)
+        state = state.requires_grad_(True)
+        joints = (rn(B, 49, 3) * 0.3).requires_grad_(True)
+        return rot, state, joints
+    res = {}
+    for mode in (0, 1, 2):
+        rot, state, joints = student()
+        shape, cam = state[:, 144:154], state[:, 154:157]
+        s2d = _proj_t(cam, joints)
+        w = [0.1, 0.8, 0.1][mode]
+        rot2 = torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3)
+        st2 = torch.zeros(B, 160)
+        st2[:, 144:154] = rn(B, 10) * 0.5
+        st2[:, 154:157] = torch.tensor([0.9, 0.02, -0.03]) + 0.05 * rn(B, 3)
+        j2 = rn(B, 49, 3) * 0.3
+        kp = torch.cat([torch.rand(B, 49, 2, generator=g) * 2 - 1, (torch.rand(B, 49, 1, generator=g) < 0.7).float()], -1)
+        kp2 = torch.cat([torch.rand(B, 49, 2, generator=g) * 2 - 1, (torch.rand(B, 49, 1, generator=g) < 0.7).float()], -1)
+        gt_rot, gt_betas = torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3), rn(B, 10) * 0.5
+        gt_s3d = torch.cat([rn(B, 24, 3) * 0.3, torch.ones(B, 24, 1)], -1)
+        extra = []
+        if mode == 0:
+            t2d = _proj_t(st2[:, 154:157], j2)
+            terms = [F.mse_loss(s2d, t2d), F.mse_loss(j2, joints), F.mse_loss(shape, st2[:, 144:154]), F.mse_loss(rot, rot2)]
+            loss = terms[0] * 5 + terms[1] * 5 + terms[2] * 0.001 + terms[3]
+        elif mode == 1:
+            st2 = st2.requires_grad_(True)
+            j2 = j2.requires_grad_(True)
+            h2d = _proj_t(st2[:, 154:157], j2)
+            pm = s2d[:, 25:] - h2d[:, 25:]
+            gm = kp[:, 25:, :2] - kp2[:, 25:, :2]
+            conf = ((kp2[:, 25:, 2:] + kp[:, 25:, 2:]) == 2).float()
+            loss = (((pm - gm) ** 2) * conf).mean()
+            terms = [loss, torch.zeros(()), torch.zeros(()), torch.zeros(())]
+            extra = [st2, j2]
+        else:
+            conf = kp[:, 25:, 2:]
+            l2d = (((s2d[:, 25:] - kp[:, 25:, :2]) ** 2) * conf).mean()
+            p24, g24 = joints[:, 25:], gt_s3d[:, :, :3]
+            pc = p24 - ((p24[:, 2] + p24[:, 3]) / 2)[:, None]
+            gc = g24 - ((g24[:, 2] + g24[:, 3]) / 2)[:, None]
+            l3d = (conf * (pc - gc) ** 2).mean()
+            terms = [l2d, l3d, F.mse_loss(shape, gt_betas), F.mse_loss(rot, gt_rot)]
+            loss = terms[0] * 5 + terms[1] * 5 + terms[2] * 0.001 + terms[3]
+        gs = torch.autograd.grad(loss * w, [rot, state, joints] + extra, allow_unused=True)
+        g_rot, g_state, g_j = gs[0], gs[1], gs[2]
+        g_rot = torch.zeros_like(rot) if g_rot is None else g_rot
+        D = lambda t: be.dev(t.detach().numpy())
+        ST, ST2 = D(state), D(st2)
+        sp, s2p = be.ptr(ST), be.ptr(ST2)
+        ROT, J, ROT2, J2, KP, KP2, GR, GB_, G3 = D(rot), D(joints), D(rot2), D(j2), D(kp), D(kp2), D(gt_rot), D(gt_betas), D(gt_s3d)
+        pre = np.float32(0.25)                       # accumulate = 1 adds to what is there
+        vals = be.empty((5,))
+        outs = {}
+        for acc in (0, 1):
+            d_rot, d_shape, d_cam, d_j = (be.dev(np.full(s, pre, np.float32)) for s in ((B, 216), (B, 10), (B, 3), (B, 147)))
+            d_cam2, d_j2 = be.empty((B, 3)), be.empty((B, 147))
+            check(L.dyb_aux_loss_terms(mode, B, acc, w, be.ptr(ROT), sp + 144 * 4, 160, sp + 154 * 4, 160, be.ptr(J), be.ptr(ROT2),
+                                       s2p + 144 * 4, 160, s2p + 154 * 4, 160, be.ptr(J2), be.ptr(KP), be.ptr(KP2), be.ptr(GR),
+                                       be.ptr(GB_), be.ptr(G3), be.ptr(vals), be.ptr(d_rot), be.ptr(d_shape), be.ptr(d_cam),
+                                       be.ptr(d_j), be.ptr(d_cam2), be.ptr(d_j2), be.stream), "aux terms")
+            outs[acc] = [be.host(x).copy() for x in (d_rot, d_shape, d_cam, d_j, d_cam2, d_j2)]
+        v = be.host(vals)
+        e = dict(vals=max(abs(float(v[i]) - float(terms[i])) / (abs(float(terms[i])) + 1e-12) for i in range(4) if float(terms[i]) != 0),
+                 total=abs(float(v[4]) - float(loss)) / abs(float(loss)))
+        ref = [g_rot.reshape(B, 216).numpy(), g_state[:, 144:154].numpy(), g_state[:, 154:157].numpy(), g_j.reshape(B, 147).numpy()]
+        for name, got, want in zip(("d_rot", "d_shape", "d_cam", "d_joints"), outs[0][:4], ref):
+            e[name] = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-20)) if np.abs(want).max() > 0 else float(np.abs(got).max())
+            e[name + "_acc"] = float(np.abs(outs[1][("d_rot", "d_shape", "d_cam", "d_joints").index(name)] - pre - want).max() /
+                                     (np.abs(want).max() + 1e-3))          # (0.25 + g rounds at 3e-8)
+        if mode == 1:
+            e["d_cam2"] = rel_err(outs[0][4], gs[3][:, 154:157].numpy())
+            e["d_joints2"] = rel_err(outs[0][5], gs[4].reshape(B, 147).numpy())
+        assert max(e.values()) < 2e-4, (mode, e)
+        res[mode] = e
+    return res

@@ -189,3 +189,8 @@ def test_conv_bf16_variant(be, cfg):
     """bf16 matrix-core variant of the tiled conv (forward / data gradient / weight gradient): equal to an fp32 convolution
     of the bf16-rounded operands up to summation order."""
     K.case_conv(be, *cfg, seed=sum(cfg), bf16=True)
+
+
+def test_aux_loss_terms(be):
+    K.case_aux_terms(be, B=3)
+    K.case_aux_terms(be, B=1, seed=5)

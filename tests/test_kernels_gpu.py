@@ -202,3 +202,9 @@ def test_batched_pairs_both_dispatches(be, k4_batch):
         K.case_bottleneck_fused(be, 2, 28, 28, 512, 256, 2, True, seed=17)
     finally:
         be.lib.dyb_set_option(b"k4_batch", 1)
+
+
+def test_aux_loss_terms(be):
+    K.case_aux_terms(be, B=1, seed=5)
+    K.case_aux_terms(be, B=8)
+    K.case_aux_terms(be, B=16, seed=3)
