@@ -167,12 +167,18 @@ class Runner:
         mk = lambda r, s: {k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + r * 7_000 + frame_base + s, batch, seed=22).items()}
         self.frames = [[mk(r, s) for s in range(nframes)] for r in range(seqs)]      # resident in HBM before any clock starts
         if seqs == 1:
+            from dynaboa_amd import _lib
+            _lib.load().dyb_set_option(b"rep_split", 0)
             self.ad = build_adaptor(device, batch, inner_step, **kw)
             self.ad.reset_records(nframes)
             self.grp = None
         else:
-            from dynaboa_amd import native_step as NS
+            from dynaboa_amd import _lib, native_step as NS
             kw = dict(kw, overlap=0)
+            # several sequences per launch: let the split-K policy see the replica-multiplied grid (fewer slabs to write and
+            # fold; +5..7 % measured).  Summation order then differs from a sequence running alone - results equal to fp32
+            # rounding (test_replica_group_with_replica_aware_split); with rep_split = 0 they are bit-identical
+            _lib.load().dyb_set_option(b"rep_split", 1)
             self.ads = [build_adaptor(device, batch, inner_step, **kw) for _ in range(seqs)]
             self.grp = NS.ReplicaGroup(self.ads, nframes)
             self.ad = self.ads[0]
@@ -242,11 +248,19 @@ def pa_mean(metrics):
 
 
 def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
-    """Aggregate frames/s of S sequences in lockstep on one GPU (a short side run: see Runner)."""
+    """Aggregate frames/s of S sequences in lockstep on one GPU (a short side run: see Runner).  S = 1, the latency
+    configuration, runs 200 frames and also reports the per-frame completion intervals."""
+    if S == 1:
+        steps = max(steps, 200)
     rn = Runner(device, S, batch, inner_step, warmup + steps, rank=rank, frame_base=3_000, **kw)
-    r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device))
-    return dict(value=S * steps * batch / r["dt"], unit="adapted frames/s", seqs=S, steps=steps, warmup=warmup,
-                ms_per_step=r["dt"] * 1e3 / steps, pa_mpjpe_mm_synthetic_mean=pa_mean(r["metrics"]))
+    r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device), per_frame=(S == 1))
+    out = dict(value=S * steps * batch / r["dt"], unit="adapted frames/s", seqs=S, steps=steps, warmup=warmup,
+               ms_per_step=r["dt"] * 1e3 / steps, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
+               pa_mpjpe_mm_synthetic_mean=pa_mean(r["metrics"]))
+    if "frame_ms" in r:
+        ft = r["frame_ms"]
+        out["frame_time_ms"] = dict(mean=float(ft.mean()), p50=float(np.percentile(ft, 50)), p99=float(np.percentile(ft, 99)), max=float(ft.max()))
+    return out
 
 
 def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, **kw):
@@ -290,9 +304,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
-    ap.add_argument("--seqs", type=int, default=1,
+    ap.add_argument("--seqs", type=int, default=16,
                     help="independent sequences per GPU in the timed run (each with its own weights / Adam state / records, batch "
-                         "--batch each), stepped in lockstep by one chain of launches; 1 = the single-sequence latency configuration")
+                         "--batch each), stepped in lockstep by one chain of launches (the throughput configuration; second-order / full-loss runs use 1); "
+                         "1 = the single-sequence latency configuration")
     ap.add_argument("--replicas", type=str, default="1,2,4,8,16",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
@@ -325,10 +340,8 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
-    seqs = args.seqs
     simple = not (args.second_order or args.full_losses)
-    if seqs > 1 and not simple:
-        raise SystemExit("bench.py: --seqs > 1 needs a configuration the native stepper covers (first order, frame-loss set)")
+    seqs = args.seqs if simple else 1           # replica groups cover the first-order frame-loss configurations
     total = args.warmup + args.steps
     n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
@@ -361,7 +374,8 @@ def main():
         fwd_pf = (args.inner_step + 2) if (args.share_forwards and not args.full_losses) else fwd_ref
         order = "second-order" if args.second_order else "first-order"
         how = ("%d independent sequences per GPU stepped in lockstep by one chain of launches (own weights / Adam state / records "
-               "each, batch %d each; per-sequence results bit-identical to running alone)" % (seqs, args.batch)) if seqs > 1 else \
+               "each, batch %d each; per-sequence results equal to running alone - bit-identical with the split policy of a "
+               "single sequence, to fp32 rounding with the replica-aware one used here)" % (seqs, args.batch)) if seqs > 1 else \
               "one sequence per GPU"
         out = {"metric": "adapted frames/sec, whole job (%d inner + 1 outer step, bs=%d per sequence, %s; synthetic 224x224 stream, no 3DPW "
                          "assets in the image: PA-MPJPE on 3DPW not measured)" % (args.inner_step, args.batch, order),

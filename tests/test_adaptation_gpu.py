@@ -368,7 +368,7 @@ def restore_switches():
     from dynaboa_amd import _lib
     yield
     lib = _lib.load()
-    for name, dflt in ((b"k4", 1), (b"k4_bwd", 1), (b"k4_batch", 1)):
+    for name, dflt in ((b"k4", 1), (b"k4_bwd", 1), (b"k4_batch", 1), (b"rep_split", 0), (b"bf16", 0)):
         lib.dyb_set_option(name, dflt)
 
 
@@ -728,3 +728,34 @@ def test_native_full_term_set_matches_autograd_path(tag):
     for k in a["log"]:
         assert abs(a["log"][k] - b["log"][k]) <= 2e-4 * abs(b["log"][k]) + 1e-9, k       # last frame's terms: the weights differ by ~2e-6 by then
     np.testing.assert_allclose(np.array(a["sims"]), np.array(b["sims"]), rtol=0, atol=1e-6)
+
+
+def test_replica_group_with_replica_aware_split(restore_switches):
+    """rep_split=1 (what bench.py uses for several sequences per GPU): the split-K depth is chosen for the replica-multiplied
+    grid, so summation order - not arithmetic - differs from a sequence running alone: weights equal to fp32 rounding."""
+    from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    S, NF = 4, 2
+
+    def mk(r):
+        o = DB.frame_only_options(inner_step=3)
+        o.deferred_metrics = 1
+        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cuda:0")
+    frames = [[{k: v.to("cuda:0") for k, v in assets.make_frame(100 * r + s, 1, seed=22).items()} for s in range(NF)] for r in range(S)]
+    singles = []
+    for r in range(S):
+        ad = mk(r)
+        ad.excute(frames[r], nframes=NF)
+        singles.append((ad.model.module.theta.detach().clone(), ad.optimizer.state[ad.model.module.theta]["exp_avg"].clone()))
+    _lib.load().dyb_set_option(b"rep_split", 1)
+    ads = [mk(r) for r in range(S)]
+    grp = NS.ReplicaGroup(ads, NF)
+    for s in range(NF):
+        grp.step([frames[r][s] for r in range(S)], s)
+    grp.flush_metrics()
+    _lib.load().dyb_set_option(b"rep_split", 0)
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    for r in range(S):
+        a = ads[r]
+        assert rel(a.model.module.theta.detach(), singles[r][0]) < 1e-6, r
+        assert rel(a.optimizer.state[a.model.module.theta]["exp_avg"], singles[r][1]) < 5e-3, r
