@@ -18,6 +18,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 
 #include "dyb_common.h"
@@ -250,7 +251,31 @@ struct Stepper {
   DybEvents* ev = nullptr;
   hipEvent_t e_theta = nullptr, e_side = nullptr, e_gt = nullptr;
   bool side_pending = false;
+  // the final inference of a frame (side stream) is issued by the NEXT call, behind that frame's first level: the host cannot
+  // run far ahead of the GPU (launches block when the queue is full), so issuing ~130 side-stream launches right after Adam
+  // left the main queue empty for ~1 ms per frame (profiles/r02_s2_frame_timeline_S1.txt)
+  struct Tail {
+    bool on = false;
+    const float* image = nullptr;
+    const long long* gender = nullptr;
+    int slot = 0;
+    bool metrics = false;
+  } tail;
+  struct GtJob {
+    bool on = false;
+    const float *pose = nullptr, *betas = nullptr;
+  } gtjob;
+  hipStream_t tail_stream = nullptr;
   std::string err;
+  // host-side issue time by section (always on: two clock reads per section), read back through dyb_stepper_get_f
+  double h_fwd = 0, h_bwd = 0, h_head = 0, h_update = 0, h_tail = 0, h_total = 0;
+  long long h_frames = 0;
+};
+struct HostTimer {
+  double& acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 static size_t a64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -455,6 +480,21 @@ extern "C" long long dyb_stepper_get_i(const void* stepper, const char* key) {
   if (k == "slots_per_frame") return (S->eval_lower ? S->inner_step : 0) + 1 + (S->full && S->dynamic ? S->optim_steps : 0);
   return -1;
 }
+// host issue time (ms, accumulated over h_frames frame steps of the frame-loss path) by section:
+// "host_ms_forward", "host_ms_backward", "host_ms_head", "host_ms_update", "host_ms_tail", "host_ms_total", "host_frames"
+extern "C" double dyb_stepper_get_f(const void* stepper, const char* key) {
+  const Stepper* S = reinterpret_cast<const Stepper*>(stepper);
+  if (!S || !key) return -1.0;
+  const std::string k(key);
+  if (k == "host_ms_forward") return S->h_fwd;
+  if (k == "host_ms_backward") return S->h_bwd;
+  if (k == "host_ms_head") return S->h_head;
+  if (k == "host_ms_update") return S->h_update;
+  if (k == "host_ms_tail") return S->h_tail;
+  if (k == "host_ms_total") return S->h_total;
+  if (k == "host_frames") return (double)S->h_frames;
+  return -1.0;
+}
 extern "C" size_t dyb_stepper_workspace_bytes(void* stepper) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   if (!S) return 0;
@@ -560,6 +600,23 @@ static int record_metrics(Stepper& S, Pass& P, const long long* gender, int slot
 // schedule order - after inner step 0, 1, ..., then the final one; losses: loss_slot*(inner_step+1) 4-vectors
 // (s2d, shape prior, pose prior, weighted total) per level.  side (may be NULL): stream for the final no-grad forward and
 // its metrics, overlapped with the next frame's first level; the call orders the weight hazards itself.
+// issue what the side stream owes: the previous frame's final forward + record, then this frame's ground-truth meshes
+static int issue_side_work(Stepper& S, hipStream_t side) {
+  if (S.tail.on) {
+    HIPOK(hipStreamWaitEvent(side, S.e_theta, 0));
+    RUN(pass_forward(S, S.fin, S.theta, S.tail.image, side));
+    if (S.tail.metrics) RUN(record_metrics(S, S.fin, S.tail.gender, S.tail.slot, side));
+    HIPOK(hipEventRecord(S.e_side, side));
+    S.side_pending = true;
+    S.tail.on = false;
+  }
+  if (S.gtjob.on) {
+    RUN(gt_meshes(S, S.gtjob.pose, S.gtjob.betas, side));
+    HIPOK(hipEventRecord(S.e_gt, side));
+    S.gtjob.on = false;
+  }
+  return DYB_OK;
+}
 static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
                             const long long* gender, int record_slot, int loss_slot, hipStream_t st, hipStream_t aux,
                             hipStream_t side) {
@@ -572,39 +629,58 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
   int slot = record_slot;
 
   if (metrics) {
-    // the ground-truth meshes only feed metric kernels: on the side stream when there is one (behind the previous frame's
-    // tail, which still reads the buffers)
-    hipStream_t gs = side ? side : st;
-    RUN(gt_meshes(S, gt_pose, gt_betas, gs));
-    if (side) HIPOK(hipEventRecord(S.e_gt, side));
+    // the ground-truth meshes only feed metric kernels: on the side stream when there is one, behind the previous frame's
+    // tail (which still reads the buffers) - both are issued below, once this frame's first level is in the main queue
+    if (side) {
+      S.gtjob.on = true; S.gtjob.pose = gt_pose; S.gtjob.betas = gt_betas;
+    } else {
+      RUN(gt_meshes(S, gt_pose, gt_betas, st));
+    }
   }
   // the main stream waits for the meshes only where it first reads them (the record after inner step 0): at the top of
   // the frame the side stream is still busy with the previous frame's final forward, and waiting there stalled the main
   // chain for that whole tail (1.1 ms per frame in the kernel trace)
   bool gt_waited = !(metrics && side);
+  HostTimer t_all(S.h_total);
+  ++S.h_frames;
   const float* cur = S.theta;                    // clone(): the learner starts as an alias of theta
   for (int i = 0; i <= K; ++i) {                 // i < K: lower level + adapt; i == K: upper level
-    RUN(pass_forward(S, S.main, cur, image, st));
-    RUN(pass_frame_head(S, S.main, kp2d, st));
-    if (losslog) {
-      hipLaunchKernelGGL(copy4_kernel, dim3(1, 1, dyb_rep_current().n), dim3(64), 0, st, (const float*)S.main.losses, losslog + 4 * i,
-                         dyb_rep_current());
-      DYB_CHECK_LAUNCH();
+    {
+      HostTimer t(S.h_fwd);
+      RUN(pass_forward(S, S.main, cur, image, st));
     }
-    // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
-    if (metrics && S.eval_lower && i > 0) {
-      if (!gt_waited) {
-        HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
-        gt_waited = true;
+    {
+      HostTimer th(S.h_head);
+      RUN(pass_frame_head(S, S.main, kp2d, st));
+      if (losslog) {
+        hipLaunchKernelGGL(copy4_kernel, dim3(1, 1, dyb_rep_current().n), dim3(64), 0, st, (const float*)S.main.losses, losslog + 4 * i,
+                           dyb_rep_current());
+        DYB_CHECK_LAUNCH();
       }
-      RUN(record_metrics(S, S.main, gender, slot++, st));
+      // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
+      if (metrics && S.eval_lower && i > 0) {
+        if (!gt_waited) {
+          HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
+          gt_waited = true;
+        }
+        RUN(record_metrics(S, S.main, gender, slot++, st));
+      }
     }
-    RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
+    {
+      HostTimer t(S.h_bwd);
+      RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
+    }
+    if (i == 0 && side) {
+      HostTimer t(S.h_tail);
+      RUN(issue_side_work(S, side));
+    }
     if (i < K) {
+      HostTimer t(S.h_update);
       RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, n, st));
       cur = S.theta_fast;
     }
   }
+  HostTimer t_tail(S.h_tail);
   // optimizer.step(): theta is about to change in place - the previous frame's tail on the side stream reads it
   if (S.side_pending) {
     HIPOK(hipStreamWaitEvent(st, S.e_side, 0));
@@ -616,19 +692,16 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
   const double bc2_sqrt = sqrt(1.0 - pow(S.beta2, t));
   RUN(dyb_adam_step(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, (float)step_size, (float)bc2_sqrt,
                     (float)S.eps, n, st));
-  // final inference() with the updated weights (dynaboa_benchmark.py:156)
-  hipStream_t fs = st;
+  // final inference() with the updated weights (dynaboa_benchmark.py:156): in line, or - with a side stream - owed to the
+  // next call / dyb_stepper_join (the caller keeps this frame's inputs alive until then)
   if (side) {
     HIPOK(hipEventRecord(S.e_theta, st));
-    HIPOK(hipStreamWaitEvent(side, S.e_theta, 0));
-    fs = side;
+    S.tail.on = true; S.tail.image = image; S.tail.gender = gender; S.tail.slot = slot++; S.tail.metrics = metrics;
+    S.tail_stream = side;
+    return DYB_OK;
   }
-  RUN(pass_forward(S, S.fin, S.theta, image, fs));
-  if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, fs));
-  if (side) {
-    HIPOK(hipEventRecord(S.e_side, side));
-    S.side_pending = true;
-  }
+  RUN(pass_forward(S, S.fin, S.theta, image, st));
+  if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
   return DYB_OK;
 }
 // ---- the full loss set -------------------------------------------------------------------------------------------------
@@ -881,6 +954,7 @@ extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs
 extern "C" int dyb_stepper_join(void* stepper, hipStream_t st) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   DYB_REQUIRE(S, DYB_ERR_ARG);
+  if ((S->tail.on || S->gtjob.on) && S->tail_stream) RUN(issue_side_work(*S, S->tail_stream));      // the last frame's final inference
   if (S->side_pending) {
     HIPOK(hipStreamWaitEvent(st, S->e_side, 0));
     S->side_pending = false;

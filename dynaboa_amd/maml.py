@@ -12,7 +12,7 @@ First order is what the reference runs.  Second order (``first_order=False``, le
 outer gradient of K inner steps is  v_k = (I - lr*H_k) v_{k+1}  with H_k the Hessian of the k-th
 lower-level loss at the k-th fast weights, and each Hessian-vector product is the central difference
 of two FIRST-order gradients,  H v ~ (g(theta + e v) - g(theta - e v)) / 2e,  e = fd_rel*|theta|/|v|
-(measured against exact double-backward on the CPU oracle: 6e-4 relative at fd_rel = 1e-6, fp32).
+(fd_rel = 1e-5, chosen by a sweep against the reference's second-order goldens - see MAML.fd_rel).
 That costs two extra forward+backward passes per inner step - the same count an exact
 double-backward needs - and re-evaluating the loss at shifted weights needs the loss as a function,
 so ``adapt`` takes it: ``learner.adapt(loss, closure=lambda learner: loss_fn(learner))`` (the one
@@ -62,7 +62,13 @@ class _SecondOrderStep(torch.autograd.Function):
 
 
 class MAML(nn.Module):
-    fd_rel = 1e-6        # finite-difference step of the second-order path, relative to |theta| / |v|
+    # finite-difference step of the second-order path, relative to |theta| / |v|.  Swept on MI355X against the reference's
+    # second-order goldens (tools/so_fd_probe.py, profiles/r02_so_fd_sweep.txt): per-tensor outer-gradient norm error
+    # median / max at inner_step 2 and 3 = 8.6e-4 / 1.3e-2 and 7.5e-4 / 1.8e-2 at 1e-6 (fp32 rounding of the difference),
+    # 3.7e-4 / 5.0e-3 and 1.2e-3 / 7.9e-3 at 1e-5, 1e-2 / 3.5e-2 and 3.4e-2 / 6.7e-2 at 1e-4, and garbage from 1e-3 on (the
+    # perturbed forward leaves the linear region of thousands of ReLUs: this network is piecewise linear in theta, a large
+    # step measures kink crossings, not curvature).  The first-order gradient is 19-24 % away from the second-order one.
+    fd_rel = 1e-5
 
     def __init__(self, model: nn.Module, lr: float, first_order: bool = True, _theta=None):
         super().__init__()

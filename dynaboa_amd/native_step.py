@@ -233,6 +233,8 @@ class NativeStepper:
         t = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
         for st in self._adam:
             st["step"] = t
+        # with a side stream the final inference of this frame is issued by the NEXT call (or join()): its inputs stay alive
+        self._prev_keep, self._keep_inputs = getattr(self, "_keep_inputs", None), keep
         self.frame += 1
         return f, slot0
 

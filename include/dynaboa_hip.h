@@ -317,6 +317,9 @@ int dyb_stepper_set_i(void* stepper, const char* key, long long value);
 int dyb_stepper_set_f(void* stepper, const char* key, double value);
 int dyb_stepper_set_p(void* stepper, const char* key, const void* ptr);
 long long dyb_stepper_get_i(const void* stepper, const char* key);
+/* host issue time in ms accumulated over "host_frames" frame steps, by section: host_ms_forward / _backward / _head (loss head
+ * + records) / _update (fast weights) / _tail (Adam + final inference) / _total */
+double dyb_stepper_get_f(const void* stepper, const char* key);
 size_t dyb_stepper_workspace_bytes(void* stepper);
 int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes, dyb_stream_t stream);
 int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,

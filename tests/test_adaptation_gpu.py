@@ -263,7 +263,7 @@ def test_second_order_matches_reference_second_order():
             err_so = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
             gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
             print("second-order grad-norm error: median %.2e max %.2e; FO-vs-SO gap: median %.2e" % (np.median(err_so), err_so.max(), np.median(gap)))
-            assert np.median(err_so) < 1e-2 and err_so.max() < 5e-2
+            assert np.median(err_so) < 3e-3 and err_so.max() < 2e-2          # measured 3.7e-4..1.2e-3 / 5e-3..8e-3 (profiles/r02_so_fd_sweep.txt)
             assert np.median(err_so) < 0.1 * np.median(gap)
             for k in SLICE_PARAMS:
                 x = g1[k].flatten()[:256].double().cpu().numpy()
@@ -472,7 +472,7 @@ def test_second_order_inner3_matches_reference_second_order():
             err_so = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
             gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
             print("SO inner3 grad-norm error: median %.2e max %.2e; FO-vs-SO gap: median %.2e" % (np.median(err_so), err_so.max(), np.median(gap)))
-            assert np.median(err_so) < 1e-2 and err_so.max() < 5e-2
+            assert np.median(err_so) < 3e-3 and err_so.max() < 2e-2          # measured 3.7e-4..1.2e-3 / 5e-3..8e-3 (profiles/r02_so_fd_sweep.txt)
             assert np.median(err_so) < 0.1 * np.median(gap)
 
 

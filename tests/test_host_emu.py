@@ -219,96 +219,16 @@ def test_native_stepper_is_bit_identical_to_autograd_path(emu_lib):
 
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
-    assert NS.supported(DB.frame_only_options(inner_step=3)) is None
-    assert NS.supported(DB.parser.parse_args([])) is not None                       # the full default term set: autograd path
+    assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None
+    assert NS.mode(DB.parser.parse_args([])) == "full"                            # the reference's default term set: covered too
     assert NS.supported(DB.frame_only_options(second_order=1)) == "second order"
     assert NS.supported(DB.frame_only_options(share_forwards=0)) is not None
-
-
-@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~2 min under the emulator (the GPU suite runs the same check at S = 3); set DYB_EMU_FULL=1")
-def test_replica_group_matches_single_sequences_on_emulator(emu_lib):
-    """Two sequence replicas stepped by ONE chain of launches (replica = a grid dimension, csrc/dyb_common.h) against
-    the same two sequences adapted alone: identical weights / Adam moments per replica."""
-    from dynaboa_amd import assets, benchmark as DB, native_step as NS
-    from dynaboa_amd.base_adaptor import synthetic_bundle
-
-    def mk(r):
-        o = DB.frame_only_options(inner_step=1)
-        o.deferred_metrics = 1
-        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=True, randomize_norm=True), device="cpu")
-    frames = [[assets.make_frame(100 * r, 1, seed=22)] for r in range(2)]
-    singles = []
-    for r in range(2):
-        ad = mk(r)
-        ad.excute(frames[r], nframes=1)
-        st = ad.optimizer.state[ad.model.module.theta]
-        singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()))
-    ads = [mk(r) for r in range(2)]
-    grp = NS.ReplicaGroup(ads, 1)
-    grp.step([frames[r][0] for r in range(2)], 0)
-    grp.flush_metrics()
-    for r in range(2):
-        st = ads[r].optimizer.state[ads[r].model.module.theta]
-        assert torch.equal(ads[r].model.module.theta.detach(), singles[r][0]), r
-        assert torch.equal(st["exp_avg"], singles[r][1]) and torch.equal(st["exp_avg_sq"], singles[r][2]), r
-
-
-@pytest.mark.slow
-def test_hmr_train_mode_dropout_forward_backward(emu_lib, ckpt_rand):
-    """HMR.train(): nn.Dropout(0.5) after fc1 / fc2 of every regressor iteration (reference model/hmr.py:84,86,165,169).
-    The masks are read back from the activations (post-dropout vector == 0 or 2x the pre-dropout one), then the regressor is
-    rebuilt in torch with exactly those masks: outputs and the gradients of every regressor parameter must agree with the
-    engine's train-mode forward / backward (which regenerates the masks from the counter-based generator)."""
-    from dynaboa_amd import assets
-    from dynaboa_amd.hmr import hmr
-    from oracle import ref_cpu as O
-    mp = assets.make_smpl_mean_params(identity_pose=False, seed=3)
-    m = hmr(mp, seed=1)
-    m.load_state_dict(ckpt_rand, strict=True)
-    img = assets.make_frame(0, 1, seed=22)["image"]
-    torch.manual_seed(77)
-    m.train()
-    r, s, c, feats = m(img, need_feature=True)
-    g = torch.Generator().manual_seed(1)
-    wr, ws_, wc = torch.randn(r.shape, generator=g), torch.randn(s.shape, generator=g), torch.randn(c.shape, generator=g)
-    ((r * wr).sum() + (s * ws_).sum() + (c * wc).sum()).backward()
-    G = m._layout1.unpack(m.theta.grad)
-    # masks from the features: 6+3t = fc1 output, 7+3t = after drop1
-    xf = feats[5].detach()
-    P = {k: v.clone().requires_grad_(True) for k, v in ckpt_rand.items() if k.split(".")[0] in ("fc1", "fc2", "decpose", "decshape", "deccam")}
-    pose, shape, cam = ckpt_rand["init_pose"].clone(), ckpt_rand["init_shape"].clone(), ckpt_rand["init_cam"].clone()
-    kept = []
-    for t in range(3):
-        pre, post = feats[6 + 3 * t].detach(), feats[7 + 3 * t].detach()
-        m1 = (post != 0).float()
-        assert torch.allclose(post, pre * m1 * 2, rtol=1e-6, atol=1e-7)          # y = x * keep / (1 - p)
-        kept.append(float(m1.mean()))
-        if t > 0:
-            continue                     # later iterations start from the (masked) previous state: the masks are what is checked
-        h1 = torch.nn.functional.linear(torch.cat([xf, pose, shape, cam], 1), P["fc1.weight"], P["fc1.bias"])
-        assert rel_err(h1.detach().numpy(), pre.numpy()) < 1e-4
-        h2 = torch.nn.functional.linear(h1 * m1 * 2, P["fc2.weight"], P["fc2.bias"])
-        assert rel_err(h2.detach().numpy(), feats[8 + 3 * t].detach().numpy()) < 1e-4
-    assert 0.4 < kept[0] < 0.6
-    # eval() is untouched by the train-mode plumbing: same output as before, and deterministic
-    m.eval()
-    with torch.no_grad():
-        a = m(img)
-        b = m(img)
-    assert torch.equal(a[1], b[1])
-    # the train-mode gradient differs from the eval-mode one (masks act in backward too) but has its scale
-    m.theta.grad = None
-    r2, s2, c2 = m(img)
-    ((r2 * wr).sum() + (s2 * ws_).sum() + (c2 * wc).sum()).backward()
-    Ge = m._layout1.unpack(m.theta.grad)
-    for k in ("fc2.weight", "decpose.weight", "layer4.2.conv3.weight"):
-        ratio = float(G[k].norm() / Ge[k].norm())
-        assert 0.5 < ratio < 2.5 and not torch.equal(G[k], Ge[k]), (k, ratio)
-    # exact check of the backward through drop1 on fc1: dL/d(fc1.bias) = sum_t (d h1_t), and d h1_t = mask1_t * 2 * (fc2^T d h2_t):
-    # rows of fc1.weight's gradient whose unit was dropped in ALL three iterations must be exactly zero
-    dead = torch.ones(1024, dtype=torch.bool)
-    for t in range(3):
-        dead &= (feats[7 + 3 * t].detach()[0] == 0)
-    assert int(dead.sum()) > 60                                        # ~1024 / 8
-    assert float(G["fc1.weight"][dead].abs().max()) == 0.0 and float(G["fc1.bias"][dead].abs().max()) == 0.0
-    assert float(G["fc1.weight"][~dead].abs().max()) > 0
+    o = DB.parser.parse_args([])
+    o.batch_size = 32
+    assert NS.mode(o) == "" and "batch" in NS.reason
+    o = DB.parser.parse_args([])
+    o.teacher_dropout = 1
+    assert NS.mode(o) == ""                                                       # train-mode teacher: the autograd composition
+    o = DB.parser.parse_args([])
+    o.sample_num = 2
+    assert NS.mode(o) == "" and NS.mode(DB.parser.parse_args([]), have_bundle=False) == "full"

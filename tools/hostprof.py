@@ -1,48 +1,32 @@
-#!/usr/bin/env python3
-"""cProfile of the host side of the bench loop (where does the ~22 ms/frame of issue time go?)."""
-import cProfile
-import os
-import pstats
-import sys
-
+"""Where the host time of a natively stepped frame goes (S = 1, frame-loss set): the stepper's own section timers
+(dyb_stepper_get_f) against the wall clock of the Python loop around it."""
+import sys, time, ctypes
+sys.path.insert(0, '/root/repo')
 import torch
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from dynaboa_amd import assets, benchmark as DB          # noqa: E402
-from dynaboa_amd.base_adaptor import synthetic_bundle     # noqa: E402
-
+from dynaboa_amd import assets, benchmark as DB
+from dynaboa_amd.base_adaptor import synthetic_bundle
 dev = torch.device("cuda:0")
-o = DB.frame_only_options(inner_step=3)
-o.deferred_metrics = 1
-o.overlap_metrics = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=dev)
-N = 30
-frames = [{k: v.to(dev) for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(N + 5)]
-ad.reset_records(N + 5)
-
-
-def run(lo, hi):
-    for s in range(lo, hi):
-        ad.global_step = s
-        ad.fit_losses = {}
-        ad.model.eval()
-        ad.adaptation(frames[s])
-
-
-run(0, 5)
-torch.cuda.synchronize()
-pr = cProfile.Profile()
-pr.enable()
-run(5, N + 5)
-pr.disable()
-torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("cumulative")
-import io
-buf = io.StringIO()
-pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(28)
-print(buf.getvalue()[:6000])
-buf = io.StringIO()
-pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(30)
-print(buf.getvalue()[:6000])
+for overlap in (0, 1):
+    o = DB.frame_only_options(inner_step=3); o.deferred_metrics = 1; o.overlap_metrics = overlap
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True), device=dev)
+    N = 120
+    frames = [{k: v.to(dev) for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(N)]
+    ad.reset_records(N)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for s in range(20):
+            ad.global_step = s; ad.fit_losses = {}; ad.adaptation(frames[s])
+        torch.cuda.synchronize()
+        lib, h = ad._native.lib, ad._native.h
+        lib.dyb_stepper_get_f.restype = ctypes.c_double
+        base = {k: lib.dyb_stepper_get_f(h, k.encode()) for k in ("host_ms_forward", "host_ms_backward", "host_ms_head", "host_ms_update", "host_ms_tail", "host_ms_total", "host_frames")}
+        t0 = time.perf_counter()
+        for s in range(20, N):
+            ad.global_step = s; ad.fit_losses = {}; ad.adaptation(frames[s])
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+    now = {k: lib.dyb_stepper_get_f(h, k.encode()) for k in base}
+    n = now["host_frames"] - base["host_frames"]
+    print("overlap", overlap, "frames", n, "wall ms/frame %.2f" % (t_all * 1e3 / n), "python loop issue ms/frame %.2f" % (t_issue * 1e3 / n),
+          {k: round((now[k] - base[k]) / n, 3) for k in base if k != "host_frames"})
