@@ -131,6 +131,15 @@ int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, co
 int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w, float* dx, const float* addend, void* ws,
                           size_t ws_bytes, int* nslabs, hipStream_t st);
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);
+// throughput schedule (several sequence replicas per launch): dy materialised once per layer, plain gradient convolutions
+bool dyb_throughput_mode();                     // "rep_split" switch on and >= 8 replicas in the current launch scope
+int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
+                        const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
+int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
+                             size_t ws_bytes, int* nslabs, hipStream_t st);
+// dw = x^T dy with x plain (x != NULL) or relu(gn(y_prev)) formed in the loader from the saved statistics
+int dyb_conv_wgrad_plain(const ConvDesc& d, const float* x, const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                         const float* beta_prev, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 int dyb_avgpool_fwd_tail(const float* x, float* const* dsts, int ndst, int ld, int N, int HW, int C, const float* tail,
                          int tail_ld, int tail_cols, int tail_dst_col, hipStream_t st);
 

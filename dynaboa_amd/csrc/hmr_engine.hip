@@ -116,7 +116,7 @@ struct HmrPlan {
   int poolH, poolW;            // max-pool output
   int featHW;                  // spatial size of the last feature map (7*7)
   // workspace carve (bytes)
-  size_t ws_conv, ws_conv_aux, ws_gn, ws_gnb, ws_lin, ws_grad_each, ws_dy, ws_reg, ws_total;
+  size_t ws_conv, ws_conv_aux, ws_gn, ws_gnb, ws_lin, ws_grad_each, ws_dy, ws_dy2, ws_reg, ws_total;
   // hipGraph cache: a whole forward / backward call is captured once per distinct set of pointer
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
@@ -252,13 +252,14 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_conv = align64(wc / 4) * 4;
   P.ws_conv_aux = P.ws_conv;
   P.ws_dy = dyoff * 4;
+  P.ws_dy2 = dyoff * 4;         // per-layer dy slots of the throughput schedule (materialised GroupNorm-backward outputs)
   P.ws_gn = align64(wg / 4) * 4;
   P.ws_gnb = gnboff * 4;
   P.ws_lin = align64(wl / 4) * 4;
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg + P.ws_dy2;
   return pp;
 }
 
@@ -416,6 +417,7 @@ struct WsCarve {
   float* g[3];
   float* dy;
   float* reg;
+  float* dy2;
 };
 static WsCarve carve(const HmrPlan& P, void* ws) {
   WsCarve c;
@@ -427,7 +429,8 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   c.lin = b; b += P.ws_lin;
   for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
   c.dy = reinterpret_cast<float*>(b); b += P.ws_dy;
-  c.reg = reinterpret_cast<float*>(b);
+  c.reg = reinterpret_cast<float*>(b); b += P.ws_reg;
+  c.dy2 = reinterpret_cast<float*>(b);
   return c;
 }
 
@@ -627,6 +630,7 @@ struct WgradJob {
   const ConvL* in_prev;
   const float* dm;
   int nch, ncolb;              // layout of the layer's partial block (0 = gn_bwd_reduce's)
+  const float* dy;             // throughput schedule: the layer's materialised dy (NULL: formed in the loader from dm)
 };
 // per-call bookkeeping of the backward chain: which layers' partial blocks have a non-default layout (written by a K4
 // data-gradient epilogue) and which layers' reduce has already happened there
@@ -639,6 +643,11 @@ static int run_wgrad(HmrPlan& P, const WgradJob& j, const float* params, const f
   const ConvL& c = P.convs[j.ci];
   const float* part = w.gnb + c.gnb;
   const ConvL* ip = j.in_prev;       // non-null: the conv's input was relu(gn(y_prev)), never materialised
+  if (j.dy) {
+    ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
+    return dyb_conv_wgrad_plain(d, ip ? nullptr : j.conv_in, ip ? acts + ip->y : nullptr, ip ? acts + ip->stats : nullptr,
+                                ip ? params + ip->gam : nullptr, ip ? params + ip->bet : nullptr, j.dy, grads + c.w, slabs, P.ws_conv, st);
+  }
   return dyb_conv2d_nhwc_wgrad_gn_n(ip ? nullptr : j.conv_in, ip ? acts + ip->y : nullptr, ip ? acts + ip->stats : nullptr,
                                     ip ? params + ip->gam : nullptr, ip ? params + ip->bet : nullptr, j.dm, acts + c.y,
                                     acts + c.stats, part, j.nch, j.ncolb, params + c.gam, grads + c.w, grads + c.gam,
@@ -655,9 +664,19 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
   float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
+  const bool tp = dyb_throughput_mode();
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
-                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st, done));
-  WgradJob j{ci, conv_in, in_prev, dm, 0, 0};
+                              acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st,
+                              tp ? nullptr : done));
+  WgradJob j{ci, conv_in, in_prev, dm, 0, 0, nullptr};
+  if (tp) {
+    // throughput schedule: dy once per layer (also dgamma / dbeta), plain gradient convolutions afterwards
+    float* dyl = w.dy2 + c.dy;
+    RUN(dyb_gn_bwd_apply_dy(dm, acts + c.y, acts + c.stats, part, 0, 0, params + c.gam, dyl, grads + c.gam, grads + c.bet, P.B,
+                            c.Ho * c.Wo, c.K, st));
+    if (done && hipEventRecord(done, st) != hipSuccess) return DYB_ERR_LAUNCH;
+    j.dy = dyl;
+  }
   if (jobs) jobs->push_back(j);
   else RUN(run_wgrad(P, j, params, acts, grads, w, w.conv, st));
   *dm_out = dm;
@@ -678,8 +697,12 @@ static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* act
   ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
   GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, bs.nch[ci], bs.ncolb[ci]};
   int ns = 1;
-  RUN(dyb_conv_dgrad_gn_raw(d, src, params + c.w, dx_buf, addend, w.conv, P.ws_conv, (out && P.fold_in_reduce) ? &ns : nullptr,
-                            st));
+  if (dyb_throughput_mode())       // dy of this layer was materialised by its reduce step (layer_gn_bwd)
+    RUN(dyb_conv_dgrad_plain_raw(d, w.dy2 + c.dy, params + c.w, dx_buf, addend, w.conv, P.ws_conv,
+                                 (out && P.fold_in_reduce) ? &ns : nullptr, st));
+  else
+    RUN(dyb_conv_dgrad_gn_raw(d, src, params + c.w, dx_buf, addend, w.conv, P.ws_conv, (out && P.fold_in_reduce) ? &ns : nullptr,
+                              st));
   if (out) {
     if (ns > 1) *out = Pending{reinterpret_cast<const float*>(w.conv), ns, (size_t)P.B * c.H * c.W * c.C, addend};
     else *out = plain(dx_buf);
@@ -836,7 +859,7 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   bs.nch.assign(P.convs.size(), 0); bs.ncolb.assign(P.convs.size(), 0); bs.reduced.assign(P.convs.size(), 0);
   // weight-gradient job of a layer whose reduce happened inside a K4 data gradient
   auto push_wgrad = [&](int ci, const float* conv_in, const ConvL* in_prev, const float* dm) -> int {
-    WgradJob j{ci, conv_in, in_prev, dm, bs.nch[ci], bs.ncolb[ci]};
+    WgradJob j{ci, conv_in, in_prev, dm, bs.nch[ci], bs.ncolb[ci], nullptr};
     if (jobs) { jobs->push_back(j); return DYB_OK; }
     return run_wgrad(P, j, params, acts, grads, w, w.conv, st);
   };

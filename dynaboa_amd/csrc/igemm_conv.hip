@@ -1093,9 +1093,11 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // Read from the environment ONCE (first use), never on the dispatch path; dyb_set_option changes one afterwards
 // (tests / A-B runs).  Names: "k4" (single-launch 1x1 forward + statistics), "k4_bwd" (1x1 data gradient carries the
 // producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit), "rep_split"
-// (split-K depth chosen for the replica-multiplied grid).
+// (replica-aware policy: split-K depth chosen for the replica-multiplied grid and, from "tp_min" replicas per launch on,
+// the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
+// "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1104,6 +1106,7 @@ struct DybSwitches {
     k4_maxc = env("DYB_K4_MAXC", 1024);
     rep_split = env("DYB_REP_SPLIT", 0);
     bf16 = 0;
+    tp_min = env("DYB_TP_MIN", 8);
   }
 };
 static DybSwitches& switches() {
@@ -1121,6 +1124,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "k4_maxc")) return &s.k4_maxc;
   if (!strcmp(name, "rep_split")) return &s.rep_split;
   if (!strcmp(name, "bf16")) return &s.bf16;
+  if (!strcmp(name, "tp_min")) return &s.tp_min;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1284,9 +1288,9 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     if (fuse) DYB_IGEMM_LAUNCH(MODE_DGRAD, true, false);
     else DYB_IGEMM_LAUNCH(MODE_DGRAD, false, false);
   } else {
-    DYB_REQUIRE(!nfuse || fuse, DYB_ERR_UNSUPPORTED);
     if (fuse && nfuse) DYB_IGEMM_LAUNCH(MODE_WGRAD, true, true);
     else if (fuse) DYB_IGEMM_LAUNCH(MODE_WGRAD, true, false);
+    else if (nfuse) DYB_IGEMM_LAUNCH(MODE_WGRAD, false, true);
     else DYB_IGEMM_LAUNCH(MODE_WGRAD, false, false);
   }
 #undef DYB_IGEMM_LAUNCH
@@ -1371,7 +1375,7 @@ bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
   const DybSwitches& sw = switches();                   // k4_bwd on: 1.40 -> 1.31 ms per backward
   const int enabled = sw.k4_bwd.load(std::memory_order_relaxed), max_k = sw.k4_maxc.load(std::memory_order_relaxed);
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && !dyb_bf16_current() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
+  return enabled && !dyb_bf16_current() && !dyb_throughput_mode() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
          d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
 }
 // dx of the 1x1 conv `d` (never materialised as such) -> dm / partials of the producer's GroupNorm; *nch, *ncolb = the
@@ -1414,6 +1418,25 @@ int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w
   if (rc != DYB_OK) return rc;
   return run_igemm(MODE_DGRAD, d, src.dm, w, dx, addend, ws, ws_bytes, nslabs, st, &f);
 }
+static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, const float* stats_in, const float* gamma,
+                       const float* beta, float* stats_out, int relu);
+// ---- throughput schedule: plain gradient convolutions over a materialised dy (dyb_common.h) -----------------------------
+bool dyb_throughput_mode() {
+  const DybSwitches& sw = switches();
+  return sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed);
+}
+int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
+                             size_t ws_bytes, int* nslabs, hipStream_t st) {
+  return run_igemm(MODE_DGRAD, d, dy, w, dx, addend, ws, ws_bytes, nslabs, st);
+}
+int dyb_conv_wgrad_plain(const ConvDesc& d, const float* x, const float* y_prev, const float* stats_prev, const float* gamma_prev,
+                         const float* beta_prev, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (x) return run_igemm(MODE_WGRAD, d, x, dy, dw, nullptr, ws, ws_bytes, nullptr, st);
+  DYB_REQUIRE(y_prev && stats_prev && gamma_prev && beta_prev && d.C % 16 == 0, DYB_ERR_ARG);
+  GnFwdFuse nf{};
+  make_nfuse(nf, d, nullptr, stats_prev, gamma_prev, beta_prev, nullptr, 1);
+  return run_igemm(MODE_WGRAD, d, y_prev, dy, dw, nullptr, ws, ws_bytes, nullptr, st, nullptr, &nf);
+}
 // out = sum_z slabs[z] (+ addend) over n floats (n % 4 == 0)
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st) {
   size_t n4 = n / 4;
@@ -1435,7 +1458,7 @@ bool dyb_conv_k4_ok(const ConvDesc& d) {
   // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
   // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && !dyb_bf16_current() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
+  return enabled && !dyb_bf16_current() && !dyb_throughput_mode() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }
 // conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count

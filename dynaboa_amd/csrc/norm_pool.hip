@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            int nchunks, int ncolb, const float* __restrict__ gamma,
                                                            float* __restrict__ dy, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int HW,
-                                                           int C, int relu) {
+                                                           int C, int relu, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, dout); DYB_RB(R, out); DYB_RB(R, y); DYB_RB(R, stats); DYB_RB(R, partials); DYB_RB(R, gpart); DYB_RB(R, gamma);
+  DYB_RB(R, dy); DYB_RB(R, dres); DYB_RB(R, dgamma); DYB_RB(R, dbeta);
   __shared__ float s_coef[16 * G * 2];          // N <= 16 per call path; larger N handled in slices below
   const int CQ = C >> 2, cqg = C >> 4;
   const float inv_m = 1.0f / ((float)(C / G) * (float)HW);
@@ -571,7 +574,30 @@ extern "C" int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_
   int minb = dyb_cdiv(C, 64);
   if (blocks < minb) blocks = minb;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dsrc, out, y, stats, (const float*)partials,
-                     (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu);
+                     (const float*)gpart, nch, ncolb, gamma, dy, dres, dgamma, dbeta, N, HW, C, relu, R1);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// The apply half on its own, for the engine's throughput schedule (several sequence replicas per launch): dy =
+// rstd*(gamma*dm - c1 - xhat*c2) is MATERIALISED once per layer from the masked gradient dm and the partial block `part`
+// (layout nch x ncolb, 0 = the reduce kernel's) instead of being re-formed in every tile of the data- and weight-gradient
+// convolutions' loaders - with the chip full, that recomputation (x9 taps, x Cout/64 column tiles) is what those kernels
+// spend their time on, while the extra launch it saves at one sequence per launch no longer matters.  Also folds dgamma / dbeta.
+int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
+                        const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st) {
+  DYB_REQUIRE(dm && y && stats && part && gamma && dy && dgamma && dbeta, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && C <= 2048 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  if (nch <= 0 || ncolb <= 0) dyb_gn_bwd_layout(N, HW, C, &nch, &ncolb);
+  const float* gpart = part + (size_t)N * nch * 2 * C;
+  const int CQ = C / 4;
+  size_t total4 = (size_t)N * HW * CQ;
+  int blocks = (int)((total4 + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  int minb = dyb_cdiv(C, 64);
+  if (blocks < minb) blocks = minb;
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, dm, (const float*)nullptr, y, stats, part, gpart, nch,
+                     ncolb, gamma, dy, (float*)nullptr, dgamma, dbeta, N, HW, C, 0, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

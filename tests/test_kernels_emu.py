@@ -172,6 +172,19 @@ def test_optim(be):
     K.case_optim(be, n=4096)
 
 
+@pytest.mark.slow
+def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand):
+    """The throughput schedule (materialised dy, plain gradient convolutions; used by launches covering >= 8 sequence
+    replicas) forced on for a plain call: the whole engine against the reference module's golden g3."""
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    try:
+        K.case_hmr_engine(be, golden, ckpt_rand)
+    finally:
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)
+
+
 @pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")
 @pytest.mark.parametrize("k4_batch", [0, 1])
 def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, k4_batch):

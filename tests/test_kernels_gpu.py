@@ -186,6 +186,20 @@ def test_hmr_engine_vs_reference_module(be, ckpt_rand, k4_batch):
     print(e)
 
 
+def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand):
+    """The engine's throughput schedule (what launches covering >= 8 sequence replicas use: dy materialised once per layer by
+    the GroupNorm-backward apply kernel, plain data- / weight-gradient convolutions, no single-launch 1x1 kernels), forced on
+    for a plain batch-2 call, against the reference module's golden g3."""
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    try:
+        e = K.case_hmr_engine(be, golden, ckpt_rand)
+    finally:
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)
+    print(e)
+
+
 @pytest.mark.parametrize("k4_batch", [1, 0])
 def test_batched_pairs_both_dispatches(be, k4_batch):
     """The batch > 1 layer pairs / data-gradient + reduce pairs / bottlenecks through both dispatches (single-launch 1x1
