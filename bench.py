@@ -77,7 +77,13 @@ def conv_roofline(run, lo, hi, main_stream):
     ms, n, flop, nbytes = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
     if lib.dyb_conv_timing_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(flop), ctypes.byref(nbytes)) != 0 or n.value == 0:
         return None
-    return dict(achieved=flop.value / (ms.value * 1e-3) / 1e12, conv_ms_per_frame=ms.value / nfr,
+    table = None
+    if hasattr(lib, "dyb_conv_timing_table"):
+        need = lib.dyb_conv_timing_table(None, 0)
+        buf = ctypes.create_string_buffer(int(need))
+        lib.dyb_conv_timing_table(buf, need)
+        table = buf.value.decode()
+    return dict(table=table, achieved=flop.value / (ms.value * 1e-3) / 1e12, conv_ms_per_frame=ms.value / nfr,
                 launches_per_frame=n.value / nfr, avg_launch_us=ms.value * 1e3 / n.value,
                 gflop_per_frame=flop.value / nfr / 1e9, algorithmic_bytes_per_launch=nbytes.value / n.value,
                 sample_frames=nfr)
@@ -311,6 +317,7 @@ def main():
     ap.add_argument("--replicas", type=str, default="1,2,4,8,16",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
+    ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")
     ap.add_argument("--cpu_baseline_only", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -406,6 +413,9 @@ def main():
             torch.cuda.synchronize()
             r = conv_roofline(run, lo, lo + n_roof, main_stream)
             rn.flush()
+        if not args.no_roofline and r is not None and args.conv_table and r.get("table"):
+            with open(args.conv_table, "w") as f:
+                f.write(r["table"])
         if not args.no_roofline and r is not None:
             tr = pmc_traffic()
             fr = n_roof * seqs

@@ -31,6 +31,9 @@
 #include <atomic>
 #include <mutex>
 #include <vector>
+#include <map>
+#include <string>
+#include <stdio.h>
 
 #include "dyb_common.h"
 
@@ -1189,11 +1192,14 @@ extern "C" size_t dyb_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
 // the metric forwards come from a third) every igemm launch carries a (start, stop) event
 // pair on its own dispatch (hipExtLaunchKernelGGL: no extra packets in the stream), so the durations
 // are those of the kernels as they run inside the real path, on whatever stream they were issued to.
+struct IgemmTimingRec { char tag; int nsplit, nrep; ConvDesc d; double flop; };
 struct IgemmTiming {
   std::vector<hipEvent_t> ev;
+  std::vector<IgemmTimingRec> rec;             // one per timed launch (event pair i <-> rec[i])
   size_t used = 0;
   double flop = 0.0, bytes = 0.0;
 };
+static std::string g_timing_table;             // per-shape table of the last closed scope (dyb_conv_timing_table)
 static IgemmTiming* g_timing = nullptr;
 static std::mutex g_timing_mu;
 
@@ -1215,9 +1221,24 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   IgemmTiming* t = g_timing;
   g_timing = nullptr;
   double ms = 0.0;
+  struct Row { double ms = 0.0, flop = 0.0; long long n = 0; };
+  std::map<std::string, Row> rows;
   for (size_t i = 0; i + 1 < t->used; i += 2) {
     float one = 0.f;
-    if (hipEventElapsedTime(&one, t->ev[i], t->ev[i + 1]) == hipSuccess) ms += one;
+    if (hipEventElapsedTime(&one, t->ev[i], t->ev[i + 1]) != hipSuccess) continue;
+    ms += one;
+    const IgemmTimingRec& r = t->rec[i / 2];
+    char key[160];
+    snprintf(key, sizeof key, "%c,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", r.tag, r.d.N, r.d.H, r.d.W, r.d.C, r.d.K, r.d.R, r.d.stride,
+             r.d.pad, r.nsplit, r.nrep);
+    Row& row = rows[key];
+    row.ms += one; row.flop += r.flop; row.n += 1;
+  }
+  g_timing_table = "kind,N,H,W,C,K,R,stride,pad,nsplit,nrep,launches,ms_total,gflop_total\n";
+  for (const auto& kv : rows) {
+    char tail[96];
+    snprintf(tail, sizeof tail, ",%lld,%.6f,%.6f\n", kv.second.n, kv.second.ms, kv.second.flop * 1e-9);
+    g_timing_table += kv.first + tail;
   }
   *ms_total = ms; *launches = (long long)(t->used / 2); *flop = t->flop; *bytes = t->bytes;
   for (auto& e : t->ev) (void)hipEventDestroy(e);
@@ -1225,8 +1246,20 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   return DYB_OK;
 }
 
+// Per-shape table of the scope closed last (CSV, header line first): kind f/d/w = tiled forward / data gradient / weight
+// gradient, F/D = the single-launch 1x1 kernels; returns the bytes needed including the terminator.
+extern "C" size_t dyb_conv_timing_table(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  if (buf && cap) {
+    size_t n = g_timing_table.size() < cap - 1 ? g_timing_table.size() : cap - 1;
+    memcpy(buf, g_timing_table.data(), n);
+    buf[n] = 0;
+  }
+  return g_timing_table.size() + 1;
+}
+
 // a (start, stop) event pair + the launch's algorithmic flop / bytes booked, when a timing scope is open
-static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1) {
+static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, char tag = '?', int nsplit = 1) {
   if (!g_timing) return;                      // unlocked fast path when no scope is open
   std::lock_guard<std::mutex> lock(g_timing_mu);
   if (!g_timing || g_timing->used + 2 > g_timing->ev.size()) return;
@@ -1236,7 +1269,9 @@ static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1) 
   const double creal = d.C == 4 ? 3.0 : (double)d.C;        // the stem's 4th input channel is padding
   const double px = (double)d.N * conv_out_dim(d.H, d.R, d.stride, d.pad) * conv_out_dim(d.W, d.S, d.stride, d.pad);
   const double nrep = (double)dyb_rep_current().n;          // a launch covering n sequence replicas does n convolutions
-  g_timing->flop += nrep * 2.0 * px * d.K * d.R * d.S * creal;
+  const double fl = nrep * 2.0 * px * d.K * d.R * d.S * creal;
+  g_timing->rec.push_back(IgemmTimingRec{tag, nsplit, (int)nrep, d, fl});
+  g_timing->flop += fl;
   g_timing->bytes += nrep * 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
 }
 
@@ -1267,7 +1302,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   DYB_REQUIRE(!(fuse || nfuse) || d.N <= 64, DYB_ERR_UNSUPPORTED);
   const dim3 blk(256);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  timing_acquire(d, &ev0, &ev1);
+  timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 'f' : mode == MODE_DGRAD ? 'd' : 'w', g.nsplit);
   const bool bf = dyb_bf16_current();
 #define DYB_IGEMM_LAUNCH1(M_, GB_, FA_, BF_)                                                                           \
   do {                                                                                                                 \
@@ -1394,7 +1429,7 @@ int dyb_conv_dgrad_k4(const ConvDesc& d, const GnBwdSrc& src, const float* w, co
   K4DgradArgs g{src.dm, w, addend, y_p, out_p, stats_p, gamma_p, beta_p, dm_p, part_p, part_p + (size_t)grid.x * 2 * d.C, M, d.C, d.K,
                 d.N, tpi};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  timing_acquire(d, &ev0, &ev1);                      // bench.py's conv timing scope
+  timing_acquire(d, &ev0, &ev1, 'D');                 // bench.py's conv timing scope
 #define DYB_K4D_LAUNCH(MU_)                                                                                          \
   do {                                                                                                               \
     if (ev0) hipExtLaunchKernelGGL((igemm_k4_dgrad_kernel<MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f, R);      \
@@ -1474,7 +1509,7 @@ int dyb_conv_fwd_k4(const ConvDesc& d, const float* x, const float* w, float* y,
   GnFwdFuse f{};
   if (nf) f = *nf;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  timing_acquire(d, &ev0, &ev1);
+  timing_acquire(d, &ev0, &ev1, 'F');
 #define DYB_K4_LAUNCH(FA_, MU_)                                                                                       \
   do {                                                                                                                \
     if (ev0) hipExtLaunchKernelGGL((igemm_k4_fwd_kernel<FA_, MU_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, f, R);    \

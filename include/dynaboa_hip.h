@@ -106,6 +106,10 @@ int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, 
  * algorithmic flop / bytes those launches stand for. */
 int dyb_conv_timing_begin(int max_launches);
 int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, double* bytes);
+/* Per-shape breakdown of the scope closed last, as CSV text (header line first; kind f/d/w = tiled forward / data gradient /
+ * weight gradient kernel, F/D = the single-launch 1x1 kernels).  Copies at most cap-1 bytes + terminator into buf; returns
+ * the size needed.  tools/conv_table.py prints it. */
+size_t dyb_conv_timing_table(char* buf, size_t cap);
 
 /* One forward layer = conv + the GroupNorm statistics of its output (what the engine issues per layer): y and *nchunks
  * partial records [G][2] in `partials` (>= dyb_groupnorm_workspace_bytes(N, Ho*Wo, K) and >= 4*(Ho*Wo/32+1)*(K/32)*8
