@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--replicas", type=str, default="1,2,4,8,16",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
+    ap.add_argument("--probe", type=str, default="", help="mode,H,C,K,R: phase clocks of the throughput conv kernel for that layer (diagnostic)")
+    ap.add_argument("--probe_out", type=str, default="")
     ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")
     ap.add_argument("--cpu_baseline_only", action="store_true")
     args = ap.parse_args()
@@ -359,7 +361,34 @@ def main():
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream
     main_stream = torch.cuda.Stream(device=device)
+    probe_buf = None
+    if args.probe:
+        from dynaboa_amd import _lib
+        pm, pH, pC, pK, pR = (int(v) for v in args.probe.split(","))
+        cap = 8192
+        probe_buf = torch.zeros(cap * 4 * 8, dtype=torch.int64, device=device)
+        _lib.load().dyb_conv_probe_set(probe_buf.data_ptr(), cap, pm, pH, pC, pK, pR)
     res = timed_stream(rn, args.warmup, args.steps, main_stream, dist, per_frame=(args.steps >= 200))
+    if probe_buf is not None:
+        torch.cuda.synchronize()
+        _lib.load().dyb_conv_probe_set(None, 0, 0, 0, 0, 0, 0)
+        rec = probe_buf.cpu().numpy().reshape(cap, 4, 8)
+        rec = rec[rec[:, 0, 1] != 0]                      # workgroups of the last matching launch
+        if len(rec):
+            t0, t1 = rec[..., 0].min(), rec[..., 1].max()
+            steps = np.maximum(rec[..., 6], 1).astype(np.float64)
+            life = (rec[..., 1] - rec[..., 0]).astype(np.float64)
+            pr = dict(workgroups=int(len(rec)), kernel_span_cycles=int(t1 - t0), ksteps_per_wg=float(steps.mean()),
+                      wave_lifetime_cycles=dict(mean=float(life.mean()), min=float(life.min()), max=float(life.max())),
+                      start_offset_cycles=dict(mean=float((rec[..., 0] - t0).mean()), max=float((rec[..., 0] - t0).max())),
+                      per_kstep_cycles=dict(load_issue=float((rec[..., 2] / steps).mean()), mfma_block=float((rec[..., 3] / steps).mean()),
+                                            wait_and_stage=float((rec[..., 4] / steps).mean()), barrier=float((rec[..., 5] / steps).mean())),
+                      outside_loop_cycles=float((life - rec[..., 2:6].sum(-1)).mean()),
+                      note="s_memtime clocks (100 MHz constant clock on gfx950 if REALTIME; else shader cycles) of lane 0 of every wave; "
+                           "the MFMA block's time is the time to ISSUE its 32 MFMAs")
+            print("PROBE " + json.dumps(pr), file=sys.stderr)
+            if args.probe_out:
+                json.dump(pr, open(args.probe_out, "w"), indent=1)
     dt, t_issue, metrics, run = res["dt"], res["t_issue"], res["metrics"], res["run"]
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)

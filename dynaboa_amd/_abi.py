@@ -11,7 +11,7 @@ from typing import Dict, List, Tuple
 HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dynaboa_hip.h")
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
-            "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "void": None}
+            "long long": ctypes.c_longlong, "long": ctypes.c_long, "unsigned long long": ctypes.c_ulonglong, "void": None}
 
 
 def _ctype(t: str):

@@ -17,7 +17,9 @@ def sources():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    deps = sources() + [os.path.join(CSRC, "dyb_common.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    deps = sources() + headers
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     objdir = os.path.join(HERE, "csrc", "_obj")
@@ -26,7 +28,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in sources():
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), os.path.getmtime(deps[-1])):
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
             cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void feat_cos_kernel(const float* __restrict_
 }
 
 // replica r's frame inputs (separate caller tensors) into its staging area inside the workspace, one launch for all replicas
-#define DYB_MAX_REPLICAS 16
+#define DYB_MAX_REPLICAS 64
 struct GatherArgs {
   const float* src[5][DYB_MAX_REPLICAS];     // image, kp2d, gt_pose, gt_betas, gender (int64 viewed as 2 floats)
   float* dst[5];                             // replica 0's staging buffers

@@ -59,6 +59,8 @@ struct IgemmArgs {
   int logC, logK;
   int M, Ncols, Kdim;    // GEMM sizes for this mode
   int ktiles, tiles_per_split, nsplit;
+  int xcd;               // throughput form: XCD-contiguous workgroup order
+  unsigned long long* probe;   // throughput form: per-wave phase clocks (dyb_conv_probe_set), normally NULL
 };
 
 // ---- tile loaders: each returns the 16 bytes this thread contributes to the K-step tile ----
@@ -1098,9 +1100,10 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit), "rep_split"
 // (replica-aware policy: split-K depth chosen for the replica-multiplied grid and, from "tp_min" replicas per launch on,
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
-// "bf16" (bf16 matrix cores for direct calls of the conv entry points).
+// "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles; 0 = the 64x64 kernel), "tp_grid" (workgroups
+// its split-K aims for), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1110,6 +1113,9 @@ struct DybSwitches {
     rep_split = env("DYB_REP_SPLIT", 0);
     bf16 = 0;
     tp_min = env("DYB_TP_MIN", 8);
+    tp_kernel = env("DYB_TP_KERNEL", 1);
+    tp_grid = env("DYB_TP_GRID", 512);
+    tp_xcd = env("DYB_TP_XCD", 1);
   }
 };
 static DybSwitches& switches() {
@@ -1128,6 +1134,9 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "rep_split")) return &s.rep_split;
   if (!strcmp(name, "bf16")) return &s.bf16;
   if (!strcmp(name, "tp_min")) return &s.tp_min;
+  if (!strcmp(name, "tp_kernel")) return &s.tp_kernel;
+  if (!strcmp(name, "tp_grid")) return &s.tp_grid;
+  if (!strcmp(name, "tp_xcd")) return &s.tp_xcd;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1246,7 +1255,7 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   return DYB_OK;
 }
 
-// Per-shape table of the scope closed last (CSV, header line first): kind f/d/w = tiled forward / data gradient / weight
+// Per-shape table of the scope closed last (CSV, header line first): kind f/d/w (t/u/v: throughput form) = tiled forward / data gradient / weight
 // gradient, F/D = the single-launch 1x1 kernels; returns the bytes needed including the terminator.
 extern "C" size_t dyb_conv_timing_table(char* buf, size_t cap) {
   std::lock_guard<std::mutex> lock(g_timing_mu);
@@ -1275,6 +1284,102 @@ static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, 
   g_timing->bytes += nrep * 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
 }
 
+// ---- phase probe of the throughput kernel (tools/tp_probe.py) ------------------------------------------------------------
+// While set, launches of igemm_tp_kernel whose (mode, H, C, K, R) match write, per wave, eight 64-bit words into `buf`
+// ([workgroup][wave][8]: start clock, end clock, cycles issuing loads, cycles in the MFMA block, cycles waiting for the loads +
+// staging them, cycles at the barrier, K-steps, replica) - s_memtime stamps taken by lane 0.  Later matching launches overwrite.
+struct TpProbe { unsigned long long* buf; long cap_wgs; int mode, H, C, K, R; };
+static TpProbe g_probe = {nullptr, 0, 0, 0, 0, 0, 0};
+extern "C" int dyb_conv_probe_set(void* buf, long cap_wgs, int mode, int H, int C, int K, int R) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  g_probe = TpProbe{reinterpret_cast<unsigned long long*>(buf), cap_wgs, mode, H, C, K, R};
+  return DYB_OK;
+}
+
+#include "igemm_tp.inc"
+
+// The throughput form (igemm_tp.inc) of one mode; same contract as run_igemm below.
+static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
+  if (fuse || dyb_bf16_current() || !dyb_throughput_mode()) return false;
+  if (!switches().tp_kernel.load(std::memory_order_relaxed)) return false;
+  // buffer addressing: 32-bit byte offsets, one mask bit per filter tap
+  const size_t lim = 0x7fffffffu / sizeof(float);
+  const int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
+  if ((size_t)d.N * d.H * d.W * d.C + (size_t)d.W * d.C * 8 >= lim || (size_t)d.N * Ho * Wo * d.K + (size_t)Wo * d.K * 8 >= lim ||
+      (size_t)d.R * d.S * d.C * d.K >= lim)
+    return false;
+  if (mode == MODE_FWD) return d.C % TPK == 0 && d.R * d.S <= 32;
+  if (mode == MODE_DGRAD) return d.K % TPK == 0 && d.R * d.S <= 32;
+  return true;
+}
+static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, const float* addend, void* ws, size_t ws_bytes,
+                        int* raw_slabs_out, hipStream_t st, const GnFwdFuse* nfuse) {
+  const DybRep& R = dyb_rep_current();
+  // tile form: 128x128, or one 64-slab along the short side
+  const int form = g.Ncols <= 64 ? 2 : (g.M <= 64 ? 1 : 0);
+  const int TM = form == 0 ? 128 : form == 1 ? 64 : 256, TN = form == 0 ? 128 : form == 1 ? 256 : 64;
+  g.ktiles = dyb_cdiv(g.Kdim, TPK);
+  g.xcd = switches().tp_xcd.load(std::memory_order_relaxed);
+  const long tiles = (long)dyb_cdiv(g.M, TM) * dyb_cdiv(g.Ncols, TN) * R.n;
+  int s = (int)(switches().tp_grid.load(std::memory_order_relaxed) / tiles);
+  const int maxs = g.ktiles / 4 > 0 ? g.ktiles / 4 : 1;                 // every split keeps >= 4 K-steps
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  const size_t per = (size_t)g.M * g.Ncols, ws_floats = ws ? ws_bytes / sizeof(float) : 0;
+  while (s > 1 && (size_t)s * per > ws_floats) --s;
+  g.nsplit = s;
+  g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
+  g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);
+  if (raw_slabs_out) *raw_slabs_out = 1;
+  const bool split = g.nsplit > 1;
+  g.out = split ? reinterpret_cast<float*>(ws) : out;
+  g.addend = split ? nullptr : addend;
+  dim3 grid(dyb_cdiv(g.M, TM), dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
+  g.probe = nullptr;
+  if (g_probe.buf && g_probe.mode == mode && g_probe.H == d.H && g_probe.C == d.C && g_probe.K == d.K && g_probe.R == d.R &&
+      (long)grid.x * grid.y * grid.z <= g_probe.cap_wgs)
+    g.probe = g_probe.buf;
+  GnFwdFuse nf{};
+  if (nfuse) nf = *nfuse;
+  DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 't' : mode == MODE_DGRAD ? 'u' : 'v', g.nsplit);
+#define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)                                                                                \
+  do {                                                                                                                   \
+    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, nf, R); \
+    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_>), grid, dim3(256), 0, st, g, nf, R);                     \
+  } while (0)
+#define DYB_TP_LAUNCH(M_, FA_)                        \
+  do {                                                \
+    if (form == 0) DYB_TP_LAUNCH2(M_, FA_, 2, 2);     \
+    else if (form == 1) DYB_TP_LAUNCH2(M_, FA_, 1, 4); \
+    else DYB_TP_LAUNCH2(M_, FA_, 4, 1);               \
+  } while (0)
+  if (mode == MODE_FWD) {
+    if (nfuse) DYB_TP_LAUNCH(MODE_FWD, true);
+    else DYB_TP_LAUNCH(MODE_FWD, false);
+  } else if (mode == MODE_DGRAD) {
+    DYB_REQUIRE(!nfuse, DYB_ERR_UNSUPPORTED);
+    DYB_TP_LAUNCH(MODE_DGRAD, false);
+  } else {
+    if (nfuse) DYB_TP_LAUNCH(MODE_WGRAD, true);
+    else DYB_TP_LAUNCH(MODE_WGRAD, false);
+  }
+#undef DYB_TP_LAUNCH
+#undef DYB_TP_LAUNCH2
+  DYB_CHECK_LAUNCH();
+  if (split) {
+    if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
+    size_t n4 = per / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
+                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4, R);
+    DYB_CHECK_LAUNCH();
+  }
+  return DYB_OK;
+}
+
 // Runs one mode.  If `raw_slabs_out` is non-null and the policy picks nsplit>1 the slabs are left
 // in the workspace un-reduced and *raw_slabs_out = nsplit (caller folds them, e.g. inside the
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
@@ -1286,6 +1391,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   int rc = fill_args(g, d, mode);
   if (rc != DYB_OK) return rc;
   g.A = A; g.B = B;
+  if (tp_eligible(mode, d, fuse)) return run_igemm_tp(mode, d, g, out, addend, ws, ws_bytes, raw_slabs_out, st, nfuse);
   g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode, raw_slabs_out != nullptr && mode != MODE_FWD);
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits

@@ -106,10 +106,14 @@ int dyb_conv2d_nhwc_wgrad_gn_gnin(const float* y_prev, const float* stats_prev, 
  * algorithmic flop / bytes those launches stand for. */
 int dyb_conv_timing_begin(int max_launches);
 int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, double* bytes);
-/* Per-shape breakdown of the scope closed last, as CSV text (header line first; kind f/d/w = tiled forward / data gradient /
+/* Per-shape breakdown of the scope closed last, as CSV text (header line first; kind f/d/w (t/u/v: throughput form) = tiled forward / data gradient /
  * weight gradient kernel, F/D = the single-launch 1x1 kernels).  Copies at most cap-1 bytes + terminator into buf; returns
  * the size needed.  tools/conv_table.py prints it. */
 size_t dyb_conv_timing_table(char* buf, size_t cap);
+/* Diagnostic: while set (buf != NULL), launches of the throughput-form conv kernel whose mode (0 forward, 1 data gradient,
+ * 2 weight gradient) and layer (H, C, K, R) match write per-wave phase clocks into buf ([workgroup][4 waves][8] 64-bit words,
+ * cap_wgs workgroups of room; layout in igemm_conv.hip).  bench.py --probe / tools/tp_probe.py read it.  buf = NULL clears. */
+int dyb_conv_probe_set(void* buf, long cap_wgs, int mode, int H, int C, int K, int R);
 
 /* One forward layer = conv + the GroupNorm statistics of its output (what the engine issues per layer): y and *nchunks
  * partial records [G][2] in `partials` (>= dyb_groupnorm_workspace_bytes(N, Ho*Wo, K) and >= 4*(Ho*Wo/32+1)*(K/32)*8

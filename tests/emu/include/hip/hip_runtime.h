@@ -1,3 +1,6 @@
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 // TEST INFRASTRUCTURE ONLY - a host stand-in for <hip/hip_runtime.h>.
 //
 // The product sources under dynaboa_amd/csrc/*.hip are plain HIP for gfx950 and contain no
@@ -59,6 +62,24 @@ typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, sync) ((void)0)
+static inline long long clock64() { return 0; }
+// raw buffer loads (stride 0): an offset whose per-lane part is >= num_records reads as 0.  Whether the hardware also adds the
+// scalar offset into that range check is not relied upon by the kernels, so the emulator aborts if an in-range per-lane offset
+// plus the scalar offset leaves the buffer.
+struct __amdgpu_buffer_rsrc_t { const char* p; unsigned n; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int n, int) {
+  return __amdgpu_buffer_rsrc_t{reinterpret_cast<const char*>(p), (unsigned)n};
+}
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  emu_u32x4 v = {0u, 0u, 0u, 0u};
+  if ((unsigned)voff >= r.n) return v;
+  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  if (off + 16 > r.n) { fprintf(stderr, "emu: buffer load leaves the buffer through the scalar offset (%llu + 16 > %u)\n", off, r.n); abort(); }
+  memcpy(&v, r.p + off, 16);
+  return v;
+}
 static inline void __threadfence_system() {}
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }

@@ -27,6 +27,31 @@ def test_conv(be, cfg):
     K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
 
 
+@pytest.fixture
+def throughput_mode(be):
+    """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas)."""
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    yield
+    be.lib.dyb_set_option(b"rep_split", 0)
+    be.lib.dyb_set_option(b"tp_min", 8)
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, K, R, stride, pad          tile forms of igemm_tp_kernel reached (fwd / dgrad / wgrad)
+    (1, 12, 12, 128, 128, 1, 1, 0),    # 128x128 everywhere, ragged M = 144
+    (1, 7, 7, 128, 256, 3, 1, 1),      # M = 49: 64x256 (fwd, dgrad); wgrad 128x128 with a 49-pixel reduction (ragged K-step)
+    (2, 10, 10, 64, 64, 3, 2, 1),      # Cout = 64: 256x64 forms, stride 2, batch 2, split-K
+    (1, 8, 8, 128, 64, 1, 2, 0),       # 1x1 stride 2 (downsample)
+    (1, 20, 20, 4, 64, 7, 2, 3),       # stem: forward stays on the 64x64 kernel (Cin = 4), weight gradient takes the 256x64 form
+])
+def test_conv_throughput_kernel(be, throughput_mode, cfg):
+    """igemm_tp_kernel (the 128x128-class tiles the throughput schedule runs) through the plain entry points: forward,
+    data gradient (+ residual addend) and weight gradient against torch's convolution."""
+    N, H, W, C, Kc, R, st, pad = cfg
+    K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
+
+
 @pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True, 1), (2, 30, 128, 1, False, 3), (1, 12, 2048, 0, False, 1),
                                  (1, 300, 64, 1, True, 2)])
 def test_groupnorm(be, cfg):

@@ -38,6 +38,30 @@ def test_conv_batch8(be, shape):
     K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
 
 
+@pytest.fixture
+def throughput_mode(be):
+    """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas)."""
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    yield
+    be.lib.dyb_set_option(b"rep_split", 0)
+    be.lib.dyb_set_option(b"tp_min", 8)
+
+
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_throughput_kernel_all_resnet_shapes(be, throughput_mode, shape):
+    """igemm_tp_kernel (128x128 / 64x256 / 256x64 tiles, XCD-contiguous workgroup order) on every ResNet-50 conv shape:
+    forward, data gradient (+ addend), weight gradient against torch's convolution."""
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc, c_real=3 if C == 4 else None)
+
+
+@pytest.mark.parametrize("shape", [(56, 56, 64, 64, 3, 1, 1), (28, 28, 512, 1024, 1, 2, 0), (7, 7, 512, 512, 3, 1, 1)])
+def test_conv_throughput_kernel_batch8(be, throughput_mode, shape):
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
+
+
 @pytest.mark.parametrize("cfg", [(1, 12544, 64, 1, False, 1), (1, 3136, 256, 1, True, 1), (1, 784, 512, 1, True, 2),
                                  (1, 196, 1024, 0, False, 5), (1, 49, 2048, 1, True, 16), (8, 196, 256, 1, False, 1),
                                  (2, 49, 512, 1, False, 9)])
