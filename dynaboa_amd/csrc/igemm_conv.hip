@@ -60,6 +60,7 @@ struct IgemmArgs {
   int M, Ncols, Kdim;    // GEMM sizes for this mode
   int ktiles, tiles_per_split, nsplit;
   int xcd;               // throughput form: XCD-contiguous workgroup order
+  int cls_tile0[4];      // throughput data gradient: first tile (grid x) of each phase class (stride 2)
   unsigned long long* probe;   // throughput form: per-wave phase clocks (dyb_conv_probe_set), normally NULL
 };
 
@@ -1315,12 +1316,31 @@ static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
 static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, const float* addend, void* ws, size_t ws_bytes,
                         int* raw_slabs_out, hipStream_t st, const GnFwdFuse* nfuse) {
   const DybRep& R = dyb_rep_current();
-  // tile form: 128x128, or one 64-slab along the short side
-  const int form = g.Ncols <= 64 ? 2 : (g.M <= 64 ? 1 : 0);
+  // tile form: 128x128, or one 64-slab along the short side.  A stride-2 data gradient enumerates its rows by phase class
+  // ((h+pad)&1, (w+pad)&1) - tiles never mix classes, each class loops over its own taps - so the row count that matters is
+  // a class's
+  const bool classes = mode == MODE_DGRAD && d.stride == 2;
+  const int rows_form = classes ? d.N * ((d.H + 1) >> 1) * ((d.W + 1) >> 1) : g.M;
+  const int form = g.Ncols <= 64 ? 2 : (rows_form <= 64 ? 1 : 0);
   const int TM = form == 0 ? 128 : form == 1 ? 64 : 256, TN = form == 0 ? 128 : form == 1 ? 256 : 64;
   g.ktiles = dyb_cdiv(g.Kdim, TPK);
   g.xcd = switches().tp_xcd.load(std::memory_order_relaxed);
-  const long tiles = (long)dyb_cdiv(g.M, TM) * dyb_cdiv(g.Ncols, TN) * R.n;
+  int mtiles = dyb_cdiv(g.M, TM), work_mtiles = mtiles;
+  g.cls_tile0[0] = g.cls_tile0[1] = g.cls_tile0[2] = g.cls_tile0[3] = 0;
+  if (classes) {
+    mtiles = work_mtiles = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int h0 = ((c >> 1) + d.pad) & 1, w0 = ((c & 1) + d.pad) & 1;
+      const int rows = d.N * ((d.H - h0 + 1) >> 1) * ((d.W - w0 + 1) >> 1);
+      DYB_REQUIRE(rows < (1 << 20) && d.H <= 1024 && d.W <= 1024, DYB_ERR_UNSUPPORTED);
+      g.cls_tile0[c] = mtiles;
+      mtiles += dyb_cdiv(rows, TM);
+      const bool has_taps = ((d.R - (c >> 1) + 1) >> 1) > 0 && ((d.S - (c & 1) + 1) >> 1) > 0;
+      if (has_taps) work_mtiles += dyb_cdiv(rows, TM);                 // a class without taps only writes zeros (+ addend)
+    }
+    g.ktiles = ((d.R + 1) >> 1) * ((d.S + 1) >> 1) * (d.K / TPK);      // the deepest class (split policy)
+  }
+  const long tiles = (long)work_mtiles * dyb_cdiv(g.Ncols, TN) * R.n;
   int s = (int)(switches().tp_grid.load(std::memory_order_relaxed) / tiles);
   const int maxs = g.ktiles / 4 > 0 ? g.ktiles / 4 : 1;                 // every split keeps >= 4 K-steps
   if (s > maxs) s = maxs;
@@ -1334,7 +1354,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   const bool split = g.nsplit > 1;
   g.out = split ? reinterpret_cast<float*>(ws) : out;
   g.addend = split ? nullptr : addend;
-  dim3 grid(dyb_cdiv(g.M, TM), dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
+  dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.probe = nullptr;
   if (g_probe.buf && g_probe.mode == mode && g_probe.H == d.H && g_probe.C == d.C && g_probe.K == d.K && g_probe.R == d.R &&
       (long)grid.x * grid.y * grid.z <= g_probe.cap_wgs)
