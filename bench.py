@@ -310,11 +310,11 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
-    ap.add_argument("--seqs", type=int, default=16,
+    ap.add_argument("--seqs", type=int, default=32,
                     help="independent sequences per GPU in the timed run (each with its own weights / Adam state / records, batch "
                          "--batch each), stepped in lockstep by one chain of launches (the throughput configuration; second-order / full-loss runs use 1); "
                          "1 = the single-sequence latency configuration")
-    ap.add_argument("--replicas", type=str, default="1,2,4,8,16",
+    ap.add_argument("--replicas", type=str, default="1,4,16",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--probe", type=str, default="", help="mode,H,C,K,R: phase clocks of the throughput conv kernel for that layer (diagnostic)")
@@ -452,9 +452,10 @@ def main():
                                "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": tr["bytes"] if tr else None,
                                "traffic_note": tr["note"] if tr else "no PMC summary under profiles/",
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-                               "kernel": "igemm_mfma_kernel<fwd|dgrad|wgrad, +/- GroupNorm loaders> + igemm_k4_{fwd,dgrad}_kernel: every conv "
-                                         "launch of the adaptation chain (main + weight-gradient streams; a launch covers all sequences "
-                                         "of the step), timed on its own dispatch inside the path",
+                               "kernel": "the convolution family - igemm_tp_kernel<fwd|dgrad|wgrad> (throughput form: launches covering >= 8 sequences), "
+                                         "igemm_mfma_kernel / igemm_k4_* (latency form): every conv launch of the adaptation chain (main + "
+                                         "weight-gradient streams; a launch covers all sequences of the step), timed on its own dispatch "
+                                         "inside the path",
                                "sample_steps": r["sample_frames"], "sample_frames": fr,
                                "avg_launch_us": r["avg_launch_us"], "launches_per_step": r["launches_per_frame"],
                                "conv_ms_per_step": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"] / seqs,

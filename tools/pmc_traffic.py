@@ -14,18 +14,19 @@ ARENA_BYTES = 26_977_504 * 4          # SURVEY 8a row 1, padded spans included (
 
 
 def fam(name):
-    return name.startswith("igemm_mfma_kernel") or name.startswith("igemm_k4_") or name.startswith("igemm_bf16")
+    return name.startswith("igemm_mfma_kernel") or name.startswith("igemm_k4_") or name.startswith("igemm_tp_kernel")
 
 
-def main(fetch_json, write_json, commit, out):
+def main(fetch_json, write_json, commit, out, seqs=1):
+    seqs = int(seqs)                      # sequences per launch of the profiled command: the streaming kernels move seqs arenas
     F, W = json.load(open(fetch_json))["kernels"], json.load(open(write_json))["kernels"]
     cal = {}
     for k, (nr, nw) in dict(fastweight_kernel=(2, 1), adam_kernel=(4, 3)).items():
         f = next((v for n, v in F.items() if n.startswith(k)), None)
         w = next((v for n, v in W.items() if n.startswith(k)), None)
         if f and w:
-            cal[k] = dict(read_bytes_true=nr * ARENA_BYTES, fetch_kib=f["per_launch"], fetch_ratio=f["per_launch"] * 1024 / (nr * ARENA_BYTES),
-                          write_bytes_true=nw * ARENA_BYTES, write_kib=w["per_launch"], write_ratio=w["per_launch"] * 1024 / (nw * ARENA_BYTES))
+            cal[k] = dict(read_bytes_true=nr * ARENA_BYTES * seqs, fetch_kib=f["per_launch"], fetch_ratio=f["per_launch"] * 1024 / (nr * ARENA_BYTES * seqs),
+                          write_bytes_true=nw * ARENA_BYTES * seqs, write_kib=w["per_launch"], write_ratio=w["per_launch"] * 1024 / (nw * ARENA_BYTES * seqs))
     per, n, rd, wr = {}, 0, 0.0, 0.0
     for name, f in F.items():
         if not fam(name):
@@ -36,9 +37,9 @@ def main(fetch_json, write_json, commit, out):
         rd += f["total"] * 1024 * 2
         wr += w.get("total", w["per_launch"] * f["launches"]) * 1024
     res = dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) on "
-                      "`bench.py --steps 3 --warmup 1 --overlap 0 --no_roofline --no_sub_records --no_cpu_baseline`",
+                      "`bench.py --seqs %d --steps 2 --warmup 1 --no_roofline --no_sub_records --no_cpu_baseline --percentile_frames 0`" % seqs,
                commit=commit, calibration=cal,
-               kernel="every conv instantiation on the path (igemm_mfma_kernel<...>, igemm_k4_fwd_kernel, igemm_k4_dgrad_kernel)",
+               kernel="every conv instantiation on the path (igemm_tp_kernel<...>, igemm_mfma_kernel<...>, igemm_k4_fwd_kernel, igemm_k4_dgrad_kernel)",
                launches=n, hbm_read_bytes_per_launch=rd / max(n, 1), hbm_write_bytes_per_launch=wr / max(n, 1),
                hbm_bytes_per_launch=(rd + wr) / max(n, 1), per_variant=per)
     json.dump(res, open(out, "w"), indent=1)
@@ -47,4 +48,4 @@ def main(fetch_json, write_json, commit, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
