@@ -167,9 +167,10 @@ class Runner:
     and its own frames, the native stepper issues ONE chain of launches per step covering all of them (per-sequence
     results bit-identical to running alone, tests)."""
 
-    def __init__(self, device, seqs, batch, inner_step, nframes, rank=0, frame_base=0, **kw):
+    def __init__(self, device, seqs, batch, inner_step, nframes, rank=0, frame_base=0, groups=1, **kw):
         from dynaboa_amd import assets
         self.S, self.batch, self.device = seqs, batch, device
+        self.G = groups if (seqs > 1 and groups > 1 and seqs % groups == 0) else 1
         mk = lambda r, s: {k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + r * 7_000 + frame_base + s, batch, seed=22).items()}
         self.frames = [[mk(r, s) for s in range(nframes)] for r in range(seqs)]      # resident in HBM before any clock starts
         if seqs == 1:
@@ -186,7 +187,12 @@ class Runner:
             # rounding (test_replica_group_with_replica_aware_split); with rep_split = 0 they are bit-identical
             _lib.load().dyb_set_option(b"rep_split", 1)
             self.ads = [build_adaptor(device, batch, inner_step, **kw) for _ in range(seqs)]
-            self.grp = NS.ReplicaGroup(self.ads, nframes)
+            per = seqs // self.G
+            # G > 1: the sequences form G lockstep groups, each with its own stepper, issuing thread and stream, free-running
+            # against each other - one group's streaming phases (GroupNorm backward, optimiser) overlap another's convolutions
+            self.grps = [NS.ReplicaGroup(self.ads[g * per:(g + 1) * per], nframes) for g in range(self.G)]
+            self.grp = self.grps[0]
+            self.gstreams = [torch.cuda.Stream(device=device) for _ in range(self.G)] if self.G > 1 else None
             self.ad = self.ads[0]
 
     def step(self, s):
@@ -199,9 +205,43 @@ class Runner:
         else:
             self.grp.step([self.frames[r][s] for r in range(self.S)], s)
 
+    def run_range(self, lo, hi, evs=None):
+        """G > 1: every group walks steps [lo, hi) from its own host thread on its own stream; returns when all have issued,
+        with the caller's current stream made to wait for them.  evs: group 0 records an event after each of its steps."""
+        import threading
+        per = self.S // self.G
+        errs = []
+
+        def work(g):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.gstreams[g]):
+                    for s in range(lo, hi):
+                        self.grps[g].step([self.frames[r][s] for r in range(g * per, (g + 1) * per)], s)
+                        if evs is not None and g == 0:
+                            e = torch.cuda.Event(enable_timing=True)
+                            e.record(self.gstreams[g])
+                            evs.append(e)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        cur = torch.cuda.current_stream(self.device)
+        for gs in self.gstreams:
+            gs.wait_stream(cur)
+        th = [threading.Thread(target=work, args=(g,)) for g in range(self.G)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        for gs in self.gstreams:
+            cur.wait_stream(gs)
+
     def flush(self):
         """-> list of per-sequence metric dicts"""
-        return [self.ad.flush_metrics()] if self.grp is None else self.grp.flush_metrics()
+        if self.grp is None:
+            return [self.ad.flush_metrics()]
+        return [m for g in self.grps for m in g.flush_metrics()]
 
     def native(self):
         return all(a._native is not None for a in ([self.ad] if self.grp is None else self.ads))
@@ -213,6 +253,8 @@ def timed_stream(runner, warmup, steps, stream, dist=None, per_frame=False):
     reference performs inside every inference() - are INSIDE the clock.  per_frame: a HIP event after every step on the
     issuing stream gives the per-step completion intervals (p50 / p99)."""
     def run(lo, hi, evs=None):
+        if getattr(runner, "G", 1) > 1:
+            return runner.run_range(lo, hi, evs)
         for s in range(lo, hi):
             runner.step(s)
             if evs is not None:
@@ -314,6 +356,8 @@ def main():
                     help="independent sequences per GPU in the timed run (each with its own weights / Adam state / records, batch "
                          "--batch each), stepped in lockstep by one chain of launches (the throughput configuration; second-order / full-loss runs use 1); "
                          "1 = the single-sequence latency configuration")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the --seqs sequences into this many lockstep groups, each issued by its own host thread on its own stream")
     ap.add_argument("--replicas", type=str, default="1,4,16",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
@@ -355,7 +399,7 @@ def main():
     n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
     nfr = total + n_roof + n_pct
-    rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, full_losses=args.full_losses,
+    rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, groups=args.groups, full_losses=args.full_losses,
                 second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule)
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
@@ -431,7 +475,7 @@ def main():
                                        args.schedule, fwd_ref, fwd_pf, args.inner_step + 1,
                                        " (forwards the reference repeats with identical weights and input are shared - bit-identical results)"
                                        if fwd_pf != fwd_ref else "", rn.native()),
-                          "sequences_per_gpu": seqs, "global_batch": args.batch * seqs * world,
+                          "sequences_per_gpu": seqs, "lockstep_groups": getattr(rn, "G", 1), "global_batch": args.batch * seqs * world,
                           "parallelism": f"replicas{world} x {seqs} sequences (stream sharded by sequence)",
                           "per_gpu_frames_per_s": value / world,
                           "pa_mpjpe_mm_synthetic_mean": pa_mean(metrics),
