@@ -52,6 +52,48 @@ def test_conv_throughput_kernel(be, throughput_mode, cfg):
     K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
 
 
+@pytest.mark.parametrize("tp_grid", [512, 8])
+@pytest.mark.parametrize("cfg", [
+    (1, 14, 14, 64, 128, 1, 2, 0),     # 1x1 stride 2: one phase class has the tap, three write zeros (+ addend); class rows 49 -> 64x256 form
+    (1, 14, 14, 64, 128, 3, 2, 1),     # 3x3 stride 2: classes with 4 / 2 / 2 / 1 taps
+    (3, 14, 14, 32, 64, 3, 2, 1),      # batch 3, Cin 32 (256x64 form for the data gradient)
+    (1, 9, 9, 16, 32, 3, 2, 1),        # odd size: classes of unequal row counts
+    (1, 16, 12, 16, 16, 3, 2, 1),      # H != W
+])
+def test_conv_throughput_data_gradient_by_phase_class(be, throughput_mode, cfg, tp_grid):
+    """Stride-2 data gradient of igemm_tp_kernel: rows enumerated by ((h+pad)&1, (w+pad)&1) class, each class's K loop over its
+    own taps; with a deep split (tp_grid 512 on these small shapes) and without one (8)."""
+    be.lib.dyb_set_option(b"tp_grid", tp_grid)
+    try:
+        K.case_conv(be, *cfg, seed=7)
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+
+
+def test_conv_timing_table_and_probe(be, throughput_mode):
+    """Measurement aids: the per-shape table of a timing scope names the throughput kernel's launches; the phase probe writes
+    one record per wave of the matching launch (clocks are 0 on the emulator; the K-step count is real)."""
+    import ctypes
+    assert be.lib.dyb_conv_timing_begin(64) == 0
+    probe = be.dev(np.zeros(64 * 4 * 8 * 2, np.float32))      # 64 workgroups x 4 waves x 8 64-bit words
+    be.lib.dyb_conv_probe_set(be.ptr(probe), 64, 0, 12, 128, 128, 1)
+    try:
+        K.case_conv(be, 1, 12, 12, 128, 128, 1, 1, 0, seed=3)
+    finally:
+        be.lib.dyb_conv_probe_set(None, 0, 0, 0, 0, 0, 0)
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+        assert be.lib.dyb_conv_timing_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)) == 0
+    assert n.value == 3 and fl.value > 0
+    need = be.lib.dyb_conv_timing_table(None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    be.lib.dyb_conv_timing_table(buf, need)
+    kinds = sorted(line.split(",")[0] for line in buf.value.decode().strip().splitlines()[1:])
+    assert kinds == ["t", "u", "v"], kinds
+    rec = be.host(probe).view(np.uint64).reshape(64, 4, 8)
+    used = rec[rec[:, 0, 6] != 0]
+    assert len(used) >= 1 and (used[..., 6] == used[0, 0, 6]).all()
+
+
 @pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True, 1), (2, 30, 128, 1, False, 3), (1, 12, 2048, 0, False, 1),
                                  (1, 300, 64, 1, True, 2)])
 def test_groupnorm(be, cfg):

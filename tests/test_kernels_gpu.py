@@ -62,6 +62,20 @@ def test_conv_throughput_kernel_batch8(be, throughput_mode, shape):
     K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
 
 
+@pytest.mark.parametrize("tp_grid", [16, 4096])
+@pytest.mark.parametrize("shape", [(56, 56, 128, 128, 3, 2, 1), (14, 14, 1024, 2048, 1, 2, 0), (14, 14, 512, 512, 3, 2, 1),
+                                   (14, 14, 256, 256, 3, 1, 1)])
+def test_conv_throughput_kernel_split_policies(be, throughput_mode, shape, tp_grid):
+    """The throughput kernel without a split (tp_grid 16) and with the deepest one the policy allows (4096), incl. the
+    stride-2 data gradients by phase class (classes of 4 / 2 / 2 / 1 taps share one split depth)."""
+    H, W, C, Kc, R, st, pad = shape
+    be.lib.dyb_set_option(b"tp_grid", tp_grid)
+    try:
+        K.case_conv(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc + tp_grid)
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+
+
 @pytest.mark.parametrize("cfg", [(1, 12544, 64, 1, False, 1), (1, 3136, 256, 1, True, 1), (1, 784, 512, 1, True, 2),
                                  (1, 196, 1024, 0, False, 5), (1, 49, 2048, 1, True, 16), (8, 196, 256, 1, False, 1),
                                  (2, 49, 512, 1, False, 9)])
