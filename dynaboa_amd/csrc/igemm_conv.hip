@@ -1291,10 +1291,20 @@ static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, 
 // staging them, cycles at the barrier, K-steps, replica) - s_memtime stamps taken by lane 0.  Later matching launches overwrite.
 struct TpProbe { unsigned long long* buf; long cap_wgs; int mode, H, C, K, R; };
 static TpProbe g_probe = {nullptr, 0, 0, 0, 0, 0, 0};
+static std::atomic<bool> g_probe_on{false};           // unlocked fast path of the launch wrapper
 extern "C" int dyb_conv_probe_set(void* buf, long cap_wgs, int mode, int H, int C, int K, int R) {
   std::lock_guard<std::mutex> lock(g_timing_mu);
+  g_probe_on.store(false);
   g_probe = TpProbe{reinterpret_cast<unsigned long long*>(buf), cap_wgs, mode, H, C, K, R};
+  g_probe_on.store(buf != nullptr);
   return DYB_OK;
+}
+// the probe buffer for a launch of `grid` workgroups of this layer, or NULL
+static unsigned long long* probe_for(int mode, const ConvDesc& d, long wgs) {
+  if (!g_probe_on.load(std::memory_order_acquire)) return nullptr;
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  const TpProbe& p = g_probe;
+  return (p.buf && p.mode == mode && p.H == d.H && p.C == d.C && p.K == d.K && p.R == d.R && wgs <= p.cap_wgs) ? p.buf : nullptr;
 }
 
 #include "igemm_tp.inc"
@@ -1355,10 +1365,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.out = split ? reinterpret_cast<float*>(ws) : out;
   g.addend = split ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
-  g.probe = nullptr;
-  if (g_probe.buf && g_probe.mode == mode && g_probe.H == d.H && g_probe.C == d.C && g_probe.K == d.K && g_probe.R == d.R &&
-      (long)grid.x * grid.y * grid.z <= g_probe.cap_wgs)
-    g.probe = g_probe.buf;
+  g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   GnFwdFuse nf{};
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
