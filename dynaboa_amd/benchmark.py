@@ -242,7 +242,7 @@ class Adaptor(BaseAdaptor):
         if self._native_why is None:
             from . import native_step as NS
             if getattr(self.options, "native_step", 1):
-                why = None if NS.mode(self.options, self.bundle is not None) else NS.reason
+                why = NS.coverage(self.options, self.bundle is not None)[1]
             else:
                 why = "native_step=0"
             self._native_why = why or ""

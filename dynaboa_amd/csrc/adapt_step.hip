@@ -5,9 +5,9 @@
 // Adam.step, inference - issued from C++ over the engine (hmr_engine.hip), the SMPL kernels (smpl_lbs.hip), the loss
 // head (losses.hip) and the flat-arena updates (optim.hip).  The Python Adaptor (dynaboa_amd/benchmark.py) stays the
 // surface; in the configurations this file covers it forwards a frame here instead of walking the same ~1700 launches
-// through torch.autograd + ctypes (9 ms of host time per frame there, ~2.5 us per launch here), which is also what
-// lets several independent sequence replicas share one GPU from separate host threads (dyb_stepper_* are re-entrant
-// per stepper: every stepper owns its workspace, events and streams' ordering).
+// through torch.autograd + ctypes (9 ms of host time per frame there, ~2.5 us per launch here).  One stepper can also
+// advance up to DYB_MAX_REPLICAS independent sequences in lockstep ("replicas", dyb_common.h): every launch of the chain
+// then covers all of them.  dyb_stepper_* are re-entrant per stepper (own workspace, events, stream ordering).
 //
 // Same kernels, same order, same operands as the Python path => identical weights / Adam state (tests assert
 // bit-equality); the metric reductions (MPJPE / PVE means) are this file's own kernels and agree to rounding.

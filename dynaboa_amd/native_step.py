@@ -17,48 +17,45 @@ from ._abi import check
 from .hmr import get_layout, stream_of
 
 
-def mode(o, have_bundle: bool = True) -> str:
-    """'frame' (first order, frame-loss set), 'full' (the reference's term set: teacher / motion / labelled exemplars /
-    dynamic loop) or '' with `reason` set when the stepper does not cover these options."""
+def coverage(o, have_bundle: bool = True):
+    """-> (mode, reason): mode 'frame' (first order, frame-loss set), 'full' (the reference's term set: teacher / motion /
+    labelled exemplars / dynamic loop) or '' with `reason` saying why the stepper does not cover these options."""
     g = lambda k, d=0: getattr(o, k, d)
-    global reason
-    reason = None
     if not g("use_boa", 1):
-        reason = "use_boa=0"
-    elif g("second_order"):
-        reason = "second order"
-    elif not (g("use_frame_losses_lower", 1) and g("use_frame_losses_upper", 1)):
-        reason = "frame losses switched off"
-    elif g("dump_predictions"):
-        reason = "prediction dumps"
-    elif not g("share_forwards", 1) or not g("fused_level", 1):
-        reason = "unshared / unfused schedule requested"
-    if reason:
-        return ""
+        return "", "use_boa=0"
+    if g("second_order"):
+        return "", "second order"
+    if not (g("use_frame_losses_lower", 1) and g("use_frame_losses_upper", 1)):
+        return "", "frame losses switched off"
+    if g("dump_predictions"):
+        return "", "prediction dumps"
+    if not g("share_forwards", 1) or not g("fused_level", 1):
+        return "", "unshared / unfused schedule requested"
     temporal = (g("use_temporal_losses_lower") or g("use_temporal_losses_upper")) and (g("use_meanteacher") or g("use_motion"))
     mix = g("lower_level_mixtrain") or g("upper_level_mixtrain")
     if not (temporal or mix or g("dynamic_boa") or g("use_meanteacher")):
-        return "frame"
+        return "frame", None
     B = int(g("batch_size", 1))
     if B > 16:
-        reason = "full term set natively needs batch <= 16"
-    elif mix and not g("retrieval"):
-        reason = "labelled term without retrieval"
-    elif mix and int(g("sample_num", 1)) != B:
-        reason = "sample_num != batch_size"
-    elif mix and not have_bundle and B != 1:
-        reason = "feature-driven retrieval is batch 1"
-    elif g("teacher_dropout"):
-        reason = "train-mode teacher"
-    return "" if reason else "full"
+        return "", "full term set natively needs batch <= 16"
+    if mix and not g("retrieval"):
+        return "", "labelled term without retrieval"
+    if mix and int(g("sample_num", 1)) != B:
+        return "", "sample_num != batch_size"
+    if mix and not have_bundle and B != 1:
+        return "", "feature-driven retrieval is batch 1"
+    if g("teacher_dropout"):
+        return "", "train-mode teacher"
+    return "full", None
 
 
-reason = None
+def mode(o, have_bundle: bool = True) -> str:
+    return coverage(o, have_bundle)[0]
 
 
 def supported(o) -> Optional[str]:
     """None if the stepper covers these options, else the reason it does not."""
-    return None if mode(o) else reason
+    return coverage(o)[1]
 
 
 class NativeStepper:

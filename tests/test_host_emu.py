@@ -225,7 +225,7 @@ def test_native_stepper_coverage_rules(emu_lib):
     assert NS.supported(DB.frame_only_options(share_forwards=0)) is not None
     o = DB.parser.parse_args([])
     o.batch_size = 32
-    assert NS.mode(o) == "" and "batch" in NS.reason
+    assert NS.mode(o) == "" and "batch" in NS.supported(o)
     o = DB.parser.parse_args([])
     o.teacher_dropout = 1
     assert NS.mode(o) == ""                                                       # train-mode teacher: the autograd composition
