@@ -1,0 +1,267 @@
+// Tangent (forward-mode) kernels for the exact Hessian-vector product of the second-order path.
+//
+// Second-order MAML (reference base_adaptor.py:119 with first_order=False) needs H v = d/de grad L(theta + e v)
+// per inner step.  Convolutions, linears, average pooling and the fixed-index max-pool are (bi)linear, so their tangents reuse
+// the first-order kernels on tangent operands; what is left is GroupNorm(+ReLU, +residual) - forward tangent and the tangent
+// of its backward - and the max-pool gather.  These are those kernels; hvp_engine.inc walks the network with them.
+//
+// One workgroup per (image, group) sweeps its HW x C/4 slab twice (sums, then outputs): the second-order path is a
+// verification-grade mode, not the throughput path, and the slab is L2-hot on the second sweep.
+#include "dyb_common.h"
+
+#define G DYB_GN_GROUPS
+
+// block-wide sums of K doubles (256 threads); result in every thread
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* s_red) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double x = v[k];
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+    if (lane == 0) s_red[wave * K + k] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = (s_red[k] + s_red[K + k]) + (s_red[2 * K + k] + s_red[3 * K + k]);
+  __syncthreads();
+}
+
+// out = relu?(gamma * xhat + beta + res), tangent tout = mask * (tgamma * xhat + gamma * txhat + tbeta + tres) with
+// xhat = (y - mu) r, txhat = r (ty - tmu - xhat a), tmu = mean(ty), a = mean(xhat ty) over the group; (tmu, a) saved for the
+// backward tangent.  grid (G, N), block 256.
+__global__ __launch_bounds__(256) void gn_jvp_fwd_kernel(const float* __restrict__ y, const float* __restrict__ ty,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ tgamma,
+                                                         const float* __restrict__ tbeta, const float* __restrict__ res,
+                                                         const float* __restrict__ tres, float* __restrict__ out,
+                                                         float* __restrict__ tout, float* __restrict__ tstats, int HW, int C,
+                                                         int relu) {
+  __shared__ double s_red[4 * 2];
+  const int g = blockIdx.x, n = blockIdx.y, Cg = C / G, cq = Cg >> 2;
+  const float mu = stats[((size_t)n * G + g) * 2], r = stats[((size_t)n * G + g) * 2 + 1];
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
+  const int total = HW * cq;
+  double acc[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const size_t off = base + (size_t)(i / cq) * C + (size_t)(i % cq) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
+    acc[0] += (double)t.x + (double)t.y + (double)t.z + (double)t.w;
+    acc[1] += (double)((v.x - mu) * r) * t.x + (double)((v.y - mu) * r) * t.y + (double)((v.z - mu) * r) * t.z +
+              (double)((v.w - mu) * r) * t.w;
+  }
+  block_sum<2>(acc, s_red);
+  const double cnt = (double)HW * (double)Cg;
+  const float tmu = (float)(acc[0] / cnt), a = (float)(acc[1] / cnt);
+  if (threadIdx.x == 0 && tstats) {
+    tstats[((size_t)n * G + g) * 2] = tmu;
+    tstats[((size_t)n * G + g) * 2 + 1] = a;
+  }
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int c = g * Cg + (i % cq) * 4;
+    const size_t off = base + (size_t)(i / cq) * C + (size_t)(i % cq) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    const float4 tg = *reinterpret_cast<const float4*>(tgamma + c), tb = *reinterpret_cast<const float4*>(tbeta + c);
+    float vv[4] = {v.x, v.y, v.z, v.w}, tt[4] = {t.x, t.y, t.z, t.w};
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    const float tgg[4] = {tg.x, tg.y, tg.z, tg.w}, tbb[4] = {tb.x, tb.y, tb.z, tb.w};
+    float rr[4] = {0.f, 0.f, 0.f, 0.f}, trr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {
+      const float4 q = *reinterpret_cast<const float4*>(res + off);
+      rr[0] = q.x; rr[1] = q.y; rr[2] = q.z; rr[3] = q.w;
+    }
+    if (tres) {
+      const float4 q = *reinterpret_cast<const float4*>(tres + off);
+      trr[0] = q.x; trr[1] = q.y; trr[2] = q.z; trr[3] = q.w;
+    }
+    float o[4], to[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (vv[k] - mu) * r;
+      const float txh = r * (tt[k] - tmu - xh * a);
+      o[k] = fmaf(xh, gg[k], bb[k]) + rr[k];
+      to[k] = tgg[k] * xh + gg[k] * txh + tbb[k] + trr[k];
+      if (relu) {
+        const bool on = o[k] > 0.f;
+        o[k] = on ? o[k] : 0.f;
+        to[k] = on ? to[k] : 0.f;
+      }
+    }
+    if (out) *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(tout + off) = make_float4(to[0], to[1], to[2], to[3]);
+  }
+}
+
+// Backward of the same layer and its tangent.  dm = mask * dout, tdm = mask * tdout (mask = out_mask > 0 when relu);
+// dxh = gamma dm, c1 = mean(dxh), c2 = mean(dxh xhat), dy = r (dxh - c1 - xhat c2);
+// tdxh = tgamma dm + gamma tdm, tc1 = mean(tdxh), tc2 = mean(tdxh xhat + dxh txhat), tr = -r^2 a,
+// tdy = tr (dxh - c1 - xhat c2) + r (tdxh - tc1 - txhat c2 - xhat tc2);
+// per image and channel: tdgb[n][0][c] = sum_p tdm (tangent of dbeta), tdgb[n][1][c] = sum_p (tdm xhat + dm txhat) (of dgamma).
+// grid (G, N), block 256.
+__global__ __launch_bounds__(256) void gn_jvp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ tdout,
+                                                         const float* __restrict__ out_mask, const float* __restrict__ y,
+                                                         const float* __restrict__ ty, const float* __restrict__ stats,
+                                                         const float* __restrict__ tstats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ tgamma, float* __restrict__ dm,
+                                                         float* __restrict__ tdm, float* __restrict__ dy, float* __restrict__ tdy,
+                                                         float* __restrict__ tdgb, int HW, int C, int relu) {
+  __shared__ double s_red[4 * 4];
+  __shared__ float s_ch[256][8];
+  const int g = blockIdx.x, n = blockIdx.y, Cg = C / G, cq = Cg >> 2;
+  const float mu = stats[((size_t)n * G + g) * 2], r = stats[((size_t)n * G + g) * 2 + 1];
+  const float tmu = tstats[((size_t)n * G + g) * 2], a = tstats[((size_t)n * G + g) * 2 + 1];
+  const float tr = -r * r * a;
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
+  const int total = HW * cq;
+  const int q = threadIdx.x % cq;                     // this thread's channel quad (cq divides 256)
+  const int c = g * Cg + q * 4;
+  const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c), tg4 = *reinterpret_cast<const float4*>(tgamma + c);
+  const float gg[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, tgg[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+  auto fetch = [&](size_t off, float (&d)[4], float (&td)[4], float (&xh)[4], float (&txh)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
+    const float4 d4 = *reinterpret_cast<const float4*>(dout + off), t4 = *reinterpret_cast<const float4*>(tdout + off);
+    const float vv[4] = {v.x, v.y, v.z, v.w}, tt[4] = {t.x, t.y, t.z, t.w};
+    d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+    td[0] = t4.x; td[1] = t4.y; td[2] = t4.z; td[3] = t4.w;
+    if (relu) {
+      const float4 m = *reinterpret_cast<const float4*>(out_mask + off);
+      const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(mm[k] > 0.f)) { d[k] = 0.f; td[k] = 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xh[k] = (vv[k] - mu) * r;
+      txh[k] = r * (tt[k] - tmu - xh[k] * a);
+    }
+  };
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  float chb[4] = {0.f, 0.f, 0.f, 0.f}, chg[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const size_t off = base + (size_t)(i / cq) * C + (size_t)q * 4;
+    float d[4], td[4], xh[4], txh[4];
+    fetch(off, d, td, xh, txh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dxh = gg[k] * d[k], tdxh = tgg[k] * d[k] + gg[k] * td[k];
+      acc[0] += (double)dxh;
+      acc[1] += (double)dxh * xh[k];
+      acc[2] += (double)tdxh;
+      acc[3] += (double)tdxh * xh[k] + (double)dxh * txh[k];
+      chb[k] += td[k];
+      chg[k] += td[k] * xh[k] + d[k] * txh[k];
+    }
+  }
+  block_sum<4>(acc, s_red);
+  const double cnt = (double)HW * (double)Cg;
+  const float c1 = (float)(acc[0] / cnt), c2 = (float)(acc[1] / cnt), tc1 = (float)(acc[2] / cnt), tc2 = (float)(acc[3] / cnt);
+  // per-channel sums: threads with the same channel quad sit 'cq' apart
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s_ch[threadIdx.x][k] = chb[k]; s_ch[threadIdx.x][4 + k] = chg[k]; }
+  __syncthreads();
+  if ((int)threadIdx.x < cq && tdgb) {
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < 256; j += cq)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sb[k] += s_ch[j][k]; sg[k] += s_ch[j][4 + k]; }
+    float* ob = tdgb + ((size_t)n * 2 + 0) * C + c;
+    float* og = tdgb + ((size_t)n * 2 + 1) * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ob[k] = sb[k]; og[k] = sg[k]; }
+  }
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const size_t off = base + (size_t)(i / cq) * C + (size_t)q * 4;
+    float d[4], td[4], xh[4], txh[4];
+    fetch(off, d, td, xh, txh);
+    float o[4], to[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dxh = gg[k] * d[k], tdxh = tgg[k] * d[k] + gg[k] * td[k];
+      const float core = dxh - c1 - xh[k] * c2;
+      o[k] = r * core;
+      to[k] = tr * core + r * (tdxh - tc1 - txh[k] * c2 - xh[k] * tc2);
+    }
+    if (dm) *reinterpret_cast<float4*>(dm + off) = make_float4(d[0], d[1], d[2], d[3]);
+    if (tdm) *reinterpret_cast<float4*>(tdm + off) = make_float4(td[0], td[1], td[2], td[3]);
+    *reinterpret_cast<float4*>(dy + off) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(tdy + off) = make_float4(to[0], to[1], to[2], to[3]);
+  }
+}
+
+// dst[c] (+)= sum_n src[n][row][c] for the two rows of a [N][2][C] block: dst_b from row 0, dst_g from row 1
+__global__ __launch_bounds__(256) void gn_jvp_colsum_kernel(const float* __restrict__ src, float* __restrict__ dst_b,
+                                                            float* __restrict__ dst_g, int N, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float sb = 0.f, sg = 0.f;
+  for (int n = 0; n < N; ++n) {
+    sb += src[((size_t)n * 2 + 0) * C + c];
+    sg += src[((size_t)n * 2 + 1) * C + c];
+  }
+  dst_b[c] = sb;
+  dst_g[c] = sg;
+}
+
+// tangent of MaxPool2d(3, 2, 1): ty[j] = tx[winning tap of j] (the tap index the forward stored, one byte per channel)
+__global__ __launch_bounds__(256) void maxpool_jvp_fwd_kernel(const float* __restrict__ tx, const uint32_t* __restrict__ idx,
+                                                              float* __restrict__ ty, int N, int H, int W, int C, int Ho, int Wo) {
+  const int CQ = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * CQ;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cq = (int)(i % CQ);
+    size_t t = i / CQ;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho), n = (int)(t / Ho);
+    const uint32_t id = idx[i];
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int tap = (int)((id >> (8 * k)) & 255u);
+      const int hi = ho * 2 - 1 + tap / 3, wi = wo * 2 - 1 + tap % 3;
+      o[k] = tx[(((size_t)n * H + hi) * W + wi) * C + (size_t)cq * 4 + k];
+    }
+    *reinterpret_cast<float4*>(ty + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int dyb_gn_jvp_fwd(const float* y, const float* ty, const float* stats, const float* gamma, const float* beta,
+                              const float* tgamma, const float* tbeta, const float* res, const float* tres, float* out, float* tout,
+                              float* tstats, int N, int HW, int C, int relu, hipStream_t st) {
+  DYB_REQUIRE(y && ty && stats && gamma && beta && tgamma && tbeta && tout, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && 256 % (C / G / 4) == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(gn_jvp_fwd_kernel, dim3(G, N), dim3(256), 0, st, y, ty, stats, gamma, beta, tgamma, tbeta, res, tres, out, tout,
+                     tstats, HW, C, relu);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// tdgb: scratch [N][2][C]; tdbeta / tdgamma [C] receive its sums over the batch
+extern "C" int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty,
+                              const float* stats, const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm,
+                              float* dy, float* tdy, float* tdgb, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu,
+                              hipStream_t st) {
+  DYB_REQUIRE(dout && tdout && y && ty && stats && tstats && gamma && tgamma && dy && tdy && tdgb && tdgamma && tdbeta, DYB_ERR_ARG);
+  DYB_REQUIRE(!relu || out_mask, DYB_ERR_ARG);
+  DYB_REQUIRE(C % 16 == 0 && 256 % (C / G / 4) == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(gn_jvp_bwd_kernel, dim3(G, N), dim3(256), 0, st, dout, tdout, out_mask, y, ty, stats, tstats, gamma, tgamma, dm,
+                     tdm, dy, tdy, tdgb, HW, C, relu);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_jvp_colsum_kernel, dim3(dyb_cdiv(C, 256)), dim3(256), 0, st, (const float*)tdgb, tdbeta, tdgamma, N, C);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_maxpool3x3s2_jvp(const float* tx, const uint32_t* idx, float* ty, int N, int H, int W, int C, hipStream_t st) {
+  DYB_REQUIRE(tx && idx && ty && C % 4 == 0, DYB_ERR_ARG);
+  DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_jvp_fwd_kernel, dim3(blocks), dim3(256), 0, st, tx, idx, ty, N, H, W, C, Ho, Wo);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}

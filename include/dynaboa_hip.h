@@ -115,6 +115,21 @@ size_t dyb_conv_timing_table(char* buf, size_t cap);
  * cap_wgs workgroups of room; layout in igemm_conv.hip).  bench.py --probe / tools/tp_probe.py read it.  buf = NULL clears. */
 int dyb_conv_probe_set(void* buf, long cap_wgs, int mode, int H, int C, int K, int R);
 
+/* ---- second-order building blocks (exact Hessian-vector products, hvp_kernels.hip / hvp_engine.inc) ----
+ * Tangent ("t" prefix = directional derivative along a parameter direction) of GroupNorm(4, C)(+ReLU)(+residual) and of its
+ * backward; NHWC [N][HW][C]; stats = the forward's [N][4][2] (mean, rstd); tstats [N][4][2] receives / supplies the tangent
+ * statistics.  out may be NULL.  dyb_gn_jvp_bwd: dout / tdout = gradient w.r.t. the layer's output and its tangent, out_mask =
+ * the primal output (ReLU mask, relu = 1); writes the masked gradients (dm, tdm; may be NULL), the gradient w.r.t. y and its
+ * tangent (dy, tdy) and the tangents of dgamma / dbeta ([C]); tdgb = scratch [N][2][C].  Not replica-aware. */
+int dyb_gn_jvp_fwd(const float* y, const float* ty, const float* stats, const float* gamma, const float* beta, const float* tgamma,
+                   const float* tbeta, const float* res, const float* tres, float* out, float* tout, float* tstats, int N, int HW,
+                   int C, int relu, dyb_stream_t stream);
+int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty, const float* stats,
+                   const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm, float* dy, float* tdy,
+                   float* tdgb, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu, dyb_stream_t stream);
+/* tangent of MaxPool2d(3,2,1): ty = tx gathered at the tap indices dyb_maxpool3x3s2_fwd stored */
+int dyb_maxpool3x3s2_jvp(const float* tx, const uint32_t* idx, float* ty, int N, int H, int W, int C, dyb_stream_t stream);
+
 /* One forward layer = conv + the GroupNorm statistics of its output (what the engine issues per layer): y and *nchunks
  * partial records [G][2] in `partials` (>= dyb_groupnorm_workspace_bytes(N, Ho*Wo, K) and >= 4*(Ho*Wo/32+1)*(K/32)*8
  * bytes).  part_prev != NULL: x is the producer's raw output, normalised in the loader from its nch_prev partials.

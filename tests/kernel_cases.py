@@ -926,3 +926,62 @@ def case_aux_terms(be, B=3, seed=91):
         assert max(e.values()) < 2e-4, (mode, e)
         res[mode] = e
     return res
+
+
+# ---------------------------------------------------------------------------------------- tangent (JVP) kernels
+def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
+    """dyb_gn_jvp_fwd / dyb_gn_jvp_bwd against torch (float64): forward tangent of relu?(GN(y) + res) along (ty, tgamma, tbeta,
+    tres), and the tangent of its backward (dy, dgamma, dbeta, dres) along the same direction plus tdout."""
+    rng = _rng(seed)
+    f32 = lambda *s: rng.standard_normal(s).astype(np.float32)
+    y, ty = f32(N, HW, C) * 1.5 + 0.3, f32(N, HW, C)
+    gamma, beta = (1 + 0.2 * f32(C)), 0.2 * f32(C)
+    tgamma, tbeta = f32(C), f32(C)
+    res, tres = (f32(N, HW, C), f32(N, HW, C)) if with_res else (None, None)
+    dout, tdout = f32(N, HW, C), f32(N, HW, C)
+    T = lambda a: torch.from_numpy(a).double()
+    to4 = lambda a: a.permute(0, 2, 1).reshape(N, C, HW, 1)
+    back = lambda a: a.reshape(N, C, HW).permute(0, 2, 1)
+
+    def fwd(yv, gv, bv, rv):
+        o = F.group_norm(to4(yv), 4, gv, bv, 1e-5)
+        if rv is not None:
+            o = o + to4(rv)
+        return back(F.relu(o) if relu else o)
+
+    prim = (T(y), T(gamma), T(beta)) + ((T(res),) if with_res else ())
+    tang = (T(ty), T(tgamma), T(tbeta)) + ((T(tres),) if with_res else ())
+    f = (lambda a, b, c, d: fwd(a, b, c, d)) if with_res else (lambda a, b, c: fwd(a, b, c, None))
+    out_ref, tout_ref = torch.autograd.functional.jvp(f, prim, tang)
+
+    def bwd(*args):            # (primal inputs..., dout) -> gradients w.r.t. the primal inputs
+        ins = [a.requires_grad_(True) for a in args[:-1]]
+        o = f(*ins)
+        return torch.autograd.grad(o, ins, args[-1], create_graph=True)
+
+    g_ref, tg_ref = torch.autograd.functional.jvp(lambda *a: bwd(*a), prim + (T(dout),), tang + (T(tdout),))
+
+    # forward statistics as the engine has them
+    yt = T(y).reshape(N, HW, 4, C // 4)
+    mean = yt.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(yt.var(dim=(1, 3), unbiased=False) + 1e-5)
+    stats = torch.stack([mean, rstd], -1).float().numpy()
+    Y, TY, ST = be.dev(y), be.dev(ty), be.dev(stats)
+    GA, BE_, TG, TB = be.dev(gamma), be.dev(beta), be.dev(tgamma), be.dev(tbeta)
+    RES, TRES = (be.dev(res), be.dev(tres)) if with_res else (None, None)
+    OUT, TOUT, TST = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, 4, 2))
+    check(be.lib.dyb_gn_jvp_fwd(be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(TG), be.ptr(TB),
+                                be.ptr(RES) if with_res else None, be.ptr(TRES) if with_res else None, be.ptr(OUT), be.ptr(TOUT),
+                                be.ptr(TST), N, HW, C, relu, be.stream), "gn jvp fwd")
+    e = dict(out=rel_err(be.host(OUT), out_ref.numpy()), tout=rel_err(be.host(TOUT), tout_ref.numpy()))
+    DM, TDM, DY, TDY = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C))
+    SCR, TDG, TDB = be.empty((N, 2, C)), be.empty((C,)), be.empty((C,))
+    check(be.lib.dyb_gn_jvp_bwd(be.ptr(be.dev(dout)), be.ptr(be.dev(tdout)), be.ptr(OUT), be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(TST),
+                                be.ptr(GA), be.ptr(TG), be.ptr(DM), be.ptr(TDM), be.ptr(DY), be.ptr(TDY), be.ptr(SCR), be.ptr(TDG),
+                                be.ptr(TDB), N, HW, C, relu, be.stream), "gn jvp bwd")
+    e.update(dy=rel_err(be.host(DY), g_ref[0].detach().numpy()), tdy=rel_err(be.host(TDY), tg_ref[0].numpy()),
+             tdgamma=rel_err(be.host(TDG), tg_ref[1].numpy()), tdbeta=rel_err(be.host(TDB), tg_ref[2].numpy()))
+    if with_res:
+        e.update(dres=rel_err(be.host(DM), g_ref[3].detach().numpy()), tdres=rel_err(be.host(TDM), tg_ref[3].numpy()))
+    assert max(e.values()) < 2e-4, e
+    return e
