@@ -930,3 +930,5 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   }
   return DYB_OK;
 }
+
+#include "hvp_engine.inc"

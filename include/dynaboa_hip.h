@@ -127,6 +127,18 @@ int dyb_gn_jvp_fwd(const float* y, const float* ty, const float* stats, const fl
 int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty, const float* stats,
                    const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm, float* dy, float* tdy,
                    float* tdgb, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu, dyb_stream_t stream);
+/* Exact Hessian-vector product through HMR, forward-over-reverse (hvp_engine.inc).  acts = the arena dyb_hmr_forward filled at
+ * (params, image); tparams = the direction v (parameter arena layout); dual = scratch of dyb_hmr_hvp_dual_floats floats shared by
+ * the two passes.  _jvp_forward leaves the tangent of the regressor's final state [B][160] at dual + dyb_hmr_hvp_offset_tstate;
+ * the caller differentiates the head (rot6d -> SMPL -> losses) along it; _jvp_backward takes the head's gradient w.r.t. that state
+ * (d_state, rot6d folded in) and its tangent (td_state) and writes hv = H v in the parameter arena layout (tensor spans only: zero
+ * hv first).  Eval mode, fp32, one sequence per call. */
+size_t dyb_hmr_hvp_dual_floats(const void* plan);
+long long dyb_hmr_hvp_offset_tstate(const void* plan);
+int dyb_hmr_jvp_forward(void* plan, const float* params, const float* tparams, const float* acts, float* dual, int n_iter, void* ws,
+                        size_t ws_bytes, dyb_stream_t stream);
+int dyb_hmr_jvp_backward(void* plan, const float* params, const float* tparams, const float* acts, float* dual, const float* d_state,
+                         const float* td_state, int n_iter, float* hv, void* ws, size_t ws_bytes, dyb_stream_t stream);
 /* tangent of MaxPool2d(3,2,1): ty = tx gathered at the tap indices dyb_maxpool3x3s2_fwd stored */
 int dyb_maxpool3x3s2_jvp(const float* tx, const uint32_t* idx, float* ty, int N, int H, int W, int C, dyb_stream_t stream);
 

@@ -64,7 +64,7 @@ def rot6d_to_rotmat(x: torch.Tensor) -> torch.Tensor:
 
 
 def hmr_forward(P: Params, x: torch.Tensor, need_feature: bool = False,
-                init_pose=None, init_shape=None, init_cam=None, n_iter: int = 3):
+                init_pose=None, init_shape=None, init_cam=None, n_iter: int = 3, return_pose6d: bool = False):
     """Functional HMR forward in eval mode (dropout = identity).  Returns
     (rotmat (B,24,3,3), shape (B,10), cam (B,3)[, 15 features])."""
     B = x.shape[0]
@@ -89,6 +89,8 @@ def hmr_forward(P: Params, x: torch.Tensor, need_feature: bool = False,
         pose = F.linear(h, P["decpose.weight"], P["decpose.bias"]) + pose
         shape = F.linear(h, P["decshape.weight"], P["decshape.bias"]) + shape
         cam = F.linear(h, P["deccam.weight"], P["deccam.bias"]) + cam
+    if return_pose6d:                 # the regressor's raw state (tests of the tangent / Hessian-vector passes)
+        return pose, shape, cam
     R = rot6d_to_rotmat(pose).view(B, 24, 3, 3)
     return (R, shape, cam, feats) if need_feature else (R, shape, cam)
 

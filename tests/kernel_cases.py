@@ -985,3 +985,76 @@ def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
         e.update(dres=rel_err(be.host(DM), g_ref[3].detach().numpy()), tdres=rel_err(be.host(TDM), tg_ref[3].numpy()))
     assert max(e.values()) < 2e-4, e
     return e
+
+
+def case_hmr_hvp(be, ckpt, seed=5):
+    """dyb_hmr_jvp_forward / dyb_hmr_jvp_backward (exact Hessian-vector product through HMR) against the oracle differentiated
+    twice by torch (CPU, float32): scalar s(theta) = <c, state(theta)>, direction v; checks the tangent of the state and
+    H v = grad_theta(<grad_theta s, v>) per tensor."""
+    from oracle import ref_cpu as O
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr_layout import HmrLayout
+    from conftest import cosine
+    B = 1
+    rng = _rng(seed)
+    L = HmrLayout(be.lib, B)
+    names = [k for k in ckpt if k not in ("init_pose", "init_shape", "init_cam")]
+    vdict = {k: torch.from_numpy(rng.standard_normal(tuple(ckpt[k].shape)).astype(np.float32)) * (0.02 if ckpt[k].dim() > 1 else 0.05)
+             for k in names}
+    for k in ("init_pose", "init_shape", "init_cam"):
+        vdict[k] = torch.zeros_like(ckpt[k])
+    params, tparams = be.dev(L.pack(ckpt).numpy()), be.dev(L.pack(vdict).numpy())
+    img = assets.make_frame(3, batch_size=B, seed=22)["image"]
+    init = np.repeat(HmrLayout.init_state(ckpt).numpy(), B, 0)
+    c = rng.standard_normal((B, 157)).astype(np.float32)
+    c[:, :144] *= 0.3
+
+    # ---- reference: torch forward-over-reverse on the oracle
+    P = {k: ckpt[k].clone().requires_grad_(k in names) for k in ckpt}
+    ct = torch.from_numpy(c)
+
+    def state_of(Pd):
+        pose, shape, cam = O.hmr_forward(Pd, img, return_pose6d=True)
+        return torch.cat([pose, shape, cam], 1)
+    plist = [P[k] for k in names]
+    st = state_of(P)
+    g = torch.autograd.grad((st * ct).sum(), plist, create_graph=True)
+    gv = sum((a * vdict[k]).sum() for a, k in zip(g, names))
+    hv_ref = dict(zip(names, torch.autograd.grad(gv, plist)))
+    # tangent of the state, J v, by forward-mode through double backward on a fresh graph
+    st2 = state_of(P)
+    u = torch.zeros_like(st2, requires_grad=True)
+    gu = torch.autograd.grad(st2, plist, u, create_graph=True)
+    jv = sum((a * vdict[k]).sum() for a, k in zip(gu, names))
+    tstate_ref = torch.autograd.grad(jv, u)[0].numpy()
+
+    # ---- device
+    acts, ws = be.empty((L.act_floats,)), be.empty((L.ws_bytes // 4,))
+    check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(be.dev(img.numpy())), be.ptr(be.dev(init)), 3, be.ptr(acts), be.ptr(ws),
+                                 L.ws_bytes, be.stream), "hmr forward")
+    nd = int(be.lib.dyb_hmr_hvp_dual_floats(L.plan))
+    dual = be.empty((nd,))
+    check(be.lib.dyb_hmr_jvp_forward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), 3, be.ptr(ws), L.ws_bytes,
+                                     be.stream), "jvp forward")
+    off = int(be.lib.dyb_hmr_hvp_offset_tstate(L.plan))
+    tstate = be.host(dual)[off:off + B * 160].reshape(B, 160)[:, :157]
+    e = dict(tstate=rel_err(tstate, tstate_ref))
+    assert e["tstate"] < 2e-3, e
+    d_state = np.zeros((B, 160), np.float32)
+    d_state[:, :157] = c
+    hv = be.zeros((L.n_params,))
+    check(be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(be.dev(d_state)),
+                                      be.ptr(be.zeros((B, 160))), 3, be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream), "jvp backward")
+    H = L.unpack(torch.from_numpy(be.host(hv)))
+    worst = {}
+    for k in names:
+        a, b = H[k].double().flatten(), hv_ref[k].double().flatten()
+        nb = float(b.norm())
+        if nb == 0.0:
+            continue
+        worst[k] = (float((a - b).norm()) / nb, cosine(a.numpy(), b.numpy()))
+    bad = {k: v for k, v in worst.items() if v[0] > 2e-3 or v[1] < 0.9999}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
+    e["hv_max_rel"] = max(v[0] for v in worst.values())
+    e["hv_min_cos"] = min(v[1] for v in worst.values())
+    return e

@@ -281,3 +281,10 @@ def test_groupnorm_tangent_kernels(be, cfg):
     """Forward tangent of GroupNorm(+ReLU)(+residual) and the tangent of its backward (the building blocks of the exact
     Hessian-vector product) against torch's forward-over-reverse in float64."""
     K.case_gn_jvp(be, *cfg)
+
+
+@pytest.mark.slow
+def test_hmr_exact_hessian_vector_product(be, ckpt_rand):
+    """The tangent passes through the whole network (exact H v, forward-over-reverse) against torch differentiating the oracle
+    twice: tangent of the regressor state and every tensor of H v."""
+    print(K.case_hmr_hvp(be, ckpt_rand))
