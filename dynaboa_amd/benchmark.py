@@ -66,6 +66,9 @@ parser.add_argument('--interval', type=int, default=5)
 parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
+parser.add_argument('--hvp', type=str, default="fd", choices=["fd", "exact"],
+                    help='second order only: Hessian-vector products as a central difference of first-order gradients (fd) or '
+                         'exactly, forward-over-reverse through the tangent kernels (exact; frame-loss levels)')
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
                     help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
                          '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')
@@ -389,7 +392,8 @@ class Adaptor(BaseAdaptor):
             if learner.first_order:
                 learner.adapt(lower_loss)           # the reference's call (dynaboa_benchmark.py:140)
             else:
-                learner.adapt(lower_loss, closure=self.level_closure("lower", image, gt_keypoints_2d, h36m_batch))
+                learner.adapt(lower_loss, closure=self.level_closure("lower", image, gt_keypoints_2d, h36m_batch),
+                              hvp_factory=self.level_hvp_factory("lower", image, gt_keypoints_2d, learner))
             if o.eval_lower:
                 if share:
                     owed = ('lower', i)

@@ -92,13 +92,19 @@ class MAML(nn.Module):
         learner.train(self.training)
         return learner
 
-    def adapt(self, loss, first_order=None, closure=None):
+    def adapt(self, loss, first_order=None, closure=None, hvp_factory=None):
+        """hvp_factory (second order only): theta_k -> (v -> H v), an exact Hessian-vector product of this level's loss at
+        the fast weights theta_k (dynaboa_amd/hvp.py); without it H v is the central difference of `closure`'s gradient."""
         fo = self.first_order if first_order is None else first_order
         if self._theta is None:
             raise RuntimeError("adapt() must be called on a clone()")
         (g,) = torch.autograd.grad(loss, [self._theta])
         if fo:
             self._theta = _FastWeightStep.apply(self._theta, g, self.lr)
+            return
+        if hvp_factory is not None:
+            exact = hvp_factory(self._theta.detach())
+            self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, lambda v: exact(v.detach()))
             return
         if closure is None:
             raise NotImplementedError(

@@ -232,3 +232,77 @@ def test_native_stepper_coverage_rules(emu_lib):
     o = DB.parser.parse_args([])
     o.sample_num = 2
     assert NS.mode(o) == "" and NS.mode(DB.parser.parse_args([]), have_bundle=False) == "full"
+
+
+@pytest.mark.slow
+def test_frame_level_exact_hvp_matches_oracle_second_derivative(emu_lib, gmm_t):
+    """--hvp exact: H v of a whole frame-loss level (HMR -> SMPL -> 2-D loss + priors) from the tangent passes + the head's
+    difference quotient, against torch differentiating the oracle's level loss twice - per tensor, next to the default
+    finite-difference product of the same level."""
+    from oracle import ref_cpu as O
+    from dynaboa_amd import assets, benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    from dynaboa_amd.hmr import get_layout
+    from conftest import cosine
+    o = DB.frame_only_options(inner_step=1, second_order=1, hvp="exact")
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True, randomize_norm=True), device="cpu")
+    ad.model.eval()
+    batch = assets.make_frame(0, 1, seed=22)
+    image, kp = batch["image"], batch["smpl_j2d"]
+    L = get_layout(1)
+    theta = ad.model.module.theta.detach()
+    # reference level loss on the oracle
+    mp = assets.make_smpl_mean_params(identity_pose=True, seed=3)
+    sd = assets.make_synthetic_checkpoint(22, mp, randomize_norm=True, prefix="")["model"]
+    oa = O.Adapter(sd, O.smpl_tables_to_torch(assets.make_synthetic_smpl(0)), gmm_t,
+                   dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0, use_motion=0, dynamic_boa=0,
+                        use_temporal_losses_upper=0, inner_step=1))
+    names = list(oa.theta)
+    plist = [oa.theta[k] for k in names]
+    rng = np.random.default_rng(9)
+    vdict = {k: torch.from_numpy(rng.standard_normal(tuple(oa.theta[k].shape)).astype(np.float32)) * (0.02 if oa.theta[k].dim() > 1 else 0.05)
+             for k in names}
+
+    def level(w):
+        rot, shape, cam = O.hmr_forward(oa._full(w), image)
+        j49, _ = oa.decode(rot, shape)
+        return oa.frame_losses(rot, shape, O.projection(cam, j49), kp, "ll")
+    g = torch.autograd.grad(level(oa.theta), plist, create_graph=True)
+    gv = sum((a * vdict[k]).sum() for a, k in zip(g, names))
+    hv_ref = dict(zip(names, torch.autograd.grad(gv, plist)))
+    # the same weights in the arena?  (the adaptor was built from the same seeds)
+    P0 = L.unpack(theta)
+    assert all(torch.equal(P0[k], oa.theta[k].detach()) for k in ("conv1.weight", "fc2.weight", "layer3.2.bn2.weight"))
+    vfull = dict(vdict, **{k: torch.zeros_like(v) for k, v in oa.buf.items()})
+    v = L.pack(vfull)
+    learner = ad.model.clone()
+    exact = ad.level_hvp_factory("lower", image, kp, learner)(theta)(v)
+    H = L.unpack(exact)
+
+    def errs(Hd):
+        out = {}
+        for k in names:
+            b = hv_ref[k].double().flatten()
+            if float(b.norm()) > 0:
+                a = Hd[k].double().flatten()
+                out[k] = (float((a - b).norm() / b.norm()), cosine(a.numpy(), b.numpy()))
+        return out
+    ee = errs(H)
+    bad = {k: x for k, x in ee.items() if x[0] > 3e-3 or x[1] < 0.9999}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+    # the default difference quotient of the same level, for the record (element-wise noisier in the backbone)
+    ad.options.hvp = "fd"
+    loss, _ = ad.lower_level_adaptation(image, kp, None, learner)
+    closure = ad.level_closure("lower", image, kp, None)
+    from dynaboa_amd.maml import MAML
+
+    def grad_at(th):
+        th = th.clone().requires_grad_(True)
+        probe = MAML(ad.model.module, ad.model.lr, True, _theta=th)
+        probe.eval()
+        return torch.autograd.grad(closure(probe), [th])[0]
+    eps = MAML.fd_rel * torch.linalg.vector_norm(theta) / torch.linalg.vector_norm(v)
+    fd = (grad_at(theta + eps * v) - grad_at(theta - eps * v)) / (2 * eps)
+    ef = errs(L.unpack(fd))
+    print("exact: max rel %.2e  min cos %.7f | fd: max rel %.2e  min cos %.7f" % (
+        max(x[0] for x in ee.values()), min(x[1] for x in ee.values()), max(x[0] for x in ef.values()), min(x[1] for x in ef.values())))
