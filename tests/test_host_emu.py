@@ -306,3 +306,38 @@ def test_frame_level_exact_hvp_matches_oracle_second_derivative(emu_lib, gmm_t):
     ef = errs(L.unpack(fd))
     print("exact: max rel %.2e  min cos %.7f | fd: max rel %.2e  min cos %.7f" % (
         max(x[0] for x in ee.values()), min(x[1] for x in ee.values()), max(x[0] for x in ef.values()), min(x[1] for x in ef.values())))
+
+
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~5 min under the emulator; set DYB_EMU_FULL=1")
+def test_second_order_exact_hvp_first_frame_vs_reference_second_order(emu_lib):
+    """--second_order 1 --hvp exact at the benchmarked depth (inner_step 3) on the emulator: the outer gradient of the first
+    frame against the reference run with learn2learn first_order=False (golden g5_so_inner3_frameonly)."""
+    from dynaboa_amd import assets
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    from conftest import cosine
+    gso, gfo = golden("g5_so_inner3_frameonly.npz"), golden("g5_fo_inner3_frameonly.npz")
+    o = DB.parser.parse_args([])
+    for k, v in dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0, use_motion=0, dynamic_boa=0,
+                     use_temporal_losses_upper=0, inner_step=3, second_order=1, hvp="exact").items():
+        setattr(o, k, v)
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=False, randomize_norm=True, smpl_seed=0), device="cpu")
+    ad.reset_records(1)
+    ad.global_step = 0
+    ad.model.eval()
+    ad.adaptation(assets.make_frame(0, 1, seed=22))
+    up = float(ad.fit_losses["ul/total"])
+    assert abs(up - gso["upper_loss"][0]) < 1e-4 * abs(gso["upper_loss"][0])
+    hmr = ad.model.module
+    st = ad.optimizer.state[hmr.theta]
+    g1 = hmr._layout1.unpack(st["exp_avg"] / (1 - ad.options.beta1))
+    names = [str(x) for x in gso["names"]]
+    gn = np.array([float(g1[k].double().norm()) for k in names])
+    err = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
+    gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
+    sl = {k[3:]: (rel_err(g1[k[3:]].flatten()[:256].numpy(), gso[k]), cosine(g1[k[3:]].flatten()[:256].numpy(), gso[k]))
+          for k in gso.files if k.startswith("g1_") and k not in ("g1_norms",)}
+    print("exact SO inner3: grad-norm error median %.2e max %.2e (FO-SO gap median %.2e); slices %s" % (
+        np.median(err), err.max(), np.median(gap), {k: ("%.1e" % a, "%.6f" % b) for k, (a, b) in sl.items()}))
+    assert np.median(err) < 5e-4 and err.max() < 3e-3
+    assert all(b > 0.9999 for _, b in sl.values()), sl
