@@ -361,6 +361,7 @@ def main():
                     help="0: re-run the forwards the reference schedule repeats with identical weights (9 instead of 5 per frame)")
     ap.add_argument("--second_order", type=int, default=0,
                     help="1: second-order MAML (BASELINE config 5's ablation arm); the reference and the default run are first-order")
+    ap.add_argument("--hvp", choices=["fd", "exact"], default="fd", help="second order: finite-difference or exact Hessian-vector products")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
@@ -412,7 +413,8 @@ def main():
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
     nfr = total + n_roof + n_pct
     rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, groups=args.groups, full_losses=args.full_losses,
-                second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule)
+                second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule,
+                hvp=args.hvp)
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream
@@ -555,6 +557,10 @@ def main():
             out["second_order"] = sub_record(device, "second_order", 24, 4, 1, args.inner_step,
                                              "configs[1] second-order arm: one sequence, second_order=1 (finite-difference Hessian-vector "
                                              "products, +2 forward+backward per inner step)", second_order=1)
+            out["second_order_exact_hvp"] = sub_record(device, "second_order_exact_hvp", 8, 2, 1, args.inner_step,
+                                                       "configs[1] second-order arm with --hvp exact: Hessian-vector products by tangent "
+                                                       "passes through the network (forward-over-reverse) instead of a difference quotient",
+                                                       second_order=1, hvp="exact")
             out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 16, 4, 8, args.inner_step,
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
