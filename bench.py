@@ -361,7 +361,7 @@ def main():
                     help="0: re-run the forwards the reference schedule repeats with identical weights (9 instead of 5 per frame)")
     ap.add_argument("--second_order", type=int, default=0,
                     help="1: second-order MAML (BASELINE config 5's ablation arm); the reference and the default run are first-order")
-    ap.add_argument("--hvp", choices=["fd", "exact"], default="fd", help="second order: finite-difference or exact Hessian-vector products")
+    ap.add_argument("--hvp", choices=["fd", "exact"], default="exact", help="second order: exact (tangent passes) or finite-difference Hessian-vector products")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_sub_records", action="store_true", help="skip the second-order / batch-8 / full-loss-set side runs")
@@ -554,13 +554,14 @@ def main():
                 note="aggregate frames/s with S independent sequences adapted in lockstep on this ONE GPU (batch 1 each, own weights / "
                      "Adam state / records; every launch of the per-frame chain covers all S); S1 = one sequence alone (the latency "
                      "configuration); the headline `value` uses S = %d" % seqs, **reps)
-            out["second_order"] = sub_record(device, "second_order", 24, 4, 1, args.inner_step,
-                                             "configs[1] second-order arm: one sequence, second_order=1 (finite-difference Hessian-vector "
-                                             "products, +2 forward+backward per inner step)", second_order=1)
-            out["second_order_exact_hvp"] = sub_record(device, "second_order_exact_hvp", 8, 2, 1, args.inner_step,
-                                                       "configs[1] second-order arm with --hvp exact: Hessian-vector products by tangent "
-                                                       "passes through the network (forward-over-reverse) instead of a difference quotient",
-                                                       second_order=1, hvp="exact")
+            out["second_order"] = sub_record(device, "second_order", 12, 3, 1, args.inner_step,
+                                             "configs[1] second-order arm: one sequence, second_order=1, exact Hessian-vector products "
+                                             "(tangent passes through the network, forward-over-reverse; the default)", second_order=1,
+                                             hvp="exact")
+            out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 24, 4, 1, args.inner_step,
+                                                    "the same with --hvp fd: Hessian-vector products as central differences of two "
+                                                    "first-order gradients of the level (+2 forward+backward per inner step)",
+                                                    second_order=1, hvp="fd")
             out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 16, 4, 8, args.inner_step,
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,

@@ -66,9 +66,10 @@ parser.add_argument('--interval', type=int, default=5)
 parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
-parser.add_argument('--hvp', type=str, default="fd", choices=["fd", "exact"],
-                    help='second order only: Hessian-vector products as a central difference of first-order gradients (fd) or '
-                         'exactly, forward-over-reverse through the tangent kernels (exact; frame-loss levels)')
+parser.add_argument('--hvp', type=str, default=os.environ.get("DYB_HVP", "exact"), choices=["fd", "exact"],
+                    help='second order only: Hessian-vector products exactly, forward-over-reverse through the tangent kernels '
+                         '(exact: levels made of the frame losses; other levels fall back) or as a central difference of '
+                         'first-order gradients of the whole level (fd)')
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
                     help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
                          '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')
