@@ -238,7 +238,7 @@ def test_second_order_matches_reference_second_order():
     first-order golden of the same frame is (they differ by 16-40 % per tensor)."""
     from dynaboa_amd import assets
     gso, gfo = golden("g5_so_inner2_frameonly.npz"), golden("g5_fo_inner2_frameonly.npz")
-    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=2, second_order=1), False)
+    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=2, second_order=1, hvp="fd"), False)
     n = int(gso["nframes"])
     ad.reset_records(n)
     hmr = ad.model.module
@@ -442,12 +442,13 @@ def test_batch8_mixtrain_matches_oracle(gmm_t, smpl_tabs):
 
 
 def test_second_order_inner3_matches_reference_second_order():
-    """Second order at the BENCHMARKED depth (inner_step=3, BASELINE configs[1]) against the reference run with
+    """Second order with the difference-quotient Hessian-vector products (--hvp fd) at the BENCHMARKED depth (inner_step=3,
+    BASELINE configs[1]; the exact form is test_second_order_inner3_exact_hvp_matches_reference_second_order) against the reference run with
     learn2learn first_order=False (golden g5_so_inner3_frameonly); the first-order golden of the same stream
     (g5_fo_inner3_frameonly) shows which of the two gradients the implementation follows."""
     from dynaboa_amd import assets
     gso, gfo = golden("g5_so_inner3_frameonly.npz"), golden("g5_fo_inner3_frameonly.npz")
-    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=3, second_order=1), False)
+    ad, bundle = make_adaptor(dict(FRAME_ONLY, inner_step=3, second_order=1, hvp="fd"), False)
     n = int(gso["nframes"])
     ad.reset_records(n)
     hmr = ad.model.module
