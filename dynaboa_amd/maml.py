@@ -8,15 +8,17 @@ fused ``p' = p - lr*g`` launch instead of 169 sub/mul pairs (18 % of the referen
 time).
 
 First order is what the reference runs.  Second order (``first_order=False``, learn2learn's
-``create_graph=True`` through every inner step) is provided without double-backward kernels: the
-outer gradient of K inner steps is  v_k = (I - lr*H_k) v_{k+1}  with H_k the Hessian of the k-th
-lower-level loss at the k-th fast weights, and each Hessian-vector product is the central difference
-of two FIRST-order gradients,  H v ~ (g(theta + e v) - g(theta - e v)) / 2e,  e = fd_rel*|theta|/|v|
-(fd_rel = 1e-5, chosen by a sweep against the reference's second-order goldens - see MAML.fd_rel).
-That costs two extra forward+backward passes per inner step - the same count an exact
-double-backward needs - and re-evaluating the loss at shifted weights needs the loss as a function,
-so ``adapt`` takes it: ``learner.adapt(loss, closure=lambda learner: loss_fn(learner))`` (the one
-extension over the learn2learn signature; first-order calls stay ``adapt(loss)``)."""
+``create_graph=True`` through every inner step): the outer gradient of K inner steps is
+v_k = (I - lr*H_k) v_{k+1}  with H_k the Hessian of the k-th lower-level loss at the k-th fast
+weights, so ``adapt`` needs Hessian-vector products of the level's loss.  Two sources:
+  * ``hvp_factory`` - exact, forward-over-reverse through the library's tangent passes
+    (dynaboa_amd/hvp.py, csrc/hvp_engine.inc; the drivers' default ``--hvp exact``);
+  * ``closure`` - the loss as a function of the learner; H v is then the central difference of two
+    FIRST-order gradients,  H v ~ (g(theta + e v) - g(theta - e v)) / 2e,  e = fd_rel*|theta|/|v|
+    (fd_rel = 1e-5, chosen by a sweep against the reference's second-order goldens - see
+    MAML.fd_rel; ``--hvp fd``, and the fallback for levels the exact form does not cover).
+``learner.adapt(loss, closure=..., hvp_factory=...)`` is the one extension over the learn2learn
+signature; first-order calls stay ``adapt(loss)``."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -58,7 +60,13 @@ class _SecondOrderStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        return d_out - ctx.lr * ctx.hvp(d_out), None, None, None
+        # v_k = v_{k+1} - lr * H v_{k+1}: the same fused streaming launch as the fast-weight step (out = p - lr * g)
+        d_out = d_out.contiguous()
+        hv = ctx.hvp(d_out).contiguous()
+        out = torch.empty_like(d_out)
+        check(_lib.load().dyb_fastweight_update(d_out.data_ptr(), hv.data_ptr(), out.data_ptr(), float(ctx.lr), d_out.numel(),
+                                                stream_of(d_out)), "dyb_fastweight_update")
+        return out, None, None, None
 
 
 class MAML(nn.Module):
