@@ -341,3 +341,23 @@ def test_second_order_exact_hvp_first_frame_vs_reference_second_order(emu_lib):
         np.median(err), err.max(), np.median(gap), {k: ("%.1e" % a, "%.6f" % b) for k, (a, b) in sl.items()}))
     assert np.median(err) < 5e-4 and err.max() < 3e-3
     assert all(b > 0.9999 for _, b in sl.values()), sl
+
+
+def test_exact_hvp_selection_rules(emu_lib):
+    """--hvp exact serves levels made of the frame losses; levels with teacher / motion / labelled terms (and --hvp fd) get no
+    factory, i.e. MAML.adapt differences the closure's gradient."""
+    from dynaboa_amd import assets, benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    assert DB.parser.parse_args([]).hvp in ("exact", "fd")
+    bundle = synthetic_bundle(seed=22, identity_pose=True)
+    img, kp = assets.make_frame(0, 1, seed=22)["image"], assets.make_frame(0, 1, seed=22)["smpl_j2d"]
+    ad = DB.Adaptor(DB.frame_only_options(inner_step=1, second_order=1, hvp="exact"), bundle, device="cpu")
+    learner = ad.model.clone()
+    assert ad.level_hvp_factory("lower", img, kp, learner) is not None
+    ad.options.hvp = "fd"
+    assert ad.level_hvp_factory("lower", img, kp, learner) is None
+    full = DB.parser.parse_args([])                      # the reference's default term set: labelled exemplars in the lower level
+    full.second_order, full.hvp = 1, "exact"
+    ad2 = DB.Adaptor(full, bundle, device="cpu")
+    assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is None
+    assert ad2.level_hvp_factory("upper", img, kp, ad2.model.clone()) is None
