@@ -97,6 +97,9 @@ class BaseAdaptor:
             self.model = model.to(self.device)
             self.model.load_state_dict({k.replace("module.", ""): v for k, v in ck.items()}, strict=True)
         self.optimizer = Adam(self.model.parameters(), lr=self.options.lr, betas=(self.options.beta1, self.options.beta2))
+        if self.options.use_boa and getattr(self.options, "second_order", 0):
+            # this optimiser understands a gradient left as (v, H v, lr): one fused "Adam + accumulate" launch for the outer step
+            self.model.defer_accumulate = bool(getattr(self.options, "fused_so_adam", 1))
         # precision of the backbone convolutions is a property of the engine plan (one per batch size, shared by every
         # model of the process): set explicitly both ways so that a bf16 run does not leak into a later fp32 one
         from .hmr import get_layout

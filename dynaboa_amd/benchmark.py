@@ -70,6 +70,8 @@ parser.add_argument('--hvp', type=str, default=os.environ.get("DYB_HVP", "exact"
                     help='second order only: Hessian-vector products exactly, forward-over-reverse through the tangent kernels '
                          '(exact: levels made of the frame losses; other levels fall back) or as a central difference of '
                          'first-order gradients of the whole level (fd)')
+parser.add_argument('--fused_so_adam', type=int, default=1, choices=[0, 1],
+                    help='second order: fold the last accumulation of the outer gradient (v - lr*Hv) into the Adam launch')
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],
                     help='1: second-order MAML (learn2learn first_order=False); the reference hard-codes first order '
                          '(base_adaptor.py:119).  See dynaboa_amd/maml.py for how the Hessian-vector products are formed')

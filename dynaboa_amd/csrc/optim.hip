@@ -60,6 +60,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     p[i] = pp; m[i] = mm; v[i] = vv;
   }
 }
+// Adam on a gradient that is still in two pieces, g - alpha * h: the last accumulation of the second-order outer gradient
+// (v_0 = v_1 - lr * H v_1, dynaboa_amd/maml.py) is formed here instead of in a pass of its own, so the outer step of the
+// second-order path is ONE streaming launch (reads p, g, h, m, v / writes p, m, v).
+__global__ __launch_bounds__(256) void adam_accum_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                         const float4* __restrict__ h, float alpha, float4* __restrict__ m,
+                                                         float4* __restrict__ v, float b1, float b2, float step_size, float bc2_sqrt,
+                                                         float eps, size_t n4, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, h); DYB_RB(Rp, m); DYB_RB(Rp, v);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = p[i], gg = g[i], hh = h[i], mm = m[i], vv = v[i];
+    gg.x = gg.x - alpha * hh.x; gg.y = gg.y - alpha * hh.y; gg.z = gg.z - alpha * hh.z; gg.w = gg.w - alpha * hh.w;
+    adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2_sqrt, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+extern "C" int dyb_adam_step_accum(float* p, const float* g, const float* h, float alpha, float* m, float* v, float beta1,
+                                   float beta2, float step_size, float bc2_sqrt, float eps, size_t n, hipStream_t st) {
+  DYB_REQUIRE(p && g && h && m && v && n % 4 == 0, DYB_ERR_ARG);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(adam_accum_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g,
+                     (const float4*)h, alpha, (float4*)m, (float4*)v, beta1, beta2, step_size, bc2_sqrt, eps, n / 4, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
 // step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t): computed by the caller in double.
 extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, float beta2, float step_size,
                              float bc2_sqrt, float eps, size_t n, hipStream_t st) {

@@ -51,8 +51,8 @@ class _SecondOrderStep(torch.autograd.Function):
     the first-order gradient at p +- e v; see the module docstring)."""
 
     @staticmethod
-    def forward(ctx, p, g, lr, hvp):
-        ctx.lr, ctx.hvp = lr, hvp
+    def forward(ctx, p, g, lr, hvp, defer_to=None):
+        ctx.lr, ctx.hvp, ctx.defer_to = lr, hvp, defer_to
         out = torch.empty_like(p)
         check(_lib.load().dyb_fastweight_update(p.data_ptr(), g.data_ptr(), out.data_ptr(), float(lr), p.numel(),
                                                 stream_of(p)), "dyb_fastweight_update")
@@ -63,10 +63,15 @@ class _SecondOrderStep(torch.autograd.Function):
         # v_k = v_{k+1} - lr * H v_{k+1}: the same fused streaming launch as the fast-weight step (out = p - lr * g)
         d_out = d_out.contiguous()
         hv = ctx.hvp(d_out).contiguous()
+        if ctx.defer_to is not None:
+            # first inner step: its output gradient IS the parameter's.  Leave the accumulation to the optimiser's fused
+            # "Adam + accumulate" launch (dynaboa_amd/optim.py): the parameter receives v and carries (H v, lr) beside it
+            ctx.defer_to._so_pending = (hv, ctx.lr)
+            return d_out, None, None, None, None
         out = torch.empty_like(d_out)
         check(_lib.load().dyb_fastweight_update(d_out.data_ptr(), hv.data_ptr(), out.data_ptr(), float(ctx.lr), d_out.numel(),
                                                 stream_of(d_out)), "dyb_fastweight_update")
-        return out, None, None, None
+        return out, None, None, None, None
 
 
 class MAML(nn.Module):
@@ -84,6 +89,10 @@ class MAML(nn.Module):
         self.lr = lr
         self.first_order = first_order
         self._theta = _theta            # None: this is the base wrapper; tensor: a learner's fast weights
+        # second order with dynaboa_amd.optim.Adam: leave the last accumulation (v - lr * H v) to the optimiser's fused launch
+        # (BaseAdaptor switches it on; off for stand-alone use, where any optimiser may read .grad)
+        self.defer_accumulate = False
+        self._first = True
 
     def forward(self, *args, **kwargs):
         if self._theta is None:
@@ -97,6 +106,7 @@ class MAML(nn.Module):
         fo = self.first_order if first_order is None else first_order
         src = self.module.theta if self._theta is None else self._theta
         learner = MAML(self.module, self.lr, fo, _theta=src.view_as(src))
+        learner.defer_accumulate = self.defer_accumulate and self._theta is None      # only a clone of the base wrapper
         learner.train(self.training)
         return learner
 
@@ -110,9 +120,12 @@ class MAML(nn.Module):
         if fo:
             self._theta = _FastWeightStep.apply(self._theta, g, self.lr)
             return
+        # the first adapt() of a clone feeds the base parameter directly: its accumulation can ride in Adam's launch
+        defer = self.module.theta if (self.defer_accumulate and self._first) else None
+        self._first = False
         if hvp_factory is not None:
             exact = hvp_factory(self._theta.detach())
-            self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, lambda v: exact(v.detach()))
+            self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, lambda v: exact(v.detach()), defer)
             return
         if closure is None:
             raise NotImplementedError(
@@ -135,7 +148,7 @@ class MAML(nn.Module):
             step = eps * v
             return (grad_at(theta_k + step) - grad_at(theta_k - step)) / (2 * eps)
 
-        self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, hvp)
+        self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, hvp, defer)
 
     def parameters(self, recurse: bool = True):
         if self._theta is None:

@@ -14,6 +14,15 @@ from ._abi import check
 from .hmr import stream_of
 
 
+def materialize_grad(p):
+    """The full gradient of a parameter whose last second-order accumulation was deferred to Adam.step (p.grad - alpha * h)."""
+    pend = getattr(p, "_so_pending", None)
+    if pend is None:
+        return p.grad
+    h, alpha = pend
+    return p.grad - alpha * h
+
+
 class Adam:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params]
@@ -26,6 +35,8 @@ class Adam:
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
+            if getattr(p, "_so_pending", None) is not None:
+                p._so_pending = None
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None
@@ -48,6 +59,15 @@ class Adam:
             step_size = lr / (1.0 - b1 ** t)
             bc2_sqrt = (1.0 - b2 ** t) ** 0.5
             g = p.grad.contiguous()
+            pend = getattr(p, "_so_pending", None)
+            if pend is not None:
+                # second order: the gradient is still g - alpha * h (MAML deferred its last accumulation, maml.py) - one launch
+                h, alpha = pend
+                p._so_pending = None
+                check(lib.dyb_adam_step_accum(p.data_ptr(), g.data_ptr(), h.data_ptr(), float(alpha), st["exp_avg"].data_ptr(),
+                                              st["exp_avg_sq"].data_ptr(), b1, b2, step_size, bc2_sqrt, eps, p.numel(), stream_of(p)),
+                      "dyb_adam_step_accum")
+                continue
             check(lib.dyb_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                     b1, b2, step_size, bc2_sqrt, eps, p.numel(), stream_of(p)), "dyb_adam_step")
 

@@ -269,6 +269,9 @@ int dyb_pa_mpjpe(const float* pred, const float* gt, float* out, float* aligned,
 int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, dyb_stream_t stream);
 int dyb_adam_step(float* p, const float* g, float* m, float* v, float beta1, float beta2, float step_size,
                   float bc2_sqrt, float eps, size_t n, dyb_stream_t stream);
+/* Adam on the gradient g - alpha * h: the second-order path's last accumulation (v - lr * H v) fused into the optimiser step */
+int dyb_adam_step_accum(float* p, const float* g, const float* h, float alpha, float* m, float* v, float beta1, float beta2,
+                        float step_size, float bc2_sqrt, float eps, size_t n, dyb_stream_t stream);
 int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, dyb_stream_t stream);
 int dyb_axpby(const float* x, float* y, float a, float b, size_t n, dyb_stream_t stream);
 int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* out, dyb_stream_t stream);

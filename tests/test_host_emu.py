@@ -361,3 +361,45 @@ def test_exact_hvp_selection_rules(emu_lib):
     ad2 = DB.Adaptor(full, bundle, device="cpu")
     assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is None
     assert ad2.level_hvp_factory("upper", img, kp, ad2.model.clone()) is None
+
+
+def test_fused_adam_accumulate_matches_separate_accumulate(emu_lib):
+    """Second order: leaving the last accumulation (v - lr * H v) to dyb_adam_step_accum gives the Adam state of the two-launch
+    sequence (fast-weight kernel, then dyb_adam_step) - toy loss, K = 2 inner steps."""
+    from dynaboa_amd.maml import MAML
+    from dynaboa_amd.optim import Adam, materialize_grad
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.theta = torch.nn.Parameter(torch.randn(256, generator=g) * 0.5)
+    g = torch.Generator().manual_seed(6)
+    A = torch.randn(256, 256, generator=g) / 16
+    c = torch.randn(256, generator=g)
+    lower = lambda th: (torch.sin(th @ A) * c).sum() + 0.1 * (th ** 4).sum()
+    upper = lambda th: ((th - 0.3) ** 2).sum() + torch.cos(th).sum()
+    old = MAML.fd_rel
+    MAML.fd_rel = 1e-3
+    res = []
+    try:
+        for defer in (False, True):
+            toy = Toy()
+            maml = MAML(toy, lr=0.05, first_order=False)
+            maml.defer_accumulate = defer
+            opt = Adam([toy.theta], lr=1e-2, betas=(0.5, 0.9))
+            learner = maml.clone()
+            for _ in range(2):
+                learner.adapt(lower(learner._theta), closure=lambda l: lower(l._theta))
+            opt.zero_grad()
+            upper(learner._theta).backward()
+            assert (getattr(toy.theta, "_so_pending", None) is not None) == defer
+            full = materialize_grad(toy.theta).clone()
+            opt.step()
+            assert getattr(toy.theta, "_so_pending", None) is None
+            st = opt.state[toy.theta]
+            res.append((full, toy.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()))
+    finally:
+        MAML.fd_rel = old
+    for a, b in zip(*res):
+        assert rel_err(b.numpy(), a.numpy()) < 1e-6
