@@ -987,7 +987,7 @@ def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
     return e
 
 
-def case_hmr_hvp(be, ckpt, seed=5):
+def case_hmr_hvp(be, ckpt, seed=5, B=1):
     """dyb_hmr_jvp_forward / dyb_hmr_jvp_backward (exact Hessian-vector product through HMR) against the oracle differentiated
     twice by torch (CPU, float32): scalar s(theta) = <c, state(theta)>, direction v; checks the tangent of the state and
     H v = grad_theta(<grad_theta s, v>) per tensor."""
@@ -995,7 +995,6 @@ def case_hmr_hvp(be, ckpt, seed=5):
     from dynaboa_amd import assets
     from dynaboa_amd.hmr_layout import HmrLayout
     from conftest import cosine
-    B = 1
     rng = _rng(seed)
     L = HmrLayout(be.lib, B)
     names = [k for k in ckpt if k not in ("init_pose", "init_shape", "init_cam")]

@@ -284,7 +284,8 @@ def test_groupnorm_tangent_kernels(be, cfg):
 
 
 @pytest.mark.slow
-def test_hmr_exact_hessian_vector_product(be, ckpt_rand):
+@pytest.mark.parametrize("B", [1, 2])
+def test_hmr_exact_hessian_vector_product(be, ckpt_rand, B):
     """The tangent passes through the whole network (exact H v, forward-over-reverse) against torch differentiating the oracle
-    twice: tangent of the regressor state and every tensor of H v."""
-    print(K.case_hmr_hvp(be, ckpt_rand))
+    twice: tangent of the regressor state and every tensor of H v; batch 1 and 2."""
+    print(K.case_hmr_hvp(be, ckpt_rand, B=B))
