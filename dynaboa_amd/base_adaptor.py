@@ -342,19 +342,23 @@ class BaseAdaptor:
         return closure
 
     def level_hvp_factory(self, level, image, gt_keypoints_2d, learner):
-        """With --hvp exact: theta -> (v -> H v) for the level `_level` just evaluated, when that level is made of the frame
-        losses only (dynaboa_amd/hvp.py); None otherwise (MAML.adapt then differences the closure's gradient)."""
+        """With --hvp exact: theta -> (v -> H v) for the level `_level` just evaluated (dynaboa_amd/hvp.py): frame-loss levels
+        through the kernels' own head gradient, levels with teacher / motion / labelled terms through the multi-pass form;
+        None (MAML.adapt then differences the closure's gradient) with --hvp fd."""
         o = self.options
         if getattr(o, "hvp", "fd") != "exact":
             return None
-        if not (getattr(o, "fused_level", 1) and getattr(o, f"use_frame_losses_{level}")):
-            return None
-        if getattr(o, f"use_temporal_losses_{level}") or getattr(o, f"{level}_level_mixtrain"):
-            return None
-        from .hvp import frame_level_hvp
+        from .hvp import frame_level_hvp, general_level_hvp
         hmr = getattr(learner, "module", learner)
-        return lambda theta: frame_level_hvp(hmr, self.smpl_neutral, self.gmm_f, theta, image, gt_keypoints_2d, o.s2dloss_weight,
-                                             o.shape_prior_weight, o.pose_prior_weight)
+        other = getattr(o, f"use_temporal_losses_{level}") or getattr(o, f"{level}_level_mixtrain")
+        if not other and getattr(o, f"use_frame_losses_{level}"):
+            # frame losses only (the benchmarked second-order configuration): the head's gradient straight from the kernels
+            return lambda theta: frame_level_hvp(hmr, self.smpl_neutral, self.gmm_f, theta, image, gt_keypoints_2d, o.s2dloss_weight,
+                                                 o.shape_prior_weight, o.pose_prior_weight)
+        if getattr(o, "hvp_terms", "frame") != "all":
+            return None                      # --hvp_terms frame (default): teacher / motion / labelled levels keep the difference quotient
+        used = getattr(self, "_last_h36m", None)
+        return lambda theta: general_level_hvp(self, level, hmr, theta, image, gt_keypoints_2d, used)
 
     def lower_level_adaptation(self, image, gt_keypoints_2d, h36m_batch, learner=None):
         return self._level("lower", image, gt_keypoints_2d, h36m_batch, learner)

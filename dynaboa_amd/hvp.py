@@ -13,9 +13,11 @@ The head's second derivative is taken as a central difference of ITS analytic gr
 function of 157 inputs per sample evaluated by the same loss / LBS kernels, where a difference quotient is accurate to ~1e-5 -
 while the 50-layer ReLU / GroupNorm backbone, where a difference quotient of the whole network is noisy element-wise, is exact.
 
-Covers levels made of the frame losses only (2-D keypoints + shape prior + pose prior): the benchmarked second-order
-configuration.  Levels with teacher / motion / labelled terms fall back to the difference quotient (``frame_level_hvp``
-returns None)."""
+``frame_level_hvp`` covers levels made of the frame losses only (2-D keypoints + shape prior + pose prior) - the benchmarked
+second-order configuration, checked on the GPU against the reference's second-order golden.  ``general_level_hvp`` covers any
+level (teacher / motion / labelled terms: up to three network passes sharing the weights, head assembled from the adaptor's
+differentiable pieces); checked against the oracle's create_graph gradient on the CPU emulator (1e-4 at layer2, 1e-6 above,
+where the difference quotient gave 2e-2 / 6e-3), opt-in (``--hvp_terms all``) until it has run on the GPU."""
 from __future__ import annotations
 
 import torch
@@ -98,4 +100,154 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
         check(lib.dyb_hmr_jvp_backward(L.plan, theta.data_ptr(), v.data_ptr(), acts.data_ptr(), dual.data_ptr(), g0.data_ptr(),
                                        td.data_ptr(), n_iter, hv.data_ptr(), ws.data_ptr(), L.ws_bytes, st), "dyb_hmr_jvp_backward")
         return hv
+    return hvp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Any level: frame losses + mean-teacher + motion + labelled-exemplar terms (reference base_adaptor.py:222-398)
+# ---------------------------------------------------------------------------------------------------------------------
+def rot6d_to_rotmat(x6: torch.Tensor) -> torch.Tensor:
+    """reference utils/geometry.py:47-61 on the regressor's 144 pose numbers -> (B, 24, 3, 3); torch ops, differentiable."""
+    m = x6.reshape(-1, 3, 2)
+    a1, a2 = m[:, :, 0], m[:, :, 1]
+    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    u = a2 - (b1 * a2).sum(1, keepdim=True) * b1
+    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    b3 = torch.cross(b1, b2, dim=1)
+    return torch.stack([b1, b2, b3], dim=2).view(-1, 24, 3, 3)
+
+
+class _Pass:
+    """One network pass of a level (an image batch evaluated with the level's weights): primal activations, tangent arena."""
+
+    def __init__(self, lib, hmr, theta, image, n_iter):
+        self.lib, self.n_iter = lib, n_iter
+        self.image = image.contiguous().float()
+        B, _, H, W = self.image.shape
+        self.B, self.L = B, get_layout(B, H, W)
+        L, dev = self.L, theta.device
+        self.ws = get_workspace(L, dev)
+        self.acts = torch.empty(L.act_floats, dtype=torch.float32, device=dev)
+        self.init_state = hmr.make_init_state(B).contiguous().float()
+        check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), self.image.data_ptr(), self.init_state.data_ptr(), n_iter, self.acts.data_ptr(),
+                                  self.ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
+        self.state = self.acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD).clone()
+        self.dual = None
+
+    def tangent(self, theta, v):
+        L, lib = self.L, self.lib
+        self.dual = torch.empty(int(lib.dyb_hmr_hvp_dual_floats(L.plan)), dtype=torch.float32, device=theta.device)
+        check(lib.dyb_hmr_jvp_forward(L.plan, theta.data_ptr(), v.data_ptr(), self.acts.data_ptr(), self.dual.data_ptr(), self.n_iter,
+                                      self.ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_jvp_forward")
+        off = int(lib.dyb_hmr_hvp_offset_tstate(L.plan))
+        return self.dual[off:off + self.B * STATE_LD].view(self.B, STATE_LD).clone()
+
+    def hv(self, theta, v, g, tg):
+        L, lib = self.L, self.lib
+        out = torch.zeros(L.n_params, dtype=torch.float32, device=theta.device)
+        g, tg = g.contiguous().float(), tg.contiguous().float()
+        check(lib.dyb_hmr_jvp_backward(L.plan, theta.data_ptr(), v.data_ptr(), self.acts.data_ptr(), self.dual.data_ptr(), g.data_ptr(),
+                                       tg.data_ptr(), self.n_iter, out.data_ptr(), self.ws.data_ptr(), L.ws_bytes, stream_of(theta)),
+              "dyb_hmr_jvp_backward")
+        return out
+
+
+def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: int = 3):
+    """-> callable v -> H v for ANY level `BaseAdaptor._level` can assemble: the level's loss is a function of the regressor
+    states of up to three network passes that share the weights - the frame (frame losses, teacher term, motion term), the
+    frame `interval` steps back (motion term) and the retrieved exemplar images (labelled term).  Per pass a tangent pass
+    gives the state tangent; the head - rot6d, SMPL, projection and the loss terms, assembled here exactly as `_level` does,
+    from the same differentiable pieces - is differentiated by torch for its gradient and by a central difference of that
+    gradient along the joint state tangent for its second derivative; per pass the tangent of the backward gives its share of
+    H v.  Exemplars, teacher targets and history are those of the level evaluation (nothing is re-drawn)."""
+    import torch.nn.functional as F
+    from .losses import frame_losses
+    lib = _lib.load()
+    o = ad.options
+    theta = theta.detach()
+    if hmr.training:
+        raise NotImplementedError("exact Hessian-vector products are the eval-mode path")
+    use_frame = bool(getattr(o, f"use_frame_losses_{level}"))
+    temporal = bool(getattr(o, f"use_temporal_losses_{level}"))
+    use_teacher = temporal and bool(o.use_meanteacher)
+    use_motion = temporal and bool(o.use_motion) and (ad.global_step - o.interval) > 0
+    use_label = bool(getattr(o, f"{level}_level_mixtrain"))
+    kp2d = kp2d.contiguous().float()
+    teacher_t = None
+    if use_teacher:
+        with torch.no_grad():
+            t_rot, t_shape, t_cam = ad.teacher(image)
+            t_s3d = ad.decode_smpl_params(t_rot, t_shape)["s3d"]
+            teacher_t = (t_rot, t_shape, t_s3d, ad.projection(t_cam, t_s3d)["normed"])
+    hist = ad.get_hist() if use_motion else None
+
+    def preds(state):
+        rot = rot6d_to_rotmat(state[:, :144])
+        shape, cam = state[:, 144:154], state[:, 154:157]
+        return rot, shape, cam, ad.decode_smpl_params(rot, shape)["s3d"]
+
+    def head(states):                                   # states: dict pass name -> (B, 160) tensor
+        rot, shape, cam, s3d = preds(states["img"])
+        loss = None
+        if use_frame:
+            loss = frame_losses(rot, shape, cam, s3d, kp2d, ad.gmm_f, o.s2dloss_weight, o.shape_prior_weight, o.pose_prior_weight)[0]
+        if temporal:
+            s2d = ad.projection(cam, s3d)["normed"]
+            if use_teacher:                             # base_adaptor.py:320-343
+                t_rot, t_shape, t_s3d, t_s2d = teacher_t
+                t = (F.mse_loss(s2d, t_s2d) * 5 + F.mse_loss(t_s3d, s3d) * 5 + F.mse_loss(shape, t_shape) * 0.001
+                     + F.mse_loss(rot, t_rot)) * o.teacherloss_weight
+                loss = t if loss is None else loss + t
+            if use_motion:                              # base_adaptor.py:379-398
+                h_rot, h_shape, h_cam, h_s3d = preds(states["hist"])
+                h_s2d = ad.projection(h_cam, h_s3d)["normed"]
+                gt, hist_s2d = kp2d[:, 25:], hist[1]
+                pm = s2d[:, 25:] - h_s2d[:, 25:]
+                gm = gt[:, :, :-1] - hist_s2d[:, 25:, :-1]
+                conf = ((hist_s2d[:, 25:, -1:] + gt[:, :, -1:]) == 2).float()
+                loss = loss + (((pm - gm) ** 2) * conf).mean() * o.motionloss_weight
+        if use_label:                                   # base_adaptor.py:346-376
+            from .geometry import batch_rodrigues
+            b = h36m_batch
+            e_rot, e_shape, e_cam, e_s3d = preds(states["ex"])
+            g2d = b["keypoints"]
+            conf = g2d[:, 25:, -1:].clone()
+            gt_rot = batch_rodrigues(b["pose"].view(-1, 3)).view(-1, 24, 3, 3)
+            e_s2d = ad.projection(e_cam, e_s3d)["normed"]
+            lab = ((((e_s2d[:, 25:] - g2d[:, 25:, :-1]) ** 2) * conf).mean() * 5
+                   + ad.cal_s3d_loss(e_s3d[:, 25:], b["pose_3d"][:, :, :-1], conf) * 5 + F.mse_loss(e_shape, b["betas"]) * 0.001
+                   + F.mse_loss(e_rot, gt_rot) * 1)
+            loss = loss + lab * o.labelloss_weight
+        return loss
+
+    def head_grad(states):
+        with torch.enable_grad():
+            leaf = {k: s.detach().clone().requires_grad_(True) for k, s in states.items()}
+            gs = torch.autograd.grad(head(leaf), list(leaf.values()), allow_unused=True)
+        return {k: (torch.zeros_like(s) if g is None else g) for (k, s), g in zip(leaf.items(), gs)}
+
+    def hvp(v):
+        v = v.detach().contiguous().float()
+        with torch.no_grad():
+            passes = {"img": _Pass(lib, hmr, theta, image, n_iter)}
+            if use_motion:
+                passes["hist"] = _Pass(lib, hmr, theta, hist[0], n_iter)
+            if use_label:
+                passes["ex"] = _Pass(lib, hmr, theta, h36m_batch["img"], n_iter)
+            states = {k: p.state for k, p in passes.items()}
+            tst = {k: p.tangent(theta, v) for k, p in passes.items()}
+            for t in tst.values():
+                t[:, 157:] = 0
+            sn = torch.sqrt(sum((s[:, :157] ** 2).sum() for s in states.values()))
+            tn = torch.sqrt(sum((t ** 2).sum() for t in tst.values()))
+            eps = HEAD_FD_REL * sn / tn.clamp_min(1e-30)
+        g0 = head_grad(states)
+        gp = head_grad({k: states[k] + eps * tst[k] for k in states})
+        gm = head_grad({k: states[k] - eps * tst[k] for k in states})
+        with torch.no_grad():
+            out = None
+            for k, p in passes.items():
+                h = p.hv(theta, v, g0[k], (gp[k] - gm[k]) / (2 * eps))
+                out = h if out is None else out + h
+        return out
     return hvp

@@ -361,6 +361,8 @@ def test_exact_hvp_selection_rules(emu_lib):
     ad2 = DB.Adaptor(full, bundle, device="cpu")
     assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is None
     assert ad2.level_hvp_factory("upper", img, kp, ad2.model.clone()) is None
+    ad2.options.hvp_terms = "all"                        # the multi-pass form (opt-in)
+    assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is not None
 
 
 def test_fused_adam_accumulate_matches_separate_accumulate(emu_lib):
@@ -403,3 +405,42 @@ def test_fused_adam_accumulate_matches_separate_accumulate(emu_lib):
         MAML.fd_rel = old
     for a, b in zip(*res):
         assert rel_err(b.numpy(), a.numpy()) < 1e-6
+
+
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~6 min under the emulator; set DYB_EMU_FULL=1")
+def test_second_order_full_loss_set_exact_hvp_vs_oracle(emu_lib, gmm_t, smpl_tabs):
+    """Second order with the reference's default term set (labelled exemplars in the lower level; teacher + exemplars in the
+    upper; frame 0, so no motion term) and exact Hessian-vector products of the multi-pass level (general_level_hvp): the
+    outer gradient against the CPU oracle in create_graph=True mode, next to the oracle's first-order gradient."""
+    from dynaboa_amd import assets
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    from oracle import ref_cpu as O
+    opts = dict(inner_step=1, interval=2, optim_steps=2, dynamic_boa=0)
+    frame = assets.make_frame(0, 1, seed=22)
+    o = DB.parser.parse_args([])
+    for k, v in dict(opts, second_order=1, hvp="exact", hvp_terms="all").items():
+        setattr(o, k, v)
+    bundle = synthetic_bundle(seed=22, identity_pose=False, randomize_norm=True, smpl_seed=0)
+    ad = DB.Adaptor(o, bundle, device="cpu")
+    ad.reset_records(1)
+    ad.global_step = 0
+    ad.model.eval()
+    ad.adaptation(frame)
+    hmr_m = ad.model.module
+    ours = hmr_m._layout1.unpack(ad.optimizer.state[hmr_m.theta]["exp_avg"] / (1 - ad.options.beta1))
+    sd = {k.replace("module.", ""): v for k, v in bundle.checkpoint["model"].items()}
+    grads = {}
+    for so in (1, 0):
+        ref = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, opts, first_order=not so)
+        ref.exemplar_fn = lambda step: assets.make_exemplars(step, ref.o["sample_num"])
+        grads[so] = ref.adapt_frame(frame)["outer_grad"]
+    names = ["conv1.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight", "layer4.2.conv3.weight", "fc1.weight", "decpose.weight"]
+    e_so = np.array([rel_err(ours[k].numpy(), grads[1][k].numpy()) for k in names])
+    gap = np.array([rel_err(grads[0][k].numpy(), grads[1][k].numpy()) for k in names])
+    print("SO full-loss exact: err vs oracle-SO", e_so, " FO-vs-SO gap", gap)
+    # conv1: the FIRST-order gradient of this configuration already differs by 4e-2 (max-abs; 8e-3 in norm, cosine 0.99997)
+    # between the engine and the oracle - a few stem activations within fp32 rounding of zero flip their ReLU mask - so the
+    # stem row is bounded by that, the rest by the Hessian-vector products' own accuracy
+    assert e_so[0] < 6e-2 and (e_so[1:] < 1e-3).all(), e_so
+    assert (e_so[1:] < 0.01 * gap[1:] + 1e-5).all(), (e_so, gap)
