@@ -59,6 +59,29 @@ def pmc_traffic():
         return None
 
 
+def mfma_busy():
+    """MFMA-pipe busy fraction of the throughput conv kernel family from the newest committed SQ-counter summary
+    (profiles/r*_pmc_sq_A_tp.json: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE, own pass, no tracing):
+    sum over launches of busy cycles / (kernel cycles x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_A_tp.json")))[-1]
+        d = json.load(open(path))
+        busy = cyc = 0.0
+        for k, v in d.items():
+            if k.startswith("igemm_tp_kernel") and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                busy += v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["launches"]
+                cyc += v["GRBM_GUI_ACTIVE"] * v["launches"]
+        if cyc <= 0:
+            return None
+        return dict(value=busy / (cyc / 8.0 * 1024.0),
+                    note="SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over every igemm_tp_kernel launch of a "
+                         "16-sequence run, from %s (PMC pass: kernels serialised; taken before the buffer-addressed loaders)"
+                         % os.path.relpath(path, ROOT))
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def conv_roofline(run, lo, hi, main_stream):
     """Dominant kernel family = igemm_mfma_kernel<fwd|dgrad|wgrad, with/without the GroupNorm loaders>.
     Measured IN the path: frames [lo, hi) of the same loop are run once more with a timing scope open on the
@@ -510,6 +533,7 @@ def main():
                                "frac": r["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": tr["bytes"] if tr else None,
                                "traffic_note": tr["note"] if tr else "no PMC summary under profiles/",
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                               "mfma_pipe_busy": mfma_busy(),
                                "kernel": "the convolution family - igemm_tp_kernel<fwd|dgrad|wgrad> (throughput form: launches covering >= 8 sequences), "
                                          "igemm_mfma_kernel / igemm_k4_* (latency form): every conv launch of the adaptation chain (main + "
                                          "weight-gradient streams; a launch covers all sequences of the step), timed on its own dispatch "
