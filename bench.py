@@ -597,6 +597,16 @@ def main():
                                 "bf16 MFMA for the convolutions (fp32 master weights / activations / statistics / accumulators)",
                                 roofline_peak=PEAK_BF16_MFMA_TFLOPS, bf16_mfma=1))
             __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(16).set_bf16(False)
+            # the same fp32 arm on the throughput schedule (materialised dy, igemm_tp_kernel), selected by the batch size: a
+            # switch that is off by default because this line is its first measurement
+            from dynaboa_amd import _lib as _L
+            try:
+                _L.load().dyb_set_option(b"tp_batch_min", 16)
+                out["batch16_fp32_vs_bf16"]["fp32_throughput_schedule"] = sub_record(
+                    device, "b16_fp32_tp", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, fp32 MFMA, "
+                    "throughput schedule selected by the batch (switch tp_batch_min = 16; default off)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
+            finally:
+                _L.load().dyb_set_option(b"tp_batch_min", 0)
             out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)

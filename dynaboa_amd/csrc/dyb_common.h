@@ -132,7 +132,9 @@ int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w
                           size_t ws_bytes, int* nslabs, hipStream_t st);
 int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* addend, float* out, hipStream_t st);
 // throughput schedule (several sequence replicas per launch): dy materialised once per layer, plain gradient convolutions
-bool dyb_throughput_mode();                     // "rep_split" switch on and >= 8 replicas in the current launch scope
+// throughput schedule: "rep_split" switch on and >= "tp_min" (8) replicas in the current launch scope, or - switch
+// "tp_batch_min" > 0 (off by default: unmeasured) - a batch of at least that many images
+bool dyb_throughput_mode(int batch = 1);
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,

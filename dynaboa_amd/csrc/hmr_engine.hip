@@ -664,7 +664,7 @@ static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* ac
   float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
-  const bool tp = dyb_throughput_mode();
+  const bool tp = dyb_throughput_mode(P.B);
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
                               acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st,
                               tp ? nullptr : done));
@@ -697,7 +697,7 @@ static int layer_dgrad(HmrPlan& P, int ci, const float* params, const float* act
   ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
   GnBwdSrc src{dm, acts + c.y, acts + c.stats, w.gnb + c.gnb, params + c.gam, bs.nch[ci], bs.ncolb[ci]};
   int ns = 1;
-  if (dyb_throughput_mode())       // dy of this layer was materialised by its reduce step (layer_gn_bwd)
+  if (dyb_throughput_mode(P.B))    // dy of this layer was materialised by its reduce step (layer_gn_bwd)
     RUN(dyb_conv_dgrad_plain_raw(d, w.dy2 + c.dy, params + c.w, dx_buf, addend, w.conv, P.ws_conv,
                                  (out && P.fold_in_reduce) ? &ns : nullptr, st));
   else

@@ -1102,9 +1102,10 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // (replica-aware policy: split-K depth chosen for the replica-multiplied grid and, from "tp_min" replicas per launch on,
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
 // "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles; 0 = the 64x64 kernel), "tp_grid" (workgroups
-// its split-K aims for), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
+// its split-K aims for), "tp_batch_min" (> 0: the throughput schedule also for single-sequence launches of at least that batch;
+// off by default - emulator-checked, not yet measured), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1117,6 +1118,7 @@ struct DybSwitches {
     tp_kernel = env("DYB_TP_KERNEL", 1);
     tp_grid = env("DYB_TP_GRID", 512);
     tp_xcd = env("DYB_TP_XCD", 1);
+    tp_batch_min = env("DYB_TP_BATCH_MIN", 0);
   }
 };
 static DybSwitches& switches() {
@@ -1138,6 +1140,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_kernel")) return &s.tp_kernel;
   if (!strcmp(name, "tp_grid")) return &s.tp_grid;
   if (!strcmp(name, "tp_xcd")) return &s.tp_xcd;
+  if (!strcmp(name, "tp_batch_min")) return &s.tp_batch_min;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1311,7 +1314,7 @@ static unsigned long long* probe_for(int mode, const ConvDesc& d, long wgs) {
 
 // The throughput form (igemm_tp.inc) of one mode; same contract as run_igemm below.
 static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
-  if (fuse || dyb_bf16_current() || !dyb_throughput_mode()) return false;
+  if (fuse || dyb_bf16_current() || !dyb_throughput_mode(d.N)) return false;
   if (!switches().tp_kernel.load(std::memory_order_relaxed)) return false;
   // buffer addressing: 32-bit byte offsets, one mask bit per filter tap
   const size_t lim = 0x7fffffffu / sizeof(float);
@@ -1543,7 +1546,7 @@ bool dyb_conv_dgrad_k4_ok(const ConvDesc& d) {
   const DybSwitches& sw = switches();                   // k4_bwd on: 1.40 -> 1.31 ms per backward
   const int enabled = sw.k4_bwd.load(std::memory_order_relaxed), max_k = sw.k4_maxc.load(std::memory_order_relaxed);
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && !dyb_bf16_current() && !dyb_throughput_mode() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
+  return enabled && !dyb_bf16_current() && !dyb_throughput_mode(d.N) && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && d.stride == 1 && dyb_is_pow2(d.K) && d.K >= 128 &&
          d.K <= max_k && d.C % 128 == 0 && d.H * d.W <= 784;
 }
 // dx of the 1x1 conv `d` (never materialised as such) -> dm / partials of the producer's GroupNorm; *nch, *ncolb = the
@@ -1589,9 +1592,11 @@ int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w
 static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, const float* stats_in, const float* gamma,
                        const float* beta, float* stats_out, int relu);
 // ---- throughput schedule: plain gradient convolutions over a materialised dy (dyb_common.h) -----------------------------
-bool dyb_throughput_mode() {
+bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
-  return sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed);
+  if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;
+  const int bmin = sw.tp_batch_min.load(std::memory_order_relaxed);
+  return bmin > 0 && batch >= bmin;
 }
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
                              size_t ws_bytes, int* nslabs, hipStream_t st) {
@@ -1626,7 +1631,7 @@ bool dyb_conv_k4_ok(const ConvDesc& d) {
   // Cin <= 512: a K-step of this kernel costs ~1.9 us (measured: 8.6 / 11.8 / 20 us at 2 / 4 / 8 steps - every step is a
   // cold-L2 round trip), so beyond 4 steps the tiled kernel's split-K over more workgroups + the statistics launch is faster
   const bool batch_ok = d.N == 1 || (sw.k4_batch.load(std::memory_order_relaxed) && d.N <= 64);
-  return enabled && !dyb_bf16_current() && !dyb_throughput_mode() && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
+  return enabled && !dyb_bf16_current() && !dyb_throughput_mode(d.N) && batch_ok && d.R == 1 && d.S == 1 && d.pad == 0 && dyb_is_pow2(d.C) && d.C >= 128 && d.C <= max_c &&
          d.K % 128 == 0 && Ho * Wo <= 784;
 }
 // conv (+ producer GroupNorm in the loader when nf) -> y and its GroupNorm partials in one launch; *nchunks = partial count

@@ -252,6 +252,17 @@ def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand):
         be.lib.dyb_set_option(b"tp_min", 8)
 
 
+@pytest.mark.slow
+def test_hmr_engine_throughput_schedule_by_batch(be, ckpt_rand):
+    """The throughput schedule selected by the batch size of a single-sequence launch (switch tp_batch_min, off by default):
+    the whole engine at batch 2 against the reference module's golden g3."""
+    be.lib.dyb_set_option(b"tp_batch_min", 2)
+    try:
+        K.case_hmr_engine(be, golden, ckpt_rand)
+    finally:
+        be.lib.dyb_set_option(b"tp_batch_min", 0)
+
+
 @pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")
 @pytest.mark.parametrize("k4_batch", [0, 1])
 def test_hmr_engine_batch2_vs_reference_module(be, ckpt_rand, k4_batch):
