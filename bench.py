@@ -610,6 +610,10 @@ def main():
             out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)
+            out["second_order_full_losses_exact_hvp"] = sub_record(
+                device, "so_full_exact", 4, 1, 1, 1, "the reference's default term set in second-order mode with exact Hessian-vector "
+                "products for every level (--hvp_terms all: multi-pass form, verified on the CPU emulator; this is its first GPU run - a "
+                "timing, not a parity check)", full_losses=1, second_order=1, hvp="exact", hvp_terms="all")
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
         print(json.dumps(out))
