@@ -1029,8 +1029,9 @@ def case_hmr_hvp(be, ckpt, seed=5, B=1):
 
     # ---- device
     acts, ws = be.empty((L.act_floats,)), be.empty((L.ws_bytes // 4,))
-    check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(be.dev(img.numpy())), be.ptr(be.dev(init)), 3, be.ptr(acts), be.ptr(ws),
-                                 L.ws_bytes, be.stream), "hmr forward")
+    IMG, INIT = be.dev(img.numpy()), be.dev(init)
+    check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(IMG), be.ptr(INIT), 3, be.ptr(acts), be.ptr(ws), L.ws_bytes, be.stream),
+          "hmr forward")
     nd = int(be.lib.dyb_hmr_hvp_dual_floats(L.plan))
     dual = be.empty((nd,))
     check(be.lib.dyb_hmr_jvp_forward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), 3, be.ptr(ws), L.ws_bytes,
@@ -1042,8 +1043,9 @@ def case_hmr_hvp(be, ckpt, seed=5, B=1):
     d_state = np.zeros((B, 160), np.float32)
     d_state[:, :157] = c
     hv = be.zeros((L.n_params,))
-    check(be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(be.dev(d_state)),
-                                      be.ptr(be.zeros((B, 160))), 3, be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream), "jvp backward")
+    DS, TDS = be.dev(d_state), be.zeros((B, 160))          # named: the buffers must outlive the call
+    check(be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(DS), be.ptr(TDS), 3,
+                                      be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream), "jvp backward")
     H = L.unpack(torch.from_numpy(be.host(hv)))
     worst = {}
     for k in names:
