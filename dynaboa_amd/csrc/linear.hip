@@ -214,32 +214,50 @@ struct OuterArgs {
   const float* x[4];
   int lddy[4], ldx[4];
 };
-// grid (ceil(I4/64), ceil(O/4)), block 256: 64 float4-columns x 4 rows
+// grid (ceil(I4/64), ceil(O/32)), block 256: 64 float4-columns x 4 row lanes, each thread OUTER_ROWS = 8 rows (o = 32 by + ty + 4 j).
+// One output float4 per thread (4 rows per workgroup) made this kernel workgroup-dispatch-bound: 2304 workgroups for fc1 took
+// 21.7 us for one sequence and 73.7 k workgroups 815 us for 32 (~90 workgroups/us, 0.36 TB/s of a pure-write kernel;
+// profiles/r02_s5_kernel_stats_S32.csv).  Eight rows per thread = 8x fewer workgroups, x loaded once per (t, b) instead of
+// once per row; every output element still sums its (t, b) terms in the same order: results unchanged bit for bit.
+#define OUTER_ROWS 8
 __global__ __launch_bounds__(256) void linear_outer_kernel(OuterArgs a, int T, int B, int I, int O, float* __restrict__ dw,
                                                            int ldw, float* __restrict__ db, DybRep R) {
   DYB_REP_PROLOGUE(R);
   DYB_RB(R, dw); DYB_RB(R, db);
-  if (dyb_rep)
+  if (dyb_rep) {
+#pragma unroll
     for (int t = 0; t < 4; ++t) { a.dy[t] = dyb_rb(a.dy[t], R, dyb_rep); a.x[t] = dyb_rb(a.x[t], R, dyb_rep); }
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i4 = blockIdx.x * 64 + tx;
-  const int o = blockIdx.y * 4 + ty;
-  if (o >= O) return;
+  const int o0 = blockIdx.y * (4 * OUTER_ROWS) + ty;
   const bool live = i4 * 4 < I;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float bs = 0.f;
-  for (int t = 0; t < T; ++t) {
+  float4 acc[OUTER_ROWS];
+  float bs[OUTER_ROWS];
+#pragma unroll
+  for (int j = 0; j < OUTER_ROWS; ++j) { acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); bs[j] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                        // constant indices into the argument block: it stays in registers
+    if (t >= T) break;
     for (int b = 0; b < B; ++b) {
-      float d = a.dy[t][(size_t)b * a.lddy[t] + o];
-      bs += d;
-      if (live) {
-        float4 xv = *reinterpret_cast<const float4*>(a.x[t] + (size_t)b * a.ldx[t] + (size_t)i4 * 4);
-        acc.x += d * xv.x; acc.y += d * xv.y; acc.z += d * xv.z; acc.w += d * xv.w;
+      const float4 xv = *reinterpret_cast<const float4*>(a.x[t] + (size_t)b * a.ldx[t] + (size_t)(live ? i4 : 0) * 4);
+      const float* dyr = a.dy[t] + (size_t)b * a.lddy[t];
+#pragma unroll
+      for (int j = 0; j < OUTER_ROWS; ++j) {
+        const int o = o0 + 4 * j;
+        const float d = dyr[o < O ? o : O - 1];               // clamped: rows past the end are never stored
+        bs[j] += d;
+        acc[j].x += d * xv.x; acc[j].y += d * xv.y; acc[j].z += d * xv.z; acc[j].w += d * xv.w;
       }
     }
   }
-  if (live) *reinterpret_cast<float4*>(dw + (size_t)o * ldw + (size_t)i4 * 4) = acc;
-  if (blockIdx.x == 0 && tx == 0) db[o] = bs;
+#pragma unroll
+  for (int j = 0; j < OUTER_ROWS; ++j) {
+    const int o = o0 + 4 * j;
+    if (o >= O) continue;
+    if (live) *reinterpret_cast<float4*>(dw + (size_t)o * ldw + (size_t)i4 * 4) = acc[j];
+    if (blockIdx.x == 0 && tx == 0) db[o] = bs[j];
+  }
 }
 extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, const float* const* xs, const int* ldxs,
                                  int T, int B, int I, int O, float* dw, int ldw, float* db, hipStream_t st) {
@@ -251,7 +269,7 @@ extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, cons
     DYB_REQUIRE(a.ldx[t] % 4 == 0, DYB_ERR_UNSUPPORTED);
   }
   const DybRep& R = dyb_rep_current();
-  hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4), R.n), dim3(256), 0, st, a, T, B, I, O, dw,
+  hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4 * OUTER_ROWS), R.n), dim3(256), 0, st, a, T, B, I, O, dw,
                      ldw, db, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
