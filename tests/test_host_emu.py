@@ -444,3 +444,49 @@ def test_second_order_full_loss_set_exact_hvp_vs_oracle(emu_lib, gmm_t, smpl_tab
     # stem row is bounded by that, the rest by the Hessian-vector products' own accuracy
     assert e_so[0] < 6e-2 and (e_so[1:] < 1e-3).all(), e_so
     assert (e_so[1:] < 0.01 * gap[1:] + 1e-5).all(), (e_so, gap)
+
+
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~4 min under the emulator; set DYB_EMU_FULL=1")
+@pytest.mark.parametrize("throughput", [0, 1])
+def test_replica_group_on_emulator(emu_lib, throughput):
+    """S = 2 sequences in one launch grid (replicas: csrc/dyb_common.h) on the emulator against the same sequences adapted one
+    at a time: identical weights / Adam state with the single-sequence policy; with the replica-aware policy forced into the
+    throughput schedule (rep_split = 1, tp_min = 2: igemm_tp_kernel, materialised dy, replica-aware chunking) equal to fp32
+    rounding."""
+    from dynaboa_amd import assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    S = 2
+
+    def mk(r):
+        o = DB.frame_only_options(inner_step=1)
+        o.deferred_metrics = 1
+        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cpu")
+    frames = [[assets.make_frame(100 * r, 1, seed=22)] for r in range(S)]
+    singles = []
+    for r in range(S):
+        ad = mk(r)
+        ad.excute(frames[r], nframes=1)
+        st = ad.optimizer.state[ad.model.module.theta]
+        singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()))
+    emu_lib.dyb_set_option(b"rep_split", throughput)
+    emu_lib.dyb_set_option(b"tp_min", 2 if throughput else 8)
+    try:
+        ads = [mk(r) for r in range(S)]
+        grp = NS.ReplicaGroup(ads, 1)
+        grp.step([frames[r][0] for r in range(S)], 0)
+        grp.flush_metrics()
+    finally:
+        emu_lib.dyb_set_option(b"rep_split", 0)
+        emu_lib.dyb_set_option(b"tp_min", 8)
+    for r in range(S):
+        a = ads[r]
+        st = a.optimizer.state[a.model.module.theta]
+        if not throughput:
+            assert torch.equal(a.model.module.theta.detach(), singles[r][0]), r
+            assert torch.equal(st["exp_avg"], singles[r][1]) and torch.equal(st["exp_avg_sq"], singles[r][2]), r
+        else:
+            L = a.model.module._layout1
+            g1, g0 = L.unpack(st["exp_avg"]), L.unpack(singles[r][1])
+            worst = max(float((g1[k].double() - g0[k].double()).norm() / g0[k].double().norm().clamp_min(1e-30)) for k in g0)
+            assert worst < 5e-3, worst
+    assert not torch.equal(ads[0].model.module.theta.detach(), ads[1].model.module.theta.detach())
