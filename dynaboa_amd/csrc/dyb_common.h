@@ -135,6 +135,7 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
 // throughput schedule: "rep_split" switch on and >= "tp_min" (8) replicas in the current launch scope, or - switch
 // "tp_batch_min" > 0 (off by default: unmeasured) - a batch of at least that many images
 bool dyb_throughput_mode(int batch = 1);
+int dyb_gn_replica_share(int N);                // > 0: workgroups per image a GroupNorm launch may use (replica-aware chunking)
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,

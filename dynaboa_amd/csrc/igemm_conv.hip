@@ -1103,9 +1103,10 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
 // "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles; 0 = the 64x64 kernel), "tp_grid" (workgroups
 // its split-K aims for), "tp_batch_min" (> 0: the throughput schedule also for single-sequence launches of at least that batch;
-// off by default - emulator-checked, not yet measured), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
+// off by default - emulator-checked, not yet measured), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
+// under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1119,6 +1120,7 @@ struct DybSwitches {
     tp_grid = env("DYB_TP_GRID", 512);
     tp_xcd = env("DYB_TP_XCD", 1);
     tp_batch_min = env("DYB_TP_BATCH_MIN", 0);
+    tp_gn_wgs = env("DYB_TP_GN_WGS", 1024);
   }
 };
 static DybSwitches& switches() {
@@ -1141,6 +1143,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_grid")) return &s.tp_grid;
   if (!strcmp(name, "tp_xcd")) return &s.tp_xcd;
   if (!strcmp(name, "tp_batch_min")) return &s.tp_batch_min;
+  if (!strcmp(name, "tp_gn_wgs")) return &s.tp_gn_wgs;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1592,6 +1595,15 @@ int dyb_conv_dgrad_gn_raw(const ConvDesc& d, const GnBwdSrc& src, const float* w
 static void make_nfuse(GnFwdFuse& nf, const ConvDesc& d, const float* partials, const float* stats_in, const float* gamma,
                        const float* beta, float* stats_out, int relu);
 // ---- throughput schedule: plain gradient convolutions over a materialised dy (dyb_common.h) -----------------------------
+// workgroups per image the GroupNorm kernels' chunking may use when a launch covers several sequence replicas under the
+// throughput policy (0: the single-sequence sizing applies): "tp_gn_wgs" (1024) over all replicas of the launch
+int dyb_gn_replica_share(int N) {
+  if (!dyb_throughput_mode()) return 0;
+  const int reps = dyb_rep_current().n;
+  if (reps <= 1) return 0;
+  int w = switches().tp_gn_wgs.load(std::memory_order_relaxed) / (reps * (N > 0 ? N : 1));
+  return w < 1 ? 1 : w;
+}
 bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
   if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;

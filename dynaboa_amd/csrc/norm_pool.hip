@@ -190,8 +190,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// Under the throughput policy a launch covers many sequence replicas: the chunk counts then come from a workgroup budget over
+// the whole launch (dyb_gn_replica_share) - sized for one sequence they make every GroupNorm launch 3-8 k workgroups at 32
+// sequences, and workgroup dispatch (~90 / us) rather than HBM bounds it.  Producer and consumers of a partial block
+// call these functions inside the same replica scope, so they agree.
 static int gn_chunks(int HW, int N) {
-  int want = 256 / (N > 0 ? N : 1);
+  const int share = dyb_gn_replica_share(N);
+  int want = share > 0 ? share : 256 / (N > 0 ? N : 1);
   if (want < 1) want = 1;
   int nch = HW < want ? HW : want;
   int rows = dyb_cdiv(HW, nch);
@@ -203,7 +208,8 @@ static int gn_chunks(int HW, int N) {
 static int gn_chunks_bwd(int HW, int N, int C) {
   int CQ = C / 4;
   int colblocks = CQ > 256 ? CQ / 256 : 1;
-  int want = 256 / (N * colblocks);
+  const int share = dyb_gn_replica_share(N);
+  int want = share > 0 ? share / colblocks : 256 / (N * colblocks);
   if (want < 1) want = 1;
   if (want > 128) want = 128;
   int nch = HW < want ? HW : want;
@@ -252,7 +258,8 @@ extern "C" int dyb_groupnorm_apply_n(const float* y, const float* partials, int 
   DYB_REQUIRE(C % 16 == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   size_t total4 = (size_t)HW * (C / 4);
   int bpi = (int)((total4 + 1023) / 1024);
-  int cap = 1024 / N > 1 ? 1024 / N : 1;
+  const int share = dyb_gn_replica_share(N);
+  int cap = share > 0 ? share : (1024 / N > 1 ? 1024 / N : 1);
   if (bpi > cap) bpi = cap;
   if (bpi < 1) bpi = 1;
   GnResidual rs{residual, res_partials, res_gamma, res_beta, res_stats, res_nch};
@@ -592,7 +599,8 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
   const int CQ = C / 4;
   size_t total4 = (size_t)N * HW * CQ;
   int blocks = (int)((total4 + 1023) / 1024);
-  if (blocks > 2048) blocks = 2048;
+  const int share = dyb_gn_replica_share(1);           // the grid-stride apply: a workgroup budget per replica (all images)
+  if (blocks > (share > 0 ? 2 * share : 2048)) blocks = share > 0 ? 2 * share : 2048;
   int minb = dyb_cdiv(C, 64);
   if (blocks < minb) blocks = minb;
   const DybRep& R = dyb_rep_current();

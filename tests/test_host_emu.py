@@ -470,6 +470,7 @@ def test_replica_group_on_emulator(emu_lib, throughput):
         singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()))
     emu_lib.dyb_set_option(b"rep_split", throughput)
     emu_lib.dyb_set_option(b"tp_min", 2 if throughput else 8)
+    emu_lib.dyb_set_option(b"tp_gn_wgs", 16 if throughput else 1024)        # 8 GroupNorm chunks per image instead of up to 128
     try:
         ads = [mk(r) for r in range(S)]
         grp = NS.ReplicaGroup(ads, 1)
@@ -478,6 +479,7 @@ def test_replica_group_on_emulator(emu_lib, throughput):
     finally:
         emu_lib.dyb_set_option(b"rep_split", 0)
         emu_lib.dyb_set_option(b"tp_min", 8)
+        emu_lib.dyb_set_option(b"tp_gn_wgs", 1024)
     for r in range(S):
         a = ads[r]
         st = a.optimizer.state[a.model.module.theta]
