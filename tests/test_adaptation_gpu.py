@@ -62,6 +62,13 @@ def test_stream_matches_reference(tag):
         assert abs(float(np.mean(mpjpe)) - g["mpjpe"][step]) < 1e-3 * g["mpjpe"][step]
         assert abs(float(np.mean(pampjpe)) - g["pampjpe"][step]) < 2e-3 * g["pampjpe"][step]
         assert abs(float(pve) - g["pve"][step]) < 1e-3 * g["pve"][step]
+    assert_final_state_matches_golden(ad, g, theta0, opts)
+
+
+def assert_final_state_matches_golden(ad, g, theta0, opts):
+    """Adam step count, per-tensor norms of the Adam moments and of (theta_after - theta_before), sampled slices, teacher drift:
+    the end-of-stream half of the reference parity gate (shared with tests/test_headline_gpu.py)."""
+    hmr = ad.model.module
     st = ad.optimizer.state[hmr.theta]
     assert st["step"] == int(g["adam_steps"])
     L = hmr._layout1
@@ -73,14 +80,17 @@ def test_stream_matches_reference(tag):
     vn = np.array([float(v[k].double().norm()) for k in names])
     # norms: 2 % (ReLU-mask flips of near-zero activations perturb early-layer gradients at the 1e-3 level;
     # theta deltas are additionally quantised by fp32 rounding of p - 1e-5)
-    def close(x, ref, tol):
-        """per-tensor norms within `tol` for at least 98 % of the 169 tensors and within 2 * tol for all (a stream of up to 12
-        Adam steps lets one early-layer GroupNorm tensor drift past the bound through ReLU-flip noise: measured 2.1 % on v)"""
+    def close(x, ref, tol, what):
+        """per-tensor norms within `tol` for every tensor except the stem / layer1 GroupNorm affine tensors (4-64 floats each,
+        fed by the ReLU-flip noise of the whole network above them over up to 12 Adam steps: measured 2.1 % on v), which get
+        2 * tol.  The offenders are named in the failure message."""
         e = np.abs(np.asarray(x) - ref) / ref
-        assert (e < tol).mean() >= 0.98 and e.max() < 2 * tol, (float(e.max()), float((e < tol).mean()))
-    close(mn, g["m_norms"], 2e-2)
-    close(vn, g["v_norms"], 2e-2)
-    close(dn, g["delta_norms"], 5e-2)
+        early = np.array([k.startswith("bn1.") or (k.startswith("layer1.") and (".bn" in k or "downsample.1" in k)) for k in names])
+        bad = [(names[i], float(e[i])) for i in range(len(names)) if e[i] >= (2 * tol if early[i] else tol)]
+        assert not bad, (what, bad[:8])
+    close(mn, g["m_norms"], 2e-2, "m")
+    close(vn, g["v_norms"], 2e-2, "v")
+    close(dn, g["delta_norms"], 5e-2, "delta")
     for k in SLICE_PARAMS:
         assert cosine(m[k].flatten()[:256], g["m_" + k]) > 0.99, k     # early-layer slices carry ReLU-flip noise
         assert cosine(delta[k].flatten()[:256], g["d_" + k]) > 0.99, k

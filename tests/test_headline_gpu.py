@@ -1,0 +1,143 @@
+"""End-to-end parity of the BENCHMARKED configuration on cuda:0: a ReplicaGroup of S >= 8 sequences with
+the replica-aware policy switched on exactly as bench.py's Runner does (`rep_split` = 1, default `tp_min` / `tp_gn_wgs` /
+`tp_kernel`), i.e. every launch of the chain on the THROUGHPUT schedule (igemm_tp kernels, materialised dy, chunked GroupNorm).
+Replica 0 carries the seed-22 checkpoint and frames of golden g5_fo_inner3_frameonly = the REFERENCE's own
+Adaptor.adaptation() (dynaboa_benchmark.py:126-157) run frame after frame, and must meet the same assertions as
+test_adaptation_gpu.py::test_stream_matches_reference; every replica must also match the same sequence adapted alone
+(latency schedule)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from test_adaptation_gpu import assert_final_state_matches_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def headline_switches():
+    """bench.py Runner.__init__ for seqs > 1: rep_split = 1, everything else at its default."""
+    from dynaboa_amd import _lib
+    lib = _lib.load()
+    lib.dyb_set_option(b"rep_split", 1)
+    yield lib
+    lib.dyb_set_option(b"rep_split", 0)
+
+
+def _mk(r):
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    o = DB.frame_only_options(inner_step=3)
+    o.deferred_metrics = 1
+    # replica 0 = the golden's checkpoint (tools/make_golden.py: seed 22, smpl_seed 0, randomised GroupNorm affine)
+    return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True, smpl_seed=0), device="cuda:0")
+
+
+def _frames(S, NF):
+    from dynaboa_amd import assets
+    # replica 0 walks the golden's frames 0..NF-1; the others their own
+    return [[{k: v.to("cuda:0") for k, v in assets.make_frame((100 * r + s) if r else s, 1, seed=22).items()} for s in range(NF)]
+            for r in range(S)]
+
+
+def _singles(S, NF, frames, lib):
+    """every sequence adapted alone (one sequence per launch = latency schedule, whatever rep_split says)"""
+    out = []
+    for r in range(S):
+        ad = _mk(r)
+        res = ad.excute(frames[r], nframes=NF)
+        st = ad.optimizer.state[ad.model.module.theta]
+        out.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), res))
+        del ad
+    return out
+
+
+def _rel(x, y):
+    return float((x.double() - y.double()).norm() / y.double().norm())
+
+
+def _opt(lib, name):
+    import ctypes
+    v = ctypes.c_int(-1)
+    assert lib.dyb_get_option(name, ctypes.byref(v)) == 0, name
+    return int(v.value)
+
+
+def _throughput_schedule_is_on(lib, S):
+    return _opt(lib, b"rep_split") == 1 and S >= _opt(lib, b"tp_min") and _opt(lib, b"tp_kernel") >= 1
+
+
+@pytest.mark.parametrize("S", [8])
+def test_headline_schedule_stream_matches_reference_and_single_runs(S, headline_switches):
+    lib = headline_switches
+    assert _throughput_schedule_is_on(lib, S)
+    from dynaboa_amd import native_step as NS
+    g = golden("g5_fo_inner3_frameonly.npz")
+    NF = int(g["nframes"])
+    frames = _frames(S, NF)
+    singles = _singles(S, NF, frames, lib)
+    ads = [_mk(r) for r in range(S)]
+    theta0 = ads[0].model.module.theta.detach().clone()
+    grp = NS.ReplicaGroup(ads, NF)
+    for step in range(NF):
+        grp.step([frames[r][step] for r in range(S)], step)
+        # replica 0 against the reference's run, frame by frame
+        up = float(grp.stepper.losses(step, 3, 0)[3])
+        assert abs(up - g["upper_loss"][step]) < 1e-4 * abs(g["upper_loss"][step]), (step, up, g["upper_loss"][step])
+        a0 = ads[0]
+        a0.model.eval()
+        with torch.no_grad():
+            r_, s_, c_ = a0.model(frames[0][step]["image"])
+            j_ = a0.decode_smpl_params(r_, s_)["s3d"]
+        for k, v in dict(rotmat=r_, shape=s_, cam=c_, joints=j_).items():
+            assert rel_err(v.cpu().numpy(), g[f"pred{step}_{k}"]) < 1e-3, (step, k)     # north_star: 1e-3 rel
+    fl = grp.flush_metrics()
+    for step in range(NF):
+        assert abs(float(np.mean(fl[0]["mpjpe"][step])) - g["mpjpe"][step]) < 1e-3 * g["mpjpe"][step]
+        assert abs(float(np.mean(fl[0]["pampjpe"][step])) - g["pampjpe"][step]) < 2e-3 * g["pampjpe"][step]
+        assert abs(float(np.ravel(fl[0]["pve"])[step]) - g["pve"][step]) < 1e-3 * g["pve"][step]
+    assert_final_state_matches_golden(ads[0], g, theta0, {})
+    # every replica against itself adapted alone: summation order differs (replica-aware split, chunked GroupNorm), arithmetic not
+    for r in range(S):
+        a = ads[r]
+        st = a.optimizer.state[a.model.module.theta]
+        assert st["step"] == NF
+        assert _rel(a.model.module.theta.detach(), singles[r][0]) < 1e-6, r
+        assert _rel(st["exp_avg"], singles[r][1]) < 5e-3, r
+        assert _rel(st["exp_avg_sq"], singles[r][2]) < 1e-2, r
+        for k in ("mpjpe", "pampjpe", "pve"):
+            np.testing.assert_allclose(np.ravel(np.array(fl[r][k], np.float64)), np.ravel(np.array(singles[r][3][k], np.float64)), rtol=2e-3)
+    assert not torch.equal(ads[0].model.module.theta.detach(), ads[1].model.module.theta.detach())
+
+
+def test_headline_32_sequences_one_frame(headline_switches):
+    """S = 32 (bench.py's default sequences per GPU), one frame: replica 0 against the reference's first frame, every replica
+    against its own single-sequence run."""
+    lib = headline_switches
+    S, NF = 32, 1
+    assert _throughput_schedule_is_on(lib, S)
+    from dynaboa_amd import native_step as NS
+    g = golden("g5_fo_inner3_frameonly.npz")
+    frames = _frames(S, NF)
+    singles = _singles(S, NF, frames, lib)
+    ads = [_mk(r) for r in range(S)]
+    grp = NS.ReplicaGroup(ads, NF)
+    grp.step([frames[r][0] for r in range(S)], 0)
+    up = float(grp.stepper.losses(0, 3, 0)[3])
+    assert abs(up - g["upper_loss"][0]) < 1e-4 * abs(g["upper_loss"][0])
+    a0 = ads[0]
+    a0.model.eval()
+    with torch.no_grad():
+        r_, s_, c_ = a0.model(frames[0][0]["image"])
+        j_ = a0.decode_smpl_params(r_, s_)["s3d"]
+    for k, v in dict(rotmat=r_, shape=s_, cam=c_, joints=j_).items():
+        assert rel_err(v.cpu().numpy(), g[f"pred0_{k}"]) < 1e-3, k
+    fl = grp.flush_metrics()
+    assert abs(float(np.mean(fl[0]["mpjpe"][0])) - g["mpjpe"][0]) < 1e-3 * g["mpjpe"][0]
+    for r in range(S):
+        a = ads[r]
+        st = a.optimizer.state[a.model.module.theta]
+        assert _rel(a.model.module.theta.detach(), singles[r][0]) < 1e-6, r
+        assert _rel(st["exp_avg"], singles[r][1]) < 5e-3, r
+        np.testing.assert_allclose(np.ravel(np.array(fl[r]["mpjpe"], np.float64)), np.ravel(np.array(singles[r][3]["mpjpe"], np.float64)), rtol=2e-3)
