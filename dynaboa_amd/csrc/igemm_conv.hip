@@ -1101,7 +1101,8 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // producer's GroupNorm-backward reduce), "k4_batch" (both at batch > 1), "k4_maxc" (their channel limit), "rep_split"
 // (replica-aware policy: split-K depth chosen for the replica-multiplied grid and, from "tp_min" replicas per launch on,
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
-// "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles; 0 = the 64x64 kernel), "tp_grid" (workgroups
+// "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles, 2 = its software-pipelined loop (default), 1 = round 2's
+// phase-separated loop; 0 = the 64x64 kernel), "tp_grid" (workgroups
 // its split-K aims for), "tp_batch_min" (> 0: the throughput schedule also for single-sequence launches of at least that batch;
 // off by default - emulator-checked, not yet measured), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
@@ -1116,7 +1117,7 @@ struct DybSwitches {
     rep_split = env("DYB_REP_SPLIT", 0);
     bf16 = 0;
     tp_min = env("DYB_TP_MIN", 8);
-    tp_kernel = env("DYB_TP_KERNEL", 1);
+    tp_kernel = env("DYB_TP_KERNEL", 2);
     tp_grid = env("DYB_TP_GRID", 512);
     tp_xcd = env("DYB_TP_XCD", 1);
     tp_batch_min = env("DYB_TP_BATCH_MIN", 0);
@@ -1372,15 +1373,24 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.addend = split ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
+  // "tp_kernel" 2 (default): the software-pipelined loop (PIPE); 1: round 2's phase-separated loop (also what the phase probe and
+  // weight gradients over maps too small for the branch-free pixel walk use)
+  const bool pipe = switches().tp_kernel.load(std::memory_order_relaxed) >= 2 && !g.probe &&
+                    !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho);
   GnFwdFuse nf{};
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 't' : mode == MODE_DGRAD ? 'u' : 'v', g.nsplit);
-#define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)                                                                                \
-  do {                                                                                                                   \
-    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, nf, R); \
-    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_>), grid, dim3(256), 0, st, g, nf, R);                     \
+#define DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, P_)                                                                                 \
+  do {                                                                                                                        \
+    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, nf, R); \
+    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), 0, st, g, nf, R);                     \
+  } while (0)
+#define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)            \
+  do {                                               \
+    if (pipe) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 1);  \
+    else DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 0);       \
   } while (0)
 #define DYB_TP_LAUNCH(M_, FA_)                        \
   do {                                                \
@@ -1400,6 +1410,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   }
 #undef DYB_TP_LAUNCH
 #undef DYB_TP_LAUNCH2
+#undef DYB_TP_LAUNCH3
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // call these functions inside the same replica scope, so they agree.
 static int gn_chunks(int HW, int N) {
   const int share = dyb_gn_replica_share(N);
-  int want = share > 0 ? share : 256 / (N > 0 ? N : 1);
+  const int plan = 256 / (N > 0 ? N : 1);            // what the partial slots are sized for (plans are made outside any replica scope)
+  int want = share > 0 && share < plan ? share : plan;   // the share only ever lowers the count: never past the slot (tp_min / tp_gn_wgs are public switches)
   if (want < 1) want = 1;
   int nch = HW < want ? HW : want;
   int rows = dyb_cdiv(HW, nch);
@@ -209,7 +210,8 @@ static int gn_chunks_bwd(int HW, int N, int C) {
   int CQ = C / 4;
   int colblocks = CQ > 256 ? CQ / 256 : 1;
   const int share = dyb_gn_replica_share(N);
-  int want = share > 0 ? share / colblocks : 256 / (N * colblocks);
+  const int plan = 256 / (N * colblocks);            // plan-time sizing; the replica share may only lower it (slot capacity)
+  int want = share > 0 && share / colblocks < plan ? share / colblocks : plan;
   if (want < 1) want = 1;
   if (want > 128) want = 128;
   int nch = HW < want ? HW : want;

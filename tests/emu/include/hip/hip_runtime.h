@@ -138,6 +138,14 @@ static inline T __shfl_down(T v, int d) {
   emu::wave_exchange(&v, &r, src > 63 ? emu::lane_id() : src, (int)sizeof(T));
   return r;
 }
+// v_mov_b32_dpp with a quad_perm control (ctrl < 0x100): lane l reads lane (l & ~3) | ((ctrl >> 2 (l & 3)) & 3)
+static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+  if (ctrl >= 0x100) { fprintf(stderr, "emu: only quad_perm DPP controls are emulated\n"); abort(); }
+  const int l = emu::lane_id();
+  int r;
+  emu::wave_exchange(&src, &r, (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3), 4);
+  return r;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z)                          \
   ({                                                                                    \
     float emu_c_[16];                                                                   \

@@ -138,6 +138,9 @@ def test_headline_32_sequences_one_frame(headline_switches):
     for r in range(S):
         a = ads[r]
         st = a.optimizer.state[a.model.module.theta]
-        assert _rel(a.model.module.theta.detach(), singles[r][0]) < 1e-6, r
+        # after ONE Adam step every element has moved by lr * g / (|g| + eps) = +-3e-6, whatever its size: elements whose gradient is
+        # rounding noise flip sign between summation orders (measured 1.3e-6 relative on theta = ~0.5 % of the elements; the 4-frame
+        # test above holds 1e-6).  The first moment m = 0.1 g is linear in the gradient and is the real check.
+        assert _rel(a.model.module.theta.detach(), singles[r][0]) < 5e-6, r
         assert _rel(st["exp_avg"], singles[r][1]) < 5e-3, r
         np.testing.assert_allclose(np.ravel(np.array(fl[r]["mpjpe"], np.float64)), np.ravel(np.array(singles[r][3]["mpjpe"], np.float64)), rtol=2e-3)

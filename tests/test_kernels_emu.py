@@ -27,14 +27,17 @@ def test_conv(be, cfg):
     K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
 
 
-@pytest.fixture
-def throughput_mode(be):
-    """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas)."""
+@pytest.fixture(params=[2, 1], ids=["pipelined", "phased"])
+def throughput_mode(be, request):
+    """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas), once with each loop
+    form of igemm_tp_kernel (tp_kernel 2 = software-pipelined, the default; 1 = round 2's phase-separated loop)."""
     be.lib.dyb_set_option(b"rep_split", 1)
     be.lib.dyb_set_option(b"tp_min", 1)
+    be.lib.dyb_set_option(b"tp_kernel", request.param)
     yield
     be.lib.dyb_set_option(b"rep_split", 0)
     be.lib.dyb_set_option(b"tp_min", 8)
+    be.lib.dyb_set_option(b"tp_kernel", 2)
 
 
 @pytest.mark.parametrize("cfg", [
@@ -44,6 +47,8 @@ def throughput_mode(be):
     (2, 10, 10, 64, 64, 3, 2, 1),      # Cout = 64: 256x64 forms, stride 2, batch 2, split-K
     (1, 8, 8, 128, 64, 1, 2, 0),       # 1x1 stride 2 (downsample)
     (1, 20, 20, 4, 64, 7, 2, 3),       # stem: forward stays on the 64x64 kernel (Cin = 4), weight gradient takes the 256x64 form
+    (1, 4, 4, 64, 128, 3, 1, 1),       # 4x4 map: a K-step of the weight gradient spans whole images (pipelined form falls back to the pixel-walk loop)
+    (2, 5, 6, 32, 128, 3, 1, 1),       # 5x6 map, batch 2: one wrap per K-step of the branch-free pixel walk, twice
 ])
 def test_conv_throughput_kernel(be, throughput_mode, cfg):
     """igemm_tp_kernel (the 128x128-class tiles the throughput schedule runs) through the plain entry points: forward,
