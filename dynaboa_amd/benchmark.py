@@ -267,24 +267,36 @@ class Adaptor(BaseAdaptor):
         f, slot = self._native.adapt_frame(batch, side_stream=self._side)
         return self._native_bookkeeping(f, slot)
 
-    def _adapt_native_full(self, batch):
-        """The reference's full term set through the native stepper: one C call for the whole frame incl. the dynamic loop."""
-        o, ns = self.options, self._native
-        K = o.inner_step
+    def _native_full_inputs(self, batch):
+        """-> (hist, exemplars) of this frame for the native full-term stepper: the history pair of the motion term (None while
+        there is no frame `interval` steps back) and the labelled exemplars when they do not depend on the level's feature (the
+        synthetic bundle; None = the stepper's retrieval callback asks self.retrieval per level)."""
+        o = self.options
         hist = None
         if o.use_motion and (self.global_step - o.interval) > 0 and (o.use_temporal_losses_upper or o.use_temporal_losses_lower):
             hist = self.get_hist()
         ex = None
         if (o.lower_level_mixtrain or o.upper_level_mixtrain) and self.bundle is not None:
             ex = self._last_h36m = self.retrieval(None)          # the synthetic bundle's exemplars depend on the step only
-        f, slot, extra = ns.adapt_frame_full(batch, hist, ex)
+        return hist, ex
+
+    def _adapt_native_full(self, batch):
+        """The reference's full term set through the native stepper: one C call for the whole frame incl. the dynamic loop."""
+        hist, ex = self._native_full_inputs(batch)
+        f, slot, extra = self._native.adapt_frame_full(batch, hist, ex)
+        return self._native_full_bookkeeping(f, slot, extra, hist)
+
+    def _native_full_bookkeeping(self, f, slot, extra, hist):
+        """What adaptation() leaves behind after a full-term frame (replica `_native_replica` of the stepper)."""
+        o, ns, rr = self.options, self._native, getattr(self, "_native_replica", 0)
+        K = o.inner_step
         log = self.fit_losses
         for i in range(K):
-            self.kp2dlosses_lower.append(ns.level_row(f, i)[0])
+            self.kp2dlosses_lower.append(ns.level_row(f, i, rr)[0])
         rows = ((("ll", K - 1, bool(o.use_temporal_losses_lower), bool(o.lower_level_mixtrain)),) if K > 0 else ()) + \
                (("ul", K + min(extra, o.optim_steps if o.dynamic_boa else 0), bool(o.use_temporal_losses_upper), bool(o.upper_level_mixtrain)),)
         for tag, row, temporal, mix in rows:
-            r = ns.level_row(f, row)
+            r = ns.level_row(f, row, rr)
             log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"], log[f"{tag}/unlabelloss"] = r[0], r[1], r[2], r[3]
             if temporal and o.use_meanteacher:
                 for j, k in enumerate(("s2dloss", "s3dloss", "shape_loss", "pose_loss", "loss")):
@@ -295,13 +307,13 @@ class Adaptor(BaseAdaptor):
                 for j, k in enumerate(("labled_s2dloss", "labled_s3dloss", "labled_shape_loss", "labled_pose_loss", "labled_loss")):
                     log[f"{tag}/{k}"] = r[10 + j]
             log[f"{tag}/total"] = r[15]
-        self.kp2dlosses_upper[self.global_step] = ns.level_row(f, K)[0]
+        self.kp2dlosses_upper[self.global_step] = ns.level_row(f, K, rr)[0]
         out = (None, None, None)
         nfinal = 1 + (min(extra, o.optim_steps) if o.dynamic_boa else 0)
         tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', k) for k in range(nfinal)]
         stats_m, stats_p = [], []
         for tag in tags:
-            v = ns.record_views(slot)
+            v = ns.record_views(slot, rr)
             slot += 1
             if o.deferred_metrics:
                 self._pending.append(dict(step=self.global_step, tag=tag, **v))
@@ -317,7 +329,7 @@ class Adaptor(BaseAdaptor):
         if self.global_step < len(self.mpjpe_statistics):
             self.mpjpe_statistics[self.global_step], self.pampjpe_statistics[self.global_step] = stats_m, stats_p
         if o.dynamic_boa:
-            gl = ns.gate_log[f]
+            gl = ns.gate_log[rr, f]
             self.feat_sims[self.global_step] = [{i: {"cos": gl[k, i]} for i in range(15)} for k in range(nfinal)]
             log["feat_sim/cos_sim"] = gl[nfinal - 1, :15].sum() / 14          # the reference divides by the last index (base_adaptor.py:218)
             self.optimized_step = extra

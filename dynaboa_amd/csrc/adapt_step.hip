@@ -51,6 +51,7 @@ int dyb_aux_loss_terms(int, int, int, float, const float*, const float*, int, co
                        const float*, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 int dyb_hmr_feature_info(const void*, int, long long*, int*, int*);
 }
+int dyb_adam_step_rep(float*, const float*, float*, float*, float, float, const float*, const float*, float, size_t, hipStream_t);   // optim.hip
 
 #define STATE_LD 160
 #define NV 6890
@@ -124,7 +125,9 @@ __global__ void copy4_kernel(const float* __restrict__ src, float* __restrict__ 
 // the 16-float log row of one level of the full loss set: frame {s2d, shape prior, pose prior, total} | teacher {s2d, s3d, shape,
 // pose, loss} | motion | labelled {s2d, s3d, shape, pose, loss} | level total = frame + wt*teacher + wm*motion + wl*labelled
 __global__ void level_log_kernel(const float* __restrict__ frame4, const float* __restrict__ teach5, const float* __restrict__ motion5,
-                                 const float* __restrict__ label5, float wt, float wm, float wl, float* __restrict__ row16) {
+                                 const float* __restrict__ label5, float wt, float wm, float wl, float* __restrict__ row16, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, frame4); DYB_RB(Rp, teach5); DYB_RB(Rp, motion5); DYB_RB(Rp, label5); DYB_RB(Rp, row16);
   if (threadIdx.x != 0) return;
   float total = frame4[3];
   for (int i = 0; i < 4; ++i) row16[i] = frame4[i];
@@ -144,7 +147,11 @@ struct FeatCosArgs {
   int rows[15], cols[15], ld[15];
 };
 __global__ __launch_bounds__(1024) void feat_cos_kernel(const float* __restrict__ A, const float* __restrict__ Bp, FeatCosArgs fa,
-                                                        float eps, float* __restrict__ out_dev, volatile float* out_host, float seq) {
+                                                        float eps, float* __restrict__ out_dev, volatile float* out_host, float seq,
+                                                        DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, A); DYB_RB(Rp, Bp); DYB_RB(Rp, out_dev);
+  if (out_host) out_host += 16 * dyb_rep;             // pinned host memory: 16 floats per physical replica
   __shared__ float sm[16][3];
   const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* a = A + fa.off[f];
@@ -175,9 +182,9 @@ __global__ __launch_bounds__(1024) void feat_cos_kernel(const float* __restrict_
 }
 
 // replica r's frame inputs (separate caller tensors) into its staging area inside the workspace, one launch for all replicas
-#define DYB_MAX_REPLICAS 64
 struct GatherArgs {
-  const float* src[5][DYB_MAX_REPLICAS];     // image, kp2d, gt_pose, gt_betas, gender (int64 viewed as 2 floats)
+  const float* src[5][DYB_MAX_REPLICAS];     // up to five inputs per launch, per PHYSICAL replica (e.g. image, kp2d, gt_pose, gt_betas,
+                                             // gender - int64 viewed as 2 floats); NULL: nothing to copy
   float* dst[5];                             // replica 0's staging buffers
   unsigned n[5];                             // floats per input
 };
@@ -218,6 +225,7 @@ struct Stepper {
   float* gate_log = nullptr;          // device: [loss_capacity][1 + optim_steps][16] cosines of every gate evaluation
   float* feat5_out = nullptr;         // [B][2048] the level's pooled feature for the retrieval callback
   int (*retrieve)(void*, int, const void**) = nullptr;
+  int (*retrieve_rep)(void*, int, int, const void**) = nullptr;     // replica groups: (user, level, physical replica, out[5])
   void* retrieve_user = nullptr;
   FeatCosArgs fca{};
   float gate_seq = 0.f;
@@ -228,8 +236,11 @@ struct Stepper {
   float *hg_cam = nullptr, *hg_joints = nullptr;                                                 // ... on the history pass
   float *vals_t = nullptr, *vals_m = nullptr, *vals_l = nullptr;
   int nrep = 1;                       // sequence replicas stepped in lockstep by every launch (dyb_common.h)
+  int active[DYB_MAX_REPLICAS] = {};  // the replicas the next frame step covers (physical indices, ascending); default: all
+  int nactive = 0;                    // 0 = all
+  long long adam_t_rep[DYB_MAX_REPLICAS] = {};   // Adam steps taken, per replica (they differ once the dynamic loop or ragged streams do)
   size_t blob = 0;                    // workspace bytes of ONE replica
-  float* in_stage[5] = {};            // image, kp2d, gt_pose, gt_betas, gender staging (replica 0; nrep > 1 only)
+  float* in_stage[12] = {};           // staging of the frame inputs, in IN_* order (replica 0; nrep > 1 only)
   double lr = 3e-6, beta1 = 0.5, beta2 = 0.9, eps = 1e-8, fastlr = 8e-6, w2d = 10.0, wshape = 2e-6, wpose = 1e-4;
   long long adam_t = 0;
   // caller-owned state and tables (device pointers)
@@ -346,6 +357,15 @@ static size_t carve(Stepper& S, char* base) {
     S.in_stage[2] = take_f(B * 72);
     S.in_stage[3] = take_f(B * 10);
     S.in_stage[4] = take_f(B * 2);
+    if (S.full) {                                // history frame (image, kp2d) and the labelled exemplars (img, kp, pose, betas, pose_3d)
+      S.in_stage[5] = take_f(B * 3 * (size_t)S.H * S.W);
+      S.in_stage[6] = take_f(B * NJ * 3);
+      S.in_stage[7] = take_f(B * 3 * (size_t)S.H * S.W);
+      S.in_stage[8] = take_f(B * NJ * 3);
+      S.in_stage[9] = take_f(B * 72);
+      S.in_stage[10] = take_f(B * 10);
+      S.in_stage[11] = take_f(B * 24 * 4);
+    }
   }
   return off;
 }
@@ -391,7 +411,16 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "eval_lower") S->eval_lower = (int)v;
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
-  else if (k == "adam_step") S->adam_t = v;
+  else if (k == "adam_step") {
+    S->adam_t = v;
+    for (int r = 0; r < DYB_MAX_REPLICAS; ++r) S->adam_t_rep[r] = v;
+  }
+  else if (k.compare(0, 10, "adam_step_") == 0) {     // "adam_step_<replica>": replicas may join with different histories
+    const int r = atoi(k.c_str() + 10);
+    DYB_REQUIRE(r >= 0 && r < DYB_MAX_REPLICAS, DYB_ERR_ARG);
+    S->adam_t_rep[r] = v;
+    if (v > S->adam_t) S->adam_t = v;
+  }
   else if (k == "full") S->full = (int)v;
   else if (k == "temporal_lower") S->temporal_lower = (int)v;
   else if (k == "temporal_upper") S->temporal_upper = (int)v;
@@ -453,6 +482,7 @@ extern "C" int dyb_stepper_set_p(void* stepper, const char* key, const void* p) 
   else if (k == "gate_log") S->gate_log = (float*)p;
   else if (k == "feat5_out") S->feat5_out = (float*)p;
   else if (k == "retrieve_fn") S->retrieve = (int (*)(void*, int, const void**))p;
+  else if (k == "retrieve_rep_fn") S->retrieve_rep = (int (*)(void*, int, int, const void**))p;
   else if (k == "retrieve_user") S->retrieve_user = (void*)p;
   else {
     for (int g = 0; g < 3; ++g) {
@@ -475,6 +505,10 @@ extern "C" long long dyb_stepper_get_i(const void* stepper, const char* key) {
   if (!S || !key) return -1;
   const std::string k(key);
   if (k == "adam_step") return S->adam_t;
+  if (k.compare(0, 10, "adam_step_") == 0) {          // "adam_step_<replica>"
+    const int r = atoi(k.c_str() + 10);
+    return (r >= 0 && r < S->nrep) ? S->adam_t_rep[r] : -1;
+  }
   if (k == "record_floats") return (long long)a64((size_t)S->B * 85 + 1);
   if (k == "loss_floats") return (S->full ? 16 : 4) * (long long)(S->inner_step + 1 + (S->full && S->dynamic ? S->optim_steps : 0));
   if (k == "slots_per_frame") return (S->eval_lower ? S->inner_step : 0) + 1 + (S->full && S->dynamic ? S->optim_steps : 0);
@@ -516,11 +550,13 @@ extern "C" int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes,
     HIPOK(hipMemsetAsync(reinterpret_cast<char*>(S->main.d_state) + (size_t)r * S->blob, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
   }
   if (S->full) {
-    DYB_REQUIRE(S->nrep == 1, DYB_ERR_UNSUPPORTED);
-    HIPOK(hipMemsetAsync(S->zeros, 0, (size_t)S->B * 216 * sizeof(float), st));
-    HIPOK(hipMemsetAsync(S->grads2, 0, S->n_params * sizeof(float), st));
-    HIPOK(hipMemsetAsync(S->ex.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
-    HIPOK(hipMemsetAsync(S->hist.d_state, 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+    for (int r = 0; r < S->nrep; ++r) {
+      auto at = [&](float* p0) { return reinterpret_cast<char*>(p0) + (size_t)r * S->blob; };
+      HIPOK(hipMemsetAsync(at(S->zeros), 0, (size_t)S->B * 216 * sizeof(float), st));
+      HIPOK(hipMemsetAsync(at(S->grads2), 0, S->n_params * sizeof(float), st));
+      HIPOK(hipMemsetAsync(at(S->ex.d_state), 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+      HIPOK(hipMemsetAsync(at(S->hist.d_state), 0, (size_t)S->B * STATE_LD * sizeof(float), st));
+    }
     for (int f = 0; f < 15; ++f) {
       long long off = 0;
       int dims[4] = {0, 0, 0, 0}, rs = 0;
@@ -617,6 +653,20 @@ static int issue_side_work(Stepper& S, hipStream_t side) {
   }
   return DYB_OK;
 }
+// Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
+static int adam_scope(Stepper& S, hipStream_t st) {
+  const DybRep& R = dyb_rep_current();
+  float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
+  for (int i = 0; i < R.n; ++i) {
+    const int r = R.map[i];
+    const double t = (double)(++S.adam_t_rep[r]);
+    ss[r] = (float)(S.lr / (1.0 - pow(S.beta1, t)));
+    bc[r] = (float)sqrt(1.0 - pow(S.beta2, t));
+    if (S.adam_t_rep[r] > S.adam_t) S.adam_t = S.adam_t_rep[r];
+  }
+  return dyb_adam_step_rep(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, S.n_params, st);
+}
 static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
                             const long long* gender, int record_slot, int loss_slot, hipStream_t st, hipStream_t aux,
                             hipStream_t side) {
@@ -686,12 +736,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     HIPOK(hipStreamWaitEvent(st, S.e_side, 0));
     S.side_pending = false;
   }
-  S.adam_t += 1;
-  const double t = (double)S.adam_t;
-  const double step_size = S.lr / (1.0 - pow(S.beta1, t));
-  const double bc2_sqrt = sqrt(1.0 - pow(S.beta2, t));
-  RUN(dyb_adam_step(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, (float)step_size, (float)bc2_sqrt,
-                    (float)S.eps, n, st));
+  RUN(adam_scope(S, st));
   // final inference() with the updated weights (dynaboa_benchmark.py:156): in line, or - with a side stream - owed to the
   // next call / dyb_stepper_join (the caller keeps this frame's inputs alive until then)
   if (side) {
@@ -720,6 +765,9 @@ static int pass_backward_ext(Stepper& S, Pass& P, const float* theta, float* gra
 }
 enum { IN_IMAGE = 0, IN_KP, IN_GT_POSE, IN_GT_BETAS, IN_GENDER, IN_HIST_IMAGE, IN_HIST_KP, IN_EX_IMG, IN_EX_KP, IN_EX_POSE,
        IN_EX_BETAS, IN_EX_POSE3D, IN_COUNT };
+// copy `nk` inputs (kinds k0 .. k0+nk-1 in IN_* order) of every replica of the current scope from the callers' separate tensors
+// into the replicas' staging areas, one launch: src[(kind - k0) * ld + physical replica] (NULL: nothing to copy)
+static int stage_inputs(Stepper& S, const void* const* src, int ld, int k0, int nk, hipStream_t st);
 struct FullCtx {
   const void* in[IN_COUNT];
   float* losslog;       // this frame's rows
@@ -760,8 +808,25 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   }
   if (label) {
     // retrieval (base_adaptor.py:82-96) happens on the host: hand it the pooled feature of this level's forward
-    if (S.retrieve) {
+    if (S.nrep > 1 && S.retrieve_rep) {
       DYB_REQUIRE(S.feat5_out, DYB_ERR_ARG);
+      const DybRep& R = dyb_rep_current();
+      RUN(dyb_scale_add(nullptr, P.acts + S.fca.off[5], nullptr, S.feat5_out, (size_t)B * 2048, st));     // every replica's feature, one launch
+      const void* exin[5 * DYB_MAX_REPLICAS];
+      for (int k = 0; k < 5 * DYB_MAX_REPLICAS; ++k) exin[k] = nullptr;
+      for (int i = 0; i < R.n; ++i) {
+        const int r = R.map[i];
+        const void* one[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (S.retrieve_rep(S.retrieve_user, level_index, r, one) != 0) return DYB_ERR_ARG;
+        for (int k = 0; k < 5; ++k) {
+          DYB_REQUIRE(one[k], DYB_ERR_ARG);
+          exin[k * DYB_MAX_REPLICAS + r] = one[k];
+        }
+      }
+      RUN(stage_inputs(S, exin, DYB_MAX_REPLICAS, IN_EX_IMG, 5, st));
+      for (int k = 0; k < 5; ++k) C.in[IN_EX_IMG + k] = S.in_stage[IN_EX_IMG + k];
+    } else if (S.retrieve) {
+      DYB_REQUIRE(S.feat5_out && S.nrep == 1, DYB_ERR_ARG);
       RUN(dyb_scale_add(nullptr, P.acts + S.fca.off[5], nullptr, S.feat5_out, (size_t)0 + (size_t)B * 2048, st));   // B == 1: contiguous
       const void* exin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
       if (S.retrieve(S.retrieve_user, level_index, exin) != 0) return DYB_ERR_ARG;
@@ -777,9 +842,10 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
                            S.exg_joints, nullptr, nullptr, st));
   }
   if (C.losslog) {
-    hipLaunchKernelGGL(level_log_kernel, dim3(1), dim3(64), 0, st, (const float*)P.losses, teacher ? (const float*)S.vals_t : nullptr,
-                       motion ? (const float*)S.vals_m : nullptr, label ? (const float*)S.vals_l : nullptr, (float)S.teacher_w,
-                       (float)S.motion_w, (float)S.label_w, C.losslog + 16 * C.level_row);
+    hipLaunchKernelGGL(level_log_kernel, dim3(1, 1, dyb_rep_current().n), dim3(64), 0, st, (const float*)P.losses,
+                       teacher ? (const float*)S.vals_t : nullptr, motion ? (const float*)S.vals_m : nullptr,
+                       label ? (const float*)S.vals_l : nullptr, (float)S.teacher_w, (float)S.motion_w, (float)S.label_w,
+                       C.losslog + 16 * C.level_row, dyb_rep_current());
     DYB_CHECK_LAUNCH();
     ++C.level_row;
   }
@@ -798,53 +864,110 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   return DYB_OK;
 }
 static int adam_and_teacher(Stepper& S, hipStream_t st) {
-  S.adam_t += 1;
-  const double t = (double)S.adam_t;
-  const double step_size = S.lr / (1.0 - pow(S.beta1, t));
-  const double bc2_sqrt = sqrt(1.0 - pow(S.beta2, t));
-  RUN(dyb_adam_step(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, (float)step_size, (float)bc2_sqrt,
-                    (float)S.eps, S.n_params, st));
+  RUN(adam_scope(S, st));
   if (S.use_teacher && S.teacher) RUN(dyb_ema_update(S.teacher, S.theta, (float)S.alpha, S.n_params, st));   // base_adaptor.py:193-201
   return DYB_OK;
 }
-// features of two forwards -> 15 cosines (device log row + host-visible copy) ; returns cos[12] read from the host copy
+// features of two forwards -> 15 cosines per replica of the current scope (device log row + host-visible copy); cos12[r] (indexed
+// by PHYSICAL replica) = cos[12] read from the host copy
 static int gate_cosine(Stepper& S, const float* actsA, const float* actsB, float* log_row, float* cos12, hipStream_t st) {
   DYB_REQUIRE(S.gate_host, DYB_ERR_ARG);
+  const DybRep& R = dyb_rep_current();
   S.gate_seq += 1.f;
-  hipLaunchKernelGGL(feat_cos_kernel, dim3(15), dim3(1024), 0, st, actsA, actsB, S.fca, 1e-12f, log_row, S.gate_host, S.gate_seq);
+  hipLaunchKernelGGL(feat_cos_kernel, dim3(15, 1, R.n), dim3(1024), 0, st, actsA, actsB, S.fca, 1e-12f, log_row, S.gate_host, S.gate_seq, R);
   DYB_CHECK_LAUNCH();
   // the one host wait of the dynamic loop (the reference's `.item()`, dynaboa_benchmark.py:165): a poll of pinned memory the
   // kernel writes, no stream synchronise / device-to-host copy call
-  long spins = 0;
-  while (S.gate_host[15] != S.gate_seq) {
-    if (++spins > 2000000000L) return DYB_ERR_LAUNCH;
-    __builtin_ia32_pause();
+  for (int i = 0; i < R.n; ++i) {
+    const int r = R.map[i];
+    long spins = 0;
+    while (S.gate_host[16 * r + 15] != S.gate_seq) {
+      if (++spins > 2000000000L) return DYB_ERR_LAUNCH;
+      __builtin_ia32_pause();
+    }
+    cos12[r] = S.gate_host[16 * r + 12];
   }
-  *cos12 = S.gate_host[12];
   return DYB_OK;
 }
-// Adaptor.adaptation with the reference's full term set (dynaboa_benchmark.py:126-193): inputs = HOST array of IN_COUNT device
-// pointers (image, kp2d, gt_pose, gt_betas, gender, hist_image, hist_kp, ex_img, ex_kp, ex_pose, ex_betas, ex_pose3d; the
-// history pair NULL while there is no frame `interval` steps back, the exemplar five NULL when a retrieval callback is set).
-// *extra_steps receives the number of dynamic-loop iterations taken.
-extern "C" int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
-                                            hipStream_t st, hipStream_t aux) {
-  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
-  DYB_REQUIRE(Sp && inputs && extra_steps, DYB_ERR_ARG);
-  Stepper& S = *Sp;
-  RUN(check_ready(S));
-  DYB_REQUIRE(S.full && S.nrep == 1 && S.B <= 16, DYB_ERR_UNSUPPORTED);
-  FullCtx C{};
-  for (int i = 0; i < IN_COUNT; ++i) C.in[i] = inputs[i];
-  DYB_REQUIRE(C.in[IN_IMAGE] && C.in[IN_KP], DYB_ERR_ARG);
+static int stage_inputs(Stepper& S, const void* const* src, int ld, int k0, int nk, hipStream_t st) {
+  DYB_REQUIRE(nk >= 1 && nk <= 5 && S.nrep > 1, DYB_ERR_ARG);
+  const DybRep& R = dyb_rep_current();
+  const size_t B = (size_t)S.B, img = B * 3 * (size_t)S.H * S.W;
+  const size_t cnt[IN_COUNT] = {img, B * NJ * 3, B * 72, B * 10, B * 2, img, B * NJ * 3, img, B * NJ * 3, B * 72, B * 10, B * 24 * 4};
+  GatherArgs g{};
+  for (int k = 0; k < nk; ++k) {
+    DYB_REQUIRE(S.in_stage[k0 + k], DYB_ERR_ARG);
+    g.dst[k] = S.in_stage[k0 + k];
+    g.n[k] = (unsigned)cnt[k0 + k];
+    for (int i = 0; i < R.n; ++i) g.src[k][R.map[i]] = reinterpret_cast<const float*>(src[(size_t)k * ld + R.map[i]]);
+  }
+  hipLaunchKernelGGL(gather_inputs_kernel, dim3(64, nk, R.n), dim3(256), 0, st, g, R);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// The launch scope of a set of physical replicas: every per-replica arena of the stepper, map = the set.
+static DybRep make_scope(const Stepper& S, const int* idx, int n) {
+  DybRep R{};
+  dyb_rep_identity(R);
+  R.n = n;
+  for (int i = 0; i < n; ++i) R.map[i] = (unsigned char)idx[i];
+  auto arena = [&](const void* lo, size_t bytes) {
+    if (!lo || !bytes || R.narenas >= DYB_MAX_ARENAS) return;
+    R.lo[R.narenas] = reinterpret_cast<const char*>(lo);
+    R.span[R.narenas] = bytes;
+    R.stride[R.narenas] = bytes;
+    ++R.narenas;
+  };
+  const int rows = S.inner_step + 1 + (S.full && S.dynamic ? S.optim_steps : 0);
+  arena(S.wsp, S.blob);
+  arena(S.theta, S.n_params * sizeof(float));
+  arena(S.adam_m, S.n_params * sizeof(float));
+  arena(S.adam_v, S.n_params * sizeof(float));
+  arena(S.records, (size_t)S.record_capacity * a64((size_t)S.B * 85 + 1) * sizeof(float));
+  arena(S.loss_log, (size_t)S.loss_capacity * (S.full ? 16 : 4) * rows * sizeof(float));
+  if (S.full) {
+    arena(S.teacher, S.n_params * sizeof(float));
+    arena(S.gate_log, (size_t)S.loss_capacity * (1 + S.optim_steps) * 16 * sizeof(float));
+    arena(S.feat5_out, (size_t)S.B * 2048 * sizeof(float));
+  }
+  return R;
+}
+// the replicas the next frame step covers (ascending physical indices; n = 0: all).  Sequences of different lengths: a replica
+// whose stream has ended simply leaves the set - its weights, Adam state and records stay as they are.
+extern "C" int dyb_stepper_set_active(void* stepper, const int* idx, int n) {
+  Stepper* S = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(S && n >= 0 && n <= S->nrep && (n == 0 || idx), DYB_ERR_ARG);
+  for (int i = 0; i < n; ++i) DYB_REQUIRE(idx[i] >= 0 && idx[i] < S->nrep && (i == 0 || idx[i] > idx[i - 1]), DYB_ERR_ARG);
+  S->nactive = n;
+  for (int i = 0; i < n; ++i) S->active[i] = idx[i];
+  return DYB_OK;
+}
+static int active_set(const Stepper& S, int* idx) {
+  if (S.nactive > 0) {
+    for (int i = 0; i < S.nactive; ++i) idx[i] = S.active[i];
+    return S.nactive;
+  }
+  for (int i = 0; i < S.nrep; ++i) idx[i] = i;
+  return S.nrep;
+}
+
+// Adaptor.adaptation with the reference's full term set (dynaboa_benchmark.py:126-193) for every replica of the current launch
+// scope (one replica without a scope).  C.in: the frame's inputs - the callers' tensors (one replica) or the staging areas.
+// extra[r] (physical replica) receives the number of dynamic-loop iterations replica r took: the gate is evaluated per replica,
+// and a replica whose feature 12 has stopped moving LEAVES the launch set of the remaining iterations (the others are not held
+// back by it, and it does not take Adam steps the reference would not have taken).
+static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slot, int* extra, hipStream_t st, hipStream_t aux) {
   const bool metrics = S.metrics != 0;
+  DYB_REQUIRE(C.in[IN_IMAGE] && C.in[IN_KP], DYB_ERR_ARG);
   DYB_REQUIRE(!metrics || (C.in[IN_GT_POSE] && C.in[IN_GT_BETAS] && C.in[IN_GENDER]), DYB_ERR_ARG);
   const long long* gender = (const long long*)C.in[IN_GENDER];
   const int K = S.inner_step;
   const int rows = K + 1 + (S.dynamic ? S.optim_steps : 0);
   C.losslog = (S.loss_log && loss_slot >= 0 && loss_slot < S.loss_capacity) ? S.loss_log + (size_t)loss_slot * 16 * rows : nullptr;
+  C.level_row = 0;
   int slot = record_slot;
-  *extra_steps = 0;
+  const DybRep outer = dyb_rep_current();                 // (copy: nested scopes below replace the thread's current one)
+  for (int i = 0; i < outer.n; ++i) extra[outer.map[i]] = 0;
   if (metrics) RUN(gt_meshes(S, (const float*)C.in[IN_GT_POSE], (const float*)C.in[IN_GT_BETAS], st));
   const float* cur = S.theta;
   for (int i = 0; i <= K; ++i) {
@@ -866,25 +989,100 @@ extern "C" int dyb_stepper_adapt_frame_full(void* stepper, const void* const* in
     // moves, repeat the upper level on the model itself (at most optim_steps times)
     float* glog = (S.gate_log && loss_slot >= 0 && loss_slot < S.loss_capacity) ? S.gate_log + (size_t)loss_slot * (1 + S.optim_steps) * 16 : nullptr;
     DYB_REQUIRE(glog, DYB_ERR_ARG);
-    const float* init_acts = (K > 0) ? S.lvl0.acts : nullptr;
-    if (!init_acts) {                                    // inner_step 0: the un-adapted feature forward is the upper level's own (lvl0)
-      init_acts = S.lvl0.acts;
-    }
-    float cos12 = 1.f;
-    RUN(gate_cosine(S, init_acts, S.fin.acts, glog, &cos12, st));
+    float cos12[DYB_MAX_REPLICAS];
+    RUN(gate_cosine(S, S.lvl0.acts, S.fin.acts, glog, cos12, st));     // (inner_step 0: the upper level's own forward is lvl0)
+    int cont[DYB_MAX_REPLICAS], ncont = 0;
+    for (int i = 0; i < outer.n; ++i)
+      if (1.f - cos12[outer.map[i]] > (float)S.cos_thr) cont[ncont++] = outer.map[i];
     int step = 0;
-    while (1.f - cos12 > (float)S.cos_thr) {
+    while (ncont > 0) {
       ++step;
-      if (step > S.optim_steps) break;
-      RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
-      RUN(adam_and_teacher(S, st));
-      RUN(pass_forward(S, S.fin, S.theta, image, st));
-      RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, &cos12, st));
-      if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
+      if (step > S.optim_steps) {
+        for (int i = 0; i < ncont; ++i) extra[cont[i]] = S.optim_steps + 1;
+        break;
+      }
+      {
+        // the replicas still adapting get a scope of their own (one replica without replica machinery: the scope it came with)
+        DybRep sub = outer;
+        sub.n = ncont;
+        for (int i = 0; i < ncont; ++i) sub.map[i] = (unsigned char)cont[i];
+        DybRepScope scope(sub);
+        C.level_row = K + step;
+        RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
+        RUN(adam_and_teacher(S, st));
+        RUN(pass_forward(S, S.fin, S.theta, image, st));
+        RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, cos12, st));
+        if (metrics) RUN(record_metrics(S, S.fin, gender, slot, st));
+      }
+      ++slot;
+      int m = 0;
+      for (int i = 0; i < ncont; ++i) {
+        extra[cont[i]] = step;
+        if (1.f - cos12[cont[i]] > (float)S.cos_thr) cont[m++] = cont[i];
+      }
+      ncont = m;
     }
-    *extra_steps = step > S.optim_steps ? S.optim_steps + 1 : step;
   }
   return DYB_OK;
+}
+// One sequence: inputs = HOST array of IN_COUNT device pointers (image, kp2d, gt_pose, gt_betas, gender, hist_image, hist_kp,
+// ex_img, ex_kp, ex_pose, ex_betas, ex_pose3d; the history pair NULL while there is no frame `interval` steps back, the exemplar
+// five NULL when a retrieval callback is set).  *extra_steps receives the number of dynamic-loop iterations taken.
+extern "C" int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
+                                            hipStream_t st, hipStream_t aux) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && inputs && extra_steps, DYB_ERR_ARG);
+  Stepper& S = *Sp;
+  RUN(check_ready(S));
+  DYB_REQUIRE(S.full && S.nrep == 1 && S.B <= 16, DYB_ERR_UNSUPPORTED);
+  FullCtx C{};
+  for (int i = 0; i < IN_COUNT; ++i) C.in[i] = inputs[i];
+  int extra[DYB_MAX_REPLICAS];
+  RUN(adapt_full_impl(S, C, record_slot, loss_slot, extra, st, aux));
+  *extra_steps = extra[0];
+  return DYB_OK;
+}
+// The same for the stepper's replicas (the active set, dyb_stepper_set_active): every launch of the chain covers all of them,
+// teacher / history / exemplar passes included.  inputs: HOST array of IN_COUNT x replicas device pointers, kind-major -
+// inputs[kind * replicas + r], r the PHYSICAL replica (entries of inactive replicas are ignored); the history pair must be
+// present for all active replicas or for none; the exemplar five may be NULL when a per-replica retrieval callback
+// ("retrieve_rep_fn") is set.  theta / adam_m / adam_v / teacher are [replicas][param floats], records / loss_log / gate_log
+// [replicas][...], gate_host 16 floats per replica, feat5_out [replicas][B][2048].  extra_steps: `replicas` ints.
+extern "C" int dyb_stepper_adapt_frames_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
+                                             hipStream_t st, hipStream_t aux) {
+  Stepper* Sp = reinterpret_cast<Stepper*>(stepper);
+  DYB_REQUIRE(Sp && inputs && extra_steps, DYB_ERR_ARG);
+  Stepper& S = *Sp;
+  RUN(check_ready(S));
+  DYB_REQUIRE(S.full && S.B <= 16, DYB_ERR_UNSUPPORTED);
+  if (S.nrep == 1) return dyb_stepper_adapt_frame_full(stepper, inputs, record_slot, loss_slot, extra_steps, st, aux);
+  int act[DYB_MAX_REPLICAS];
+  const int na = active_set(S, act);
+  const int n = S.nrep;
+  bool have_hist = false, have_ex = false, have_gt = false;
+  for (int i = 0; i < na; ++i) {
+    const int r = act[i];
+    DYB_REQUIRE(inputs[IN_IMAGE * n + r] && inputs[IN_KP * n + r], DYB_ERR_ARG);
+    const bool h = inputs[IN_HIST_IMAGE * n + r] && inputs[IN_HIST_KP * n + r];
+    const bool e = inputs[IN_EX_IMG * n + r] && inputs[IN_EX_KP * n + r] && inputs[IN_EX_POSE * n + r] && inputs[IN_EX_BETAS * n + r] &&
+                   inputs[IN_EX_POSE3D * n + r];
+    const bool gt = inputs[IN_GT_POSE * n + r] && inputs[IN_GT_BETAS * n + r] && inputs[IN_GENDER * n + r];
+    if (i == 0) { have_hist = h; have_ex = e; have_gt = gt; }
+    DYB_REQUIRE(h == have_hist && e == have_ex && gt == have_gt, DYB_ERR_UNSUPPORTED);     // lockstep: the same terms for every replica
+  }
+  const DybRep R = make_scope(S, act, na);
+  DybRepScope scope(R);
+  RUN(stage_inputs(S, inputs, n, IN_IMAGE, 5, st));
+  if (have_hist) RUN(stage_inputs(S, inputs + (size_t)IN_HIST_IMAGE * n, n, IN_HIST_IMAGE, 2, st));
+  if (have_ex) RUN(stage_inputs(S, inputs + (size_t)IN_EX_IMG * n, n, IN_EX_IMG, 5, st));
+  FullCtx C{};
+  for (int k = 0; k < IN_COUNT; ++k) C.in[k] = nullptr;
+  C.in[IN_IMAGE] = S.in_stage[IN_IMAGE]; C.in[IN_KP] = S.in_stage[IN_KP];
+  if (have_gt) { C.in[IN_GT_POSE] = S.in_stage[IN_GT_POSE]; C.in[IN_GT_BETAS] = S.in_stage[IN_GT_BETAS]; C.in[IN_GENDER] = S.in_stage[IN_GENDER]; }
+  if (have_hist) { C.in[IN_HIST_IMAGE] = S.in_stage[IN_HIST_IMAGE]; C.in[IN_HIST_KP] = S.in_stage[IN_HIST_KP]; }
+  if (have_ex) for (int k = IN_EX_IMG; k <= IN_EX_POSE3D; ++k) C.in[k] = S.in_stage[k];
+  for (int r = 0; r < n; ++r) extra_steps[r] = 0;
+  return adapt_full_impl(S, C, record_slot, loss_slot, extra_steps, st, aux);
 }
 
 extern "C" int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose,
@@ -911,37 +1109,16 @@ extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs
   if (n == 1)
     return adapt_frame_impl(S, (const float*)inputs[0], (const float*)inputs[1], (const float*)inputs[2], (const float*)inputs[3],
                             (const long long*)inputs[4], record_slot, loss_slot, st, aux, side);
-  DybRep R{};
-  R.n = n;
-  auto arena = [&](const void* lo, size_t bytes) {
-    if (!lo || !bytes) return;
-    R.lo[R.narenas] = reinterpret_cast<const char*>(lo);
-    R.span[R.narenas] = bytes;
-    R.stride[R.narenas] = bytes;
-    ++R.narenas;
-  };
-  arena(S.wsp, S.blob);
-  arena(S.theta, S.n_params * sizeof(float));
-  arena(S.adam_m, S.n_params * sizeof(float));
-  arena(S.adam_v, S.n_params * sizeof(float));
-  arena(S.records, (size_t)S.record_capacity * a64((size_t)S.B * 85 + 1) * sizeof(float));
-  arena(S.loss_log, (size_t)S.loss_capacity * 4 * (S.inner_step + 1) * sizeof(float));
+  int act[DYB_MAX_REPLICAS];
+  const int na = active_set(S, act);
+  const DybRep R = make_scope(S, act, na);
   DybRepScope scope(R);
-  GatherArgs g{};
-  const size_t B = (size_t)S.B;
-  const unsigned cnt[5] = {(unsigned)(B * 3 * S.H * S.W), (unsigned)(B * NJ * 3), (unsigned)(B * 72), (unsigned)(B * 10), (unsigned)(B * 2)};
-  for (int k = 0; k < 5; ++k) {
-    g.dst[k] = S.in_stage[k];
-    g.n[k] = cnt[k];
-    for (int r = 0; r < n; ++r) g.src[k][r] = reinterpret_cast<const float*>(inputs[k * n + r]);
-  }
-  for (int r = 0; r < n; ++r) DYB_REQUIRE(g.src[0][r] && g.src[1][r], DYB_ERR_ARG);
+  for (int i = 0; i < na; ++i) DYB_REQUIRE(inputs[0 * n + act[i]] && inputs[1 * n + act[i]], DYB_ERR_ARG);
   // previous frame's tail on the side stream still reads the staged inputs
   hipStream_t gst = st;
   if (S.side_pending) HIPOK(hipStreamWaitEvent(gst, S.e_side, 0));
-  hipLaunchKernelGGL(gather_inputs_kernel, dim3(64, 5, n), dim3(256), 0, gst, g, R);
-  DYB_CHECK_LAUNCH();
-  const bool have_gt = g.src[2][0] && g.src[3][0] && g.src[4][0];
+  RUN(stage_inputs(S, inputs, n, IN_IMAGE, 5, gst));
+  const bool have_gt = inputs[2 * n + act[0]] && inputs[3 * n + act[0]] && inputs[4 * n + act[0]];
   if (S.use_side && side && side != st) {
     // the ground-truth meshes are issued on the side stream: it has to see the staged inputs
     HIPOK(hipEventRecord(S.e_gt, st));

@@ -62,14 +62,22 @@ __device__ __forceinline__ float dyb_wave_sum(float v) {
 // by replica * stride (pointers into shared tables - SMPL, GMM prior, regressors - match no arena and stay).
 // The host side carries the current replica set in a thread-local (DybRepScope), so the launch wrappers need no
 // extra parameters; without a scope n = 1 and every kernel behaves exactly as before.
-#define DYB_MAX_ARENAS 8
+// A launch may also cover a SUBSET of the replicas (the "active set": sequences still inside the dynamic-BOA loop, sequences
+// that have frames left): `map[i]` is the physical replica - the index its arenas are addressed with - of the launch's i-th
+// replica.  Identity outside such a scope.
+#define DYB_MAX_ARENAS 12
+#define DYB_MAX_REPLICAS 64
 struct DybRep {
   int n;                                        // replicas covered by the launch
   int narenas;
   const char* lo[DYB_MAX_ARENAS];               // replica 0's range of each arena
   unsigned long long span[DYB_MAX_ARENAS];      // bytes
   unsigned long long stride[DYB_MAX_ARENAS];    // bytes between consecutive replicas
+  unsigned char map[DYB_MAX_REPLICAS];          // launch replica -> physical replica
 };
+static inline void dyb_rep_identity(DybRep& R) {
+  for (int i = 0; i < DYB_MAX_REPLICAS; ++i) R.map[i] = (unsigned char)i;
+}
 template <class T>
 __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
   const char* c = reinterpret_cast<const char*>(p);
@@ -79,11 +87,13 @@ __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
       return reinterpret_cast<T*>(const_cast<char*>(c) + (unsigned long long)rep * R.stride[a]);
   return p;
 }
-// replica index and the kernel's own z coordinates; then DYB_RB(ptr)... for every pointer the kernel dereferences
+// replica index (dyb_lrep: within the launch; dyb_rep: physical, what arenas and per-replica argument tables are indexed with)
+// and the kernel's own z coordinates; then DYB_RB(ptr)... for every pointer the kernel dereferences
 #define DYB_REP_PROLOGUE(R)                                   \
   const unsigned dyb_gz = gridDim.z / (unsigned)(R).n;        \
-  const int dyb_rep = (int)(blockIdx.z / dyb_gz);             \
-  const unsigned dyb_bz = blockIdx.z - (unsigned)dyb_rep * dyb_gz; \
+  const int dyb_lrep = (int)(blockIdx.z / dyb_gz);            \
+  const int dyb_rep = (int)(R).map[dyb_lrep];                 \
+  const unsigned dyb_bz = blockIdx.z - (unsigned)dyb_lrep * dyb_gz; \
   (void)dyb_bz
 #define DYB_RB(R, p) \
   do {               \

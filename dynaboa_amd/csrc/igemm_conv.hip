@@ -1090,7 +1090,13 @@ DybBf16Scope::DybBf16Scope(bool on) : saved(t_bf16) { t_bf16 = on; }
 DybBf16Scope::~DybBf16Scope() { t_bf16 = saved; }
 
 // ---- current replica set of the calling host thread (dyb_common.h) ------------------------------------------------
-static thread_local DybRep t_rep = {1, 0, {}, {}, {}};
+static DybRep rep_single() {
+  DybRep r{};
+  r.n = 1;
+  dyb_rep_identity(r);
+  return r;
+}
+static thread_local DybRep t_rep = rep_single();
 const DybRep& dyb_rep_current() { return t_rep; }
 DybRepScope::DybRepScope(const DybRep& r) : saved(t_rep) { t_rep = r; }
 DybRepScope::~DybRepScope() { t_rep = saved; }
@@ -1107,7 +1113,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // off by default - emulator-checked, not yet measured), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1122,6 +1128,7 @@ struct DybSwitches {
     tp_xcd = env("DYB_TP_XCD", 1);
     tp_batch_min = env("DYB_TP_BATCH_MIN", 0);
     tp_gn_wgs = env("DYB_TP_GN_WGS", 1024);
+    tp_occ = env("DYB_TP_OCC", 0);
   }
 };
 static DybSwitches& switches() {
@@ -1145,6 +1152,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_xcd")) return &s.tp_xcd;
   if (!strcmp(name, "tp_batch_min")) return &s.tp_batch_min;
   if (!strcmp(name, "tp_gn_wgs")) return &s.tp_gn_wgs;
+  if (!strcmp(name, "tp_occ")) return &s.tp_occ;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1373,24 +1381,33 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.addend = split ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
-  // "tp_kernel" 2 (default): the software-pipelined loop (PIPE); 1: round 2's phase-separated loop (also what the phase probe and
+  // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);
+  // 1: round 2's phase-separated loop (also what the phase probe and
   // weight gradients over maps too small for the branch-free pixel walk use)
-  const bool pipe = switches().tp_kernel.load(std::memory_order_relaxed) >= 2 && !g.probe &&
-                    !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho);
+  const int tpk = switches().tp_kernel.load(std::memory_order_relaxed);
+  const int pipe = (tpk >= 2 && !g.probe && !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho)) ? (tpk >= 3 ? 2 : 1) : 0;
   GnFwdFuse nf{};
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
+  // "tp_occ" = k > 0: at most k workgroups of this launch per CU - unused dynamic LDS makes a (k+1)-th not fit (160 KiB per CU)
+  unsigned lds_pad = 0;
+  if (const int occ = switches().tp_occ.load(std::memory_order_relaxed); occ > 0) {
+    const unsigned lds_static = 2u * TPK * (unsigned)(TM + 4 + TN + 4) * 4u + (nfuse ? 64u * DYB_GN_GROUPS * 2u * 12u : 24u);
+    const unsigned want = 163840u / (unsigned)occ - 1024u;
+    if (want > lds_static) lds_pad = want - lds_static;
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 't' : mode == MODE_DGRAD ? 'u' : 'v', g.nsplit);
-#define DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, P_)                                                                                 \
-  do {                                                                                                                        \
-    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), 0, st, ev0, ev1, 0, g, nf, R); \
-    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), 0, st, g, nf, R);                     \
+#define DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, P_)                                                                                      \
+  do {                                                                                                                             \
+    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), lds_pad, st, ev0, ev1, 0, g, nf, R); \
+    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), lds_pad, st, g, nf, R);                     \
   } while (0)
-#define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)            \
-  do {                                               \
-    if (pipe) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 1);  \
-    else DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 0);       \
+#define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)                 \
+  do {                                                    \
+    if (pipe == 2) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 2);  \
+    else if (pipe) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 1);  \
+    else DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 0);            \
   } while (0)
 #define DYB_TP_LAUNCH(M_, FA_)                        \
   do {                                                \

@@ -46,11 +46,17 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   float denom = sqrtf(v) / bc2_sqrt + eps;
   p = p - step_size * (m / denom);
 }
+// bias corrections per PHYSICAL replica: sequence replicas stepped in lockstep may have taken different numbers of Adam steps
+// (the dynamic-BOA loop repeats the outer step for some of them only; sequences of different lengths)
+struct AdamRepScal {
+  float step_size[DYB_MAX_REPLICAS], bc2_sqrt[DYB_MAX_REPLICAS];
+};
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
-                                                   float4* __restrict__ v, float b1, float b2, float step_size,
-                                                   float bc2_sqrt, float eps, size_t n4, DybRep Rp) {
+                                                   float4* __restrict__ v, float b1, float b2, AdamRepScal sc, float eps, size_t n4,
+                                                   DybRep Rp) {
   DYB_REP_PROLOGUE(Rp);
   DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, m); DYB_RB(Rp, v);
+  const float step_size = sc.step_size[dyb_rep], bc2_sqrt = sc.bc2_sqrt[dyb_rep];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
     adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
@@ -93,13 +99,31 @@ extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float
                              float bc2_sqrt, float eps, size_t n, hipStream_t st) {
   DYB_REQUIRE(p && g && m && v && n % 4 == 0, DYB_ERR_ARG);
   const DybRep& Rp = dyb_rep_current();
+  AdamRepScal sc;
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size; sc.bc2_sqrt[r] = bc2_sqrt; }
   hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
-                     (float4*)v, beta1, beta2, step_size, bc2_sqrt, eps, n / 4, Rp);
+                     (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// the same with the two bias-correction scalars given per physical replica (host arrays of DYB_MAX_REPLICAS = 64 floats; entries of
+// replicas outside the current launch scope are ignored)
+int dyb_adam_step_rep(float* p, const float* g, float* m, float* v, float beta1, float beta2, const float* step_size,
+                      const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
+  DYB_REQUIRE(p && g && m && v && step_size && bc2_sqrt && n % 4 == 0, DYB_ERR_ARG);
+  const DybRep& Rp = dyb_rep_current();
+  AdamRepScal sc;
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size[r]; sc.bc2_sqrt[r] = bc2_sqrt[r]; }
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
+                     (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const float4* __restrict__ p, float alpha, size_t n4) {
+__global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const float4* __restrict__ p, float alpha, size_t n4,
+                                                  DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, t); DYB_RB(Rp, p);
   const float om = 1.f - alpha;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 a = t[i], b = p[i];
@@ -110,15 +134,18 @@ __global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const 
 }
 extern "C" int dyb_ema_update(float* teacher, const float* p, float alpha, size_t n, hipStream_t st) {
   DYB_REQUIRE(teacher && p && n % 4 == 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(ema_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (float4*)teacher, (const float4*)p, alpha,
-                     n / 4);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(ema_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)teacher, (const float4*)p, alpha,
+                     n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 
 // y = a*x + b*y  (gradient accumulation across several forward passes that share theta)
 __global__ __launch_bounds__(256) void axpby_kernel(const float4* __restrict__ x, float4* __restrict__ y, float a, float b,
-                                                    size_t n4) {
+                                                    size_t n4, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, x); DYB_RB(Rp, y);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 u = x[i], w = y[i];
     w.x = a * u.x + b * w.x; w.y = a * u.y + b * w.y; w.z = a * u.z + b * w.z; w.w = a * u.w + b * w.w;
@@ -127,7 +154,8 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float4* __restrict__ x
 }
 extern "C" int dyb_axpby(const float* x, float* y, float a, float b, size_t n, hipStream_t st) {
   DYB_REQUIRE(x && y && n % 4 == 0, DYB_ERR_ARG);
-  hipLaunchKernelGGL(axpby_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (const float4*)x, (float4*)y, a, b, n / 4);
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(axpby_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (const float4*)x, (float4*)y, a, b, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -91,8 +91,6 @@ class NativeStepper:
         si("replicas", S)
         self.mode = mode(o, getattr(adaptor, "bundle", None) is not None)
         self.full = self.mode == "full"
-        if self.full and S != 1:
-            raise ValueError("replica groups cover the frame-loss configurations only")
         si("inner_step", self.K); si("eval_lower", self.eval_lower); si("n_iter", 3)
         if self.full:
             g = lambda k, d=0: getattr(o, k, d)
@@ -115,8 +113,6 @@ class NativeStepper:
         for a in ads:
             st = a.optimizer.state.get(a.model.module.theta)
             steps.append(0 if st is None else int(st["step"]))
-        if len(set(steps)) != 1:
-            raise ValueError("replicas must have taken the same number of Adam steps")
         if S == 1:
             theta = hmr.theta
             st = adaptor.optimizer.state.get(theta)
@@ -138,6 +134,8 @@ class NativeStepper:
                 a.optimizer.state[p] = dict(step=steps[r], exp_avg=self.m[r], exp_avg_sq=self.v[r])
                 self._adam.append(a.optimizer.state[p])
         si("adam_step", steps[0])
+        for r, t in enumerate(steps):                   # replicas may join with different histories (per-replica bias corrections)
+            si(f"adam_step_{r}", t)
         sp("theta", self.theta); sp("adam_m", self.m); sp("adam_v", self.v)
         sp("init_state", hmr.make_init_state(B))
         prior = adaptor.gmm_f
@@ -162,32 +160,58 @@ class NativeStepper:
         sp("records", self.records); sp("loss_log", self.loss_log)
         if self.full:
             if o.use_meanteacher:
-                sp("teacher", adaptor.teacher.theta.data)
-            self.gate_host = torch.zeros(16).pin_memory() if dev.type == "cuda" else torch.zeros(16)
-            self.gate_log = torch.zeros(cap, 1 + self.optim_steps, 16, device=dev)
-            self.feat5 = torch.zeros(B, 2048, device=dev)
+                if S == 1:
+                    sp("teacher", adaptor.teacher.theta.data)
+                else:                                   # one [S][n] stack; replica r's teacher Parameter aliases row r
+                    self.teacher = torch.empty(S, n, device=dev)
+                    for r, a in enumerate(ads):
+                        self.teacher[r].copy_(a.teacher.theta.data)
+                        a.teacher.theta.data = self.teacher[r]
+                    sp("teacher", self.teacher)
+            self.gate_host = torch.zeros(16 * S).pin_memory() if dev.type == "cuda" else torch.zeros(16 * S)
+            self.gate_log = torch.zeros(S, cap, 1 + self.optim_steps, 16, device=dev)
+            self.feat5 = torch.zeros(S, B, 2048, device=dev)
             sp("gate_host", self.gate_host); sp("gate_log", self.gate_log); sp("feat5_out", self.feat5)
             self._cb = None
             if (o.lower_level_mixtrain or o.upper_level_mixtrain) and getattr(adaptor, "bundle", None) is None:
-                CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
+                # retrieval (base_adaptor.py:82-96) stays on the host: argmin over the cluster table + a seeded sample, per sequence
+                self._ex_keep = [None] * S
 
-                def _retrieve(_user, _level, out):
-                    try:
-                        if dev.type == "cuda":
-                            torch.cuda.current_stream(dev).synchronize()          # feat5 of this level's forward is complete
-                        ex = adaptor.retrieval(self.feat5)                        # base_adaptor.py:82-96 (host: argmin + seeded sample)
-                        adaptor._last_h36m = ex
-                        keep = [ex["img"].contiguous().float(), ex["keypoints"].contiguous().float(), ex["pose"].contiguous().float(),
-                                ex["betas"].contiguous().float(), ex["pose_3d"].contiguous().float()]
-                        self._ex_keep = keep
-                        for i, t in enumerate(keep):
-                            out[i] = t.data_ptr()
-                        return 0
-                    except Exception as e:      # noqa: BLE001
-                        self._cb_error = e
-                        return 1
+                def _retrieve_one(r, out):
+                    if dev.type == "cuda":
+                        torch.cuda.current_stream(dev).synchronize()              # feat5 of this level's forward is complete
+                    a = ads[r]
+                    ex = a.retrieval(self.feat5[r])
+                    a._last_h36m = ex
+                    keep = [ex["img"].contiguous().float(), ex["keypoints"].contiguous().float(), ex["pose"].contiguous().float(),
+                            ex["betas"].contiguous().float(), ex["pose_3d"].contiguous().float()]
+                    self._ex_keep[r] = keep
+                    for i, t in enumerate(keep):
+                        out[i] = t.data_ptr()
+                if S == 1:
+                    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
+
+                    def _retrieve(_user, _level, out):
+                        try:
+                            _retrieve_one(0, out)
+                            return 0
+                        except Exception as e:      # noqa: BLE001
+                            self._cb_error = e
+                            return 1
+                    key = b"retrieve_fn"
+                else:
+                    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
+
+                    def _retrieve(_user, _level, r, out):
+                        try:
+                            _retrieve_one(int(r), out)
+                            return 0
+                        except Exception as e:      # noqa: BLE001
+                            self._cb_error = e
+                            return 1
+                    key = b"retrieve_rep_fn"
                 self._cb = CB(_retrieve)
-                check(lib.dyb_stepper_set_p(h, b"retrieve_fn", ctypes.cast(self._cb, ctypes.c_void_p)), "set_p retrieve_fn")
+                check(lib.dyb_stepper_set_p(h, key, ctypes.cast(self._cb, ctypes.c_void_p)), "set_p " + key.decode())
         nbytes = int(lib.dyb_stepper_workspace_bytes(h))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(lib.dyb_stepper_bind_workspace(h, self.ws.data_ptr(), nbytes, stream_of(self.theta)), "dyb_stepper_bind_workspace")
@@ -227,9 +251,7 @@ class NativeStepper:
         check(self.lib.dyb_stepper_adapt_frames(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, stream_of(self.theta),
                                                 self._aux.cuda_stream if self._aux is not None else None, side),
               "dyb_stepper_adapt_frames")
-        t = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
-        for st in self._adam:
-            st["step"] = t
+        self._sync_adam_steps()
         # with a side stream the final inference of this frame is issued by the NEXT call (or join()): its inputs stay alive
         self._prev_keep, self._keep_inputs = getattr(self, "_keep_inputs", None), keep
         self.frame += 1
@@ -258,16 +280,58 @@ class NativeStepper:
         if getattr(self, "_cb_error", None) is not None:
             raise self._cb_error
         check(rc, "dyb_stepper_adapt_frame_full")
-        t = int(self.lib.dyb_stepper_get_i(self.h, b"adam_step"))
-        for st in self._adam:
-            st["step"] = t
+        self._sync_adam_steps()
         self.frame += 1
         return f, slot0, int(extra.value)
 
-    def level_row(self, frame: int, row: int):
+    def _sync_adam_steps(self):
+        for r, st in enumerate(self._adam):
+            st["step"] = int(self.lib.dyb_stepper_get_i(self.h, f"adam_step_{r}".encode()))
+
+    def set_active(self, idx=None):
+        """The replicas the following frame steps cover (ascending indices; None = all): a sequence whose stream has ended leaves
+        the set - its weights, Adam state and records stay as they are."""
+        idx = [] if idx is None else sorted(int(i) for i in idx)
+        arr = (ctypes.c_int * max(1, len(idx)))(*idx)
+        check(self.lib.dyb_stepper_set_active(self.h, ctypes.cast(arr, ctypes.c_void_p), len(idx)), "dyb_stepper_set_active")
+        self.active = list(range(self.S)) if not idx else idx
+
+    def adapt_frames_full(self, batches, hists, exemplars):
+        """One frame of the full term set per ACTIVE replica, in lockstep (lists of length S; entries of inactive replicas None).
+        hists[r] = (image, kp2d) or None (all active replicas alike); exemplars[r] = dict or None (retrieval callback).
+        -> (frame index, first record slot, [extra dynamic-loop steps per replica])."""
+        f = self.frame
+        if f >= self.loss_log.shape[1]:
+            raise RuntimeError("native stepper: more frames than reset_records() announced")
+        S = self.S
+        c = lambda t: t.contiguous().float()
+        ptrs = (ctypes.c_void_p * (12 * S))()
+        keep = []
+        for r in getattr(self, "active", range(S)):
+            b = batches[r]
+            row = [c(b["image"]), c(b["smpl_j2d"]), c(b["pose"]), c(b["betas"]), b["gender"].contiguous().long()]
+            row += [c(hists[r][0]), c(hists[r][1])] if hists[r] is not None else [None, None]
+            row += [c(exemplars[r][k]) for k in ("img", "keypoints", "pose", "betas", "pose_3d")] if exemplars[r] is not None else [None] * 5
+            keep.append(row)
+            for k, t in enumerate(row):
+                ptrs[k * S + r] = None if t is None else t.data_ptr()
+        extra = (ctypes.c_int * S)()
+        slot0 = f * self.slots_per_frame
+        self._cb_error = None
+        rc = self.lib.dyb_stepper_adapt_frames_full(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, ctypes.cast(extra, ctypes.c_void_p),
+                                                    stream_of(self.theta), self._aux.cuda_stream if self._aux is not None else None)
+        if getattr(self, "_cb_error", None) is not None:
+            raise self._cb_error
+        check(rc, "dyb_stepper_adapt_frames_full")
+        self._sync_adam_steps()
+        self._keep_inputs = keep
+        self.frame += 1
+        return f, slot0, [int(x) for x in extra]
+
+    def level_row(self, frame: int, row: int, r: int = 0):
         """16-float log row `row` of `frame` (full mode): frame {s2d, shape, pose, total} | teacher {s2d, s3d, shape, pose, loss} |
         motion | labelled {s2d, s3d, shape, pose, loss} | level total."""
-        return self.loss_log[0, frame, 16 * row:16 * row + 16]
+        return self.loss_log[r, frame, 16 * row:16 * row + 16]
 
     def join(self):
         check(self.lib.dyb_stepper_join(self.h, stream_of(self.theta)), "dyb_stepper_join")
@@ -301,12 +365,33 @@ class ReplicaGroup:
             a._native, a._native_replica = self.stepper, r
 
     def step(self, batches, global_step: int):
-        for a, b in zip(self.adaptors, batches):
+        """One frame per sequence.  batches[r] = None: sequence r has no frame left (streams of different lengths, reference
+        boa_dataset/pw3d.py:19-35) - it sits this and all later steps out; the others are not held back by it."""
+        ns = self.stepper
+        active = [r for r, b in enumerate(batches) if b is not None]
+        if not active:
+            return [None] * len(batches)
+        if len(active) != len(batches) or getattr(ns, "active", None) not in (None, active):
+            ns.set_active(active)
+        for r in active:
+            a, b = self.adaptors[r], batches[r]
             a.global_step = global_step
             a.fit_losses = {}
             a.save_hist(b["image"], b["smpl_j2d"])
-        f, slot = self.stepper.adapt_frames(batches)
-        return [a._native_bookkeeping(f, slot) for a in self.adaptors]
+        out = [None] * len(batches)
+        if ns.full:
+            ins = {r: self.adaptors[r]._native_full_inputs(batches[r]) for r in active}
+            hists = [ins[r][0] if r in ins else None for r in range(len(batches))]
+            exs = [ins[r][1] if r in ins else None for r in range(len(batches))]
+            f, slot, extra = ns.adapt_frames_full(batches, hists, exs)
+            for r in active:
+                out[r] = self.adaptors[r]._native_full_bookkeeping(f, slot, extra[r], hists[r])
+        else:
+            full = [b if b is not None else batches[active[0]] for b in batches]     # (inactive entries are ignored by the stepper)
+            f, slot = ns.adapt_frames(full)
+            for r in active:
+                out[r] = self.adaptors[r]._native_bookkeeping(f, slot)
+        return out
 
     def flush_metrics(self):
         return [a.flush_metrics() for a in self.adaptors]

@@ -385,6 +385,19 @@ int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs, int recor
  * ex_pose, ex_betas, ex_pose3d (NULL with a retrieval callback).  loss_log rows are 16 floats per level (adapt_step.hip). */
 int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
                                  dyb_stream_t stream, dyb_stream_t aux);
+/* The full term set for the stepper's sequence replicas in lockstep (round 3; reference dynaboa_benchmark.py:126-193 per sequence):
+ * every launch - teacher forward, history-frame pass, exemplar pass, the feature cosines - covers all active replicas.  The
+ * dynamic-BOA gate is decided PER replica: a replica whose feature 12 has stopped moving leaves the launch set of the remaining
+ * iterations, so replicas take different numbers of Adam steps (per-replica step counts: get_i "adam_step_<r>").  inputs: HOST
+ * array of 12 x replicas device pointers, kind-major - inputs[kind * replicas + r] in the order of dyb_stepper_adapt_frame_full,
+ * r the physical replica (entries of inactive replicas ignored; the history pair present for all active replicas or none;
+ * exemplars NULL with the per-replica callback set_p "retrieve_rep_fn": int fn(void* user, int level, int replica, const void**
+ * ex5)).  teacher / gate_log / feat5_out are [replicas][...] like theta; gate_host 16 floats per replica.  extra_steps: `replicas`
+ * ints.  dyb_stepper_set_active: the replicas following frame steps cover (ascending physical indices; n = 0: all) - sequences of
+ * different lengths: a replica whose stream has ended leaves the set, its weights / Adam state / records stay as they are. */
+int dyb_stepper_adapt_frames_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
+                                  dyb_stream_t stream, dyb_stream_t aux);
+int dyb_stepper_set_active(void* stepper, const int* idx, int n);
 int dyb_stepper_join(void* stepper, dyb_stream_t stream);
 const float* dyb_stepper_output(const void* stepper, int which);
 

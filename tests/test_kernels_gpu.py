@@ -38,10 +38,10 @@ def test_conv_batch8(be, shape):
     K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
 
 
-@pytest.fixture(params=[2, 1], ids=["pipelined", "phased"])
+@pytest.fixture(params=[2, 1, 3], ids=["pipelined", "phased", "pipelined2"])
 def throughput_mode(be, request):
     """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas), once with each loop
-    form of igemm_tp_kernel (tp_kernel 2 = software-pipelined, the default; 1 = round 2's phase-separated loop)."""
+    form of igemm_tp_kernel (tp_kernel 2 = software-pipelined, the default; 1 = round 2's phase-separated loop; 3 = pipelined with two K-steps of loads in flight)."""
     be.lib.dyb_set_option(b"rep_split", 1)
     be.lib.dyb_set_option(b"tp_min", 1)
     be.lib.dyb_set_option(b"tp_kernel", request.param)
