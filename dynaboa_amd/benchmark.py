@@ -102,6 +102,11 @@ parser.add_argument('--native_step', type=int, default=1, choices=[0, 1],
                     help='1: configurations the native frame stepper covers (first order, frame-loss set; csrc/adapt_step.hip) '
                          'run as ONE C call per frame - same kernels, same order, identical weights; 0: always the '
                          'torch.autograd composition')
+parser.add_argument('--num_shards', type=int, default=1,
+                    help="split the stream by sequence over this many processes (1 = the reference's single stream; dynaboa_amd/sharded.py)")
+parser.add_argument('--shard_rank', type=int, default=0, help="this process's shard (torchrun's RANK overrides it)")
+parser.add_argument('--seqs_per_gpu', type=int, default=1,
+                    help="sequences of this shard adapted at once, in lockstep launches (own weights / Adam state / records each)")
 parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
                     help='run inference() after every inner step like the reference (:142)')
 
@@ -564,6 +569,10 @@ class Adaptor(BaseAdaptor):
 
 if __name__ == '__main__':
     options = parser.parse_args()
-    adaptor = Adaptor(options)
-    res = adaptor.excute()
-    print(f"MPJPE:{np.mean(res['mpjpe'])}, PAMPJPE:{np.mean(res['pampjpe'])}, PVE:{np.mean(res['pve'])}")
+    if options.num_shards > 1 or options.seqs_per_gpu > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from dynaboa_amd import sharded
+        sharded.main(options)
+    else:
+        adaptor = Adaptor(options)
+        res = adaptor.excute()
+        print(f"MPJPE:{np.mean(res['mpjpe'])}, PAMPJPE:{np.mean(res['pampjpe'])}, PVE:{np.mean(res['pve'])}")

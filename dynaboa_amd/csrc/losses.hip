@@ -205,6 +205,116 @@ extern "C" int dyb_projection_bwd(const float* cam, int ldc, const float* p3, co
 }
 
 // ------------------------------------------------------------------------------------------
+// utils/geometry.py:63-91 perspective_projection: out = f * (R p + t).xy / (R p + t).z + c  - the general form behind
+// BaseAdaptor.projection (whose identity-rotation / weak-perspective case above is what the adaptation path itself uses).
+// Differentiable w.r.t. the points and the translation (what the reference differentiates: the predicted joints and camera).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void persp_fwd_kernel(const float* __restrict__ pts, const float* __restrict__ rot,
+                                                       const float* __restrict__ tr, const float* __restrict__ focal, int ldf,
+                                                       const float* __restrict__ cen, float* __restrict__ out, int B, int np) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B * np) return;
+  const int b = i / np;
+  const float* R = rot + (size_t)b * 9;
+  const float* p = pts + (size_t)i * 3;
+  const float x = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + tr[b * 3], y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + tr[b * 3 + 1],
+              z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + tr[b * 3 + 2];
+  const float f = focal[(size_t)b * ldf];
+  out[(size_t)i * 2] = f * (x / z) + cen[b * 2];
+  out[(size_t)i * 2 + 1] = f * (y / z) + cen[b * 2 + 1];
+}
+// one workgroup per sample: d(points) per point, d(translation) summed over the sample's points (np <= 4096)
+__global__ __launch_bounds__(64) void persp_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ rot,
+                                                       const float* __restrict__ tr, const float* __restrict__ focal, int ldf,
+                                                       const float* __restrict__ g2, float* __restrict__ dpts,
+                                                       float* __restrict__ dtr, int np) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* R = rot + (size_t)b * 9;
+  const float f = focal[(size_t)b * ldf];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = t; j < np; j += 64) {
+    const size_t i = (size_t)b * np + j;
+    const float* p = pts + i * 3;
+    const float x = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + tr[b * 3], y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + tr[b * 3 + 1],
+                z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + tr[b * 3 + 2];
+    const float gx = f * g2[i * 2] / z, gy = f * g2[i * 2 + 1] / z, gz = -(gx * x + gy * y) / z;
+    dpts[i * 3] = R[0] * gx + R[3] * gy + R[6] * gz;
+    dpts[i * 3 + 1] = R[1] * gx + R[4] * gy + R[7] * gz;
+    dpts[i * 3 + 2] = R[2] * gx + R[5] * gy + R[8] * gz;
+    sx += gx; sy += gy; sz += gz;
+  }
+  sx = dyb_wave_sum(sx); sy = dyb_wave_sum(sy); sz = dyb_wave_sum(sz);
+  if (t == 0) { dtr[b * 3] = sx; dtr[b * 3 + 1] = sy; dtr[b * 3 + 2] = sz; }
+}
+// focal: per sample with stride ldf floats (ldf = 0: one value for all)
+extern "C" int dyb_perspective_projection_fwd(const float* points, const float* rotation, const float* translation, const float* focal,
+                                              int ldf, const float* center, float* out, int B, int np, hipStream_t st) {
+  DYB_REQUIRE(points && rotation && translation && focal && center && out && B > 0 && np > 0 && ldf >= 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(persp_fwd_kernel, dim3(dyb_cdiv(B * np, 64)), dim3(64), 0, st, points, rotation, translation, focal, ldf, center, out,
+                     B, np);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+extern "C" int dyb_perspective_projection_bwd(const float* points, const float* rotation, const float* translation, const float* focal,
+                                              int ldf, const float* g2, float* dpoints, float* dtranslation, int B, int np,
+                                              hipStream_t st) {
+  DYB_REQUIRE(points && rotation && translation && focal && g2 && dpoints && dtranslation && B > 0 && np > 0 && ldf >= 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(persp_bwd_kernel, dim3(B), dim3(64), 0, st, points, rotation, translation, focal, ldf, g2, dpoints, dtranslation, np);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxMixturePrior.merged_log_likelihood (utils/smplify/prior.py:181-196) on an axis-angle body pose [B][69]: per-sample
+// min_m (0.5 d_m^T P_m d_m - log w_m) and its gradient w.r.t. the pose - the module-level form of the prior (the adaptation path
+// uses the copy inside frame_losses_kernel, which starts from rotation matrices).  One workgroup per sample.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gmm_prior_kernel(const float* __restrict__ pose, const float* __restrict__ means,
+                                                        const float* __restrict__ prec, const float* __restrict__ logw,
+                                                        float* __restrict__ out, float* __restrict__ dpose) {
+  __shared__ float sD[NG][ND], sRow[NG][ND], sCol[NG][ND], sQ[NG];
+  __shared__ int sBest;
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < NG * ND; i += 256) sD[i / ND][i % ND] = pose[(size_t)b * ND + i % ND] - means[i];
+  __syncthreads();
+  for (int i = t; i < NG * ND; i += 256) {
+    const int m = i / ND, k = i % ND;
+    const float* P = prec + (size_t)m * ND * ND;
+    float r = 0.f, c = 0.f;
+    for (int j = 0; j < ND; ++j) {
+      const float d = sD[m][j];
+      r += P[k * ND + j] * d;
+      c += P[j * ND + k] * d;
+    }
+    sRow[m][k] = r;
+    sCol[m][k] = c;
+  }
+  __syncthreads();
+  if (t < NG) {
+    float q = 0.f;
+    for (int k = 0; k < ND; ++k) q += sRow[t][k] * sD[t][k];
+    sQ[t] = 0.5f * q - logw[t];
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    for (int m = 1; m < NG; ++m)
+      if (sQ[m] < sQ[best]) best = m;
+    sBest = best;
+    out[b] = sQ[best];
+  }
+  __syncthreads();
+  if (dpose && t < ND) dpose[(size_t)b * ND + t] = 0.5f * (sRow[sBest][t] + sCol[sBest][t]);
+}
+extern "C" int dyb_gmm_prior(const float* pose69, const float* gmm_means, const float* gmm_prec, const float* gmm_logw, float* out,
+                             float* dpose69, int B, hipStream_t st) {
+  DYB_REQUIRE(pose69 && gmm_means && gmm_prec && gmm_logw && out && B > 0, DYB_ERR_ARG);
+  hipLaunchKernelGGL(gmm_prior_kernel, dim3(B), dim3(256), 0, st, pose69, gmm_means, gmm_prec, gmm_logw, out, dpose69);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // fused frame losses, value + gradient
 // ------------------------------------------------------------------------------------------
 struct FrameLossArgs {

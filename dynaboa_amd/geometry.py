@@ -1,5 +1,5 @@
-"""Rotation conversions with the reference's names (``utils/geometry.py``): rot6d_to_rotmat (:47-61),
-rotation_matrix_to_angle_axis (:184-213) on HIP kernels with hand-derived backward;
+"""Rotation conversions and the camera projection with the reference's names (``utils/geometry.py``): rot6d_to_rotmat (:47-61),
+rotation_matrix_to_angle_axis (:184-213), perspective_projection (:63-91) on HIP kernels with hand-derived backward;
 batch_rodrigues (:9-24) as a few tiny torch ops - it only converts the ground-truth pose of
 retrieved exemplars / metric targets, never a learned quantity."""
 from __future__ import annotations
@@ -74,3 +74,39 @@ def batch_rodrigues(theta):
             2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
             2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]
     return torch.stack(rows, 1).view(-1, 3, 3)
+
+
+class _Perspective(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, rotation, translation, focal, center):
+        B, n = points.shape[0], points.shape[1]
+        pts, rot, tr = points.contiguous().float(), rotation.contiguous().float(), translation.contiguous().float()
+        cen = center.contiguous().float()
+        out = torch.empty(B, n, 2, device=pts.device)
+        ldf = 1 if focal.numel() == B and B > 1 else 0
+        check(_lib.load().dyb_perspective_projection_fwd(pts.data_ptr(), rot.data_ptr(), tr.data_ptr(), focal.data_ptr(), ldf, cen.data_ptr(),
+                                                         out.data_ptr(), B, n, stream_of(pts)), "dyb_perspective_projection_fwd")
+        ctx.save_for_backward(pts, rot, tr, focal)
+        ctx.ldf = ldf
+        return out
+
+    @staticmethod
+    def backward(ctx, g2):
+        pts, rot, tr, focal = ctx.saved_tensors
+        B, n = pts.shape[0], pts.shape[1]
+        g2 = g2.contiguous().float()
+        dp, dt = torch.empty_like(pts), torch.empty_like(tr)
+        check(_lib.load().dyb_perspective_projection_bwd(pts.data_ptr(), rot.data_ptr(), tr.data_ptr(), focal.data_ptr(), ctx.ldf,
+                                                         g2.data_ptr(), dp.data_ptr(), dt.data_ptr(), B, n, stream_of(pts)),
+              "dyb_perspective_projection_bwd")
+        return dp, None, dt, None, None
+
+
+def perspective_projection(points, rotation, translation, focal_length, camera_center):
+    """utils/geometry.py:63-91, same signature: points (bs, N, 3), rotation (bs, 3, 3), translation (bs, 3), focal_length (bs,) or
+    scalar, camera_center (bs, 2) -> (bs, N, 2).  Differentiable in points and translation (what base_adaptor.py:160-170
+    differentiates); rotation, focal length and centre are treated as constants."""
+    B = points.shape[0]
+    f = torch.as_tensor(focal_length, dtype=torch.float32, device=points.device).reshape(-1)
+    f = f.expand(B).contiguous() if f.numel() == 1 else f.contiguous()
+    return _Perspective.apply(points, rotation, translation, f, camera_center)

@@ -38,8 +38,30 @@ class MaxMixturePrior(nn.Module):
         self.register_buffer("log_nll_weights", torch.from_numpy(logw).contiguous())
 
     def forward(self, pose, betas=None):
-        raise NotImplementedError("use dynaboa_amd.losses.pose_prior(rotmat, prior) - the axis-angle conversion "
-                                  "and the mixture are one fused kernel")
+        """merged_log_likelihood (reference utils/smplify/prior.py:181-196; the call ``self.gmm_f(body_pose, betas)`` of
+        base_adaptor.py:405-409): pose (B, 69) axis-angle body pose -> (B,) min over the mixture, differentiable in the pose;
+        ``betas`` is unused, as in the reference.  (The adaptation path itself uses ``frame_losses`` / ``pose_prior``, where the
+        rotation-matrix -> axis-angle conversion and the mixture are one fused kernel.)"""
+        return _GmmPrior.apply(pose.reshape(-1, 69), self)
+
+    merged_log_likelihood = forward
+
+
+class _GmmPrior(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, prior):
+        pose = pose.contiguous().float()
+        B = pose.shape[0]
+        out, dpose = torch.empty(B, device=pose.device), torch.empty_like(pose)
+        check(_lib.load().dyb_gmm_prior(pose.data_ptr(), prior.means.data_ptr(), prior.precisions.data_ptr(),
+                                        prior.log_nll_weights.data_ptr(), out.data_ptr(), dpose.data_ptr(), B, stream_of(pose)), "dyb_gmm_prior")
+        ctx.save_for_backward(dpose)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpose,) = ctx.saved_tensors
+        return dpose * g.reshape(-1, 1), None
 
 
 class _FrameLoss(torch.autograd.Function):

@@ -229,6 +229,16 @@ int dyb_regress_joints(const float* reg, const float* verts, float* out, int nj,
 int dyb_projection_fwd(const float* cam, int ldc, const float* p3, float* p2, int B, int np, dyb_stream_t stream);
 int dyb_projection_bwd(const float* cam, int ldc, const float* p3, const float* g2, float* dp3, float* dcam, int lddc,
                        int B, int np, dyb_stream_t stream);
+/* utils/geometry.py:63-91 perspective_projection(points (B,N,3), rotation (B,3,3), translation (B,3), focal_length, camera_center
+ * (B,2)) -> (B,N,2) and its gradient w.r.t. points and translation; focal: per sample with stride ldf floats (0: one value). */
+int dyb_perspective_projection_fwd(const float* points, const float* rotation, const float* translation, const float* focal, int ldf,
+                                   const float* center, float* out, int B, int np, dyb_stream_t stream);
+int dyb_perspective_projection_bwd(const float* points, const float* rotation, const float* translation, const float* focal, int ldf,
+                                   const float* g2, float* dpoints, float* dtranslation, int B, int np, dyb_stream_t stream);
+/* MaxMixturePrior.forward / merged_log_likelihood (utils/smplify/prior.py:181-196) on an axis-angle body pose [B][69]: out[B] =
+ * per-sample min over the 8 Gaussians, dpose69 (may be NULL) = its gradient. */
+int dyb_gmm_prior(const float* pose69, const float* gmm_means, const float* gmm_prec, const float* gmm_logw, float* out,
+                  float* dpose69, int B, dyb_stream_t stream);
 int dyb_frame_losses(const float* rotmat, const float* shape, int lds, const float* cam, int ldc, const float* joints49,
                      const float* kp2d, const float* gmm_means, const float* gmm_prec, const float* gmm_logw, float w2d,
                      float wshape, float wpose, float* losses_out, float* drot, float* dshape, int ldds, float* dcam,

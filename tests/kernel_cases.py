@@ -363,6 +363,49 @@ def case_projection(be, B=3, npnt=49, seed=6):
     return e
 
 
+def case_perspective_projection(be, B=3, npnt=49, seed=16):
+    """dyb_perspective_projection_* against the reference's formula (utils/geometry.py:63-91) written out in torch."""
+    rng = _rng(seed)
+    pts = torch.from_numpy((rng.standard_normal((B, npnt, 3)) * 0.4).astype(np.float32)).requires_grad_(True)
+    q, _ = np.linalg.qr(rng.standard_normal((B, 3, 3)))
+    rot = torch.from_numpy(q.astype(np.float32))
+    tr = torch.from_numpy(np.array([[0.05, -0.03, 40.0]], np.float32).repeat(B, 0) + rng.standard_normal((B, 3)).astype(np.float32) * 0.1).requires_grad_(True)
+    focal = torch.tensor([5000.0, 4000.0, 1200.0][:B])
+    cen = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32) * 10)
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = focal; K[:, 1, 1] = focal; K[:, 2, 2] = 1.0; K[:, :-1, -1] = cen
+    p = torch.einsum('bij,bkj->bki', rot, pts) + tr.unsqueeze(1)
+    ref = torch.einsum('bij,bkj->bki', K, p / p[:, :, -1].unsqueeze(-1))[:, :, :-1]
+    g2 = torch.from_numpy(rng.standard_normal((B, npnt, 2)).astype(np.float32))
+    gp, gt = torch.autograd.grad(ref, [pts, tr], g2)
+    P, R, T, F_, C = (be.dev(t.detach().numpy()) for t in (pts, rot, tr, focal, cen))
+    OUT, DP, DT = be.empty((B, npnt, 2)), be.empty((B, npnt, 3)), be.empty((B, 3))
+    check(be.lib.dyb_perspective_projection_fwd(be.ptr(P), be.ptr(R), be.ptr(T), be.ptr(F_), 1, be.ptr(C), be.ptr(OUT), B, npnt, be.stream), "persp fwd")
+    check(be.lib.dyb_perspective_projection_bwd(be.ptr(P), be.ptr(R), be.ptr(T), be.ptr(F_), 1, be.ptr(be.dev(g2.numpy())), be.ptr(DP), be.ptr(DT),
+                                                B, npnt, be.stream), "persp bwd")
+    e = dict(fwd=rel_err(be.host(OUT), ref.detach().numpy()), dp=rel_err(be.host(DP), gp.numpy()), dt=rel_err(be.host(DT), gt.numpy()))
+    assert max(e.values()) < 1e-4, e
+    return e
+
+
+def case_gmm_prior(be, gmm, B=5, seed=17):
+    """dyb_gmm_prior against MaxMixturePrior.merged_log_likelihood restated in torch (utils/smplify/prior.py:181-196), incl. golden g2."""
+    rng = _rng(seed)
+    means, prec, w = (torch.from_numpy(np.asarray(gmm[k], np.float32)) for k in ("means", "precisions", "nll_weights"))
+    pose = (means[rng.integers(0, 8, B)] + torch.from_numpy(rng.standard_normal((B, 69)).astype(np.float32)) * 0.3).requires_grad_(True)
+    d = pose.unsqueeze(1) - means
+    ll = 0.5 * (torch.einsum('mij,bmj->bmi', prec, d) * d).sum(-1) - torch.log(w.reshape(1, -1))
+    ref = ll.min(1)[0]
+    (gp,) = torch.autograd.grad(ref.sum(), [pose])
+    logw = np.log(np.asarray(gmm["nll_weights"], np.float32).reshape(-1))
+    OUT, DP = be.empty((B,)), be.empty((B, 69))
+    check(be.lib.dyb_gmm_prior(be.ptr(be.dev(pose.detach().numpy())), be.ptr(be.dev(means.numpy())), be.ptr(be.dev(prec.numpy())), be.ptr(be.dev(logw)),
+                               be.ptr(OUT), be.ptr(DP), B, be.stream), "gmm prior")
+    e = dict(val=rel_err(be.host(OUT), ref.detach().numpy()), dpose=rel_err(be.host(DP), gp.numpy()))
+    assert max(e.values()) < 1e-4, e
+    return e
+
+
 # ---------------------------------------------------------------------------------------- optimiser family
 def case_optim(be, n=4096 * 3, seed=7):
     rng = _rng(seed)

@@ -95,31 +95,41 @@ def test_adaptor_from_reference_tree(emu_lib, data_tree, monkeypatch):
     """BaseAdaptor with NO bundle reads the reference's relative paths (base_adaptor.py:116-125,144-149;
     model/hmr.py:100-103): weights equal the checkpoint, SMPL models are the three gendered files, the prior is the
     pickle's."""
+    _adaptor_from_reference_tree("cpu", data_tree, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_adaptor_from_reference_tree_gpu(data_tree, monkeypatch):
+    """The same loaders feeding the real library on cuda:0 (the asset-format tests had no GPU run)."""
+    _adaptor_from_reference_tree("cuda:0", data_tree, monkeypatch)
+
+
+def _adaptor_from_reference_tree(device, data_tree, monkeypatch):
     from dynaboa_amd import benchmark as DB
     monkeypatch.chdir(data_tree["root"])
     o = DB.frame_only_options(inner_step=1)
     o.model_file = "data/basemodel.pt"
-    ad = DB.Adaptor(o, None, device="cpu")
+    ad = DB.Adaptor(o, None, device=device)
     sd = ad.model.state_dict()
     ck = data_tree["ck"]["model"]
     assert set(sd) == set(ck)
     for k in ("module.conv1.weight", "module.layer3.2.bn2.bias", "module.fc1.weight", "module.decshape.bias", "module.init_pose"):
         assert torch.equal(sd[k].cpu(), ck[k]), k
     tab = data_tree["tabs"]
-    assert rel_err(ad.smpl_female.v_template.numpy(), tab["FEMALE"]["v_template"]) < 1e-6
-    assert rel_err(ad.smpl_male.posedirs.numpy(), tab["MALE"]["posedirs"]) < 1e-6
+    assert rel_err(ad.smpl_female.v_template.cpu().numpy(), tab["FEMALE"]["v_template"]) < 1e-6
+    assert rel_err(ad.smpl_male.posedirs.cpu().numpy(), tab["MALE"]["posedirs"]) < 1e-6
     assert tuple(ad.J_regressor.shape) == (17, 6890)
-    assert rel_err(ad.gmm_f.means.numpy(), data_tree["gmm"]["means"].astype(np.float32)) < 1e-6
+    assert rel_err(ad.gmm_f.means.cpu().numpy(), data_tree["gmm"]["means"].astype(np.float32)) < 1e-6
     # and the loaded SMPL runs: one LBS forward on the emulated kernels against the oracle on the same tables
     from oracle import ref_cpu as O
     g = torch.Generator().manual_seed(3)
     betas = torch.randn(1, 10, generator=g) * 0.5
     rot = O.smplx_rodrigues(torch.randn(24, 3, generator=g) * 0.3).view(1, 24, 3, 3)
-    out = ad.smpl_neutral(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+    out = ad.smpl_neutral(betas=betas.to(device), body_pose=rot[:, 1:].to(device), global_orient=rot[:, :1].to(device), pose2rot=False)
     T = O.smpl_tables_to_torch(tab["NEUTRAL"])
     verts, j49 = O.smpl_forward(T, betas, rot[:, 1:], rot[:, :1], pose2rot=False)
-    assert rel_err(out.vertices.numpy(), verts.numpy()) < 1e-5
-    assert rel_err(out.joints.numpy(), j49.numpy()) < 1e-5
+    assert rel_err(out.vertices.cpu().numpy(), verts.numpy()) < 1e-5
+    assert rel_err(out.joints.cpu().numpy(), j49.numpy()) < 1e-5
 
 
 @pytest.mark.slow
@@ -127,6 +137,17 @@ def test_adaptor_real_data_path_one_frame(emu_lib, data_tree, monkeypatch):
     """The reference's CLI path end to end with NO synthetic bundle: Adaptor(options) builds the 3DPW loader and the exemplar
     set from a reference-style data tree (default flags: retrieval=1, labelled exemplars, teacher, dynamic loop), excute()
     walks the first frame - decode, device crop, lower level with a retrieved exemplar, upper level, Adam, metrics."""
+    _real_data_path("cpu", 1, data_tree, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_adaptor_real_data_path_gpu(data_tree, monkeypatch):
+    """The same on cuda:0 over four frames (the motion term's history pair exists from frame 3 on with interval 2): the real
+    cluster-argmin retrieval callback of the native stepper, device crop preprocessing, default flags."""
+    _real_data_path("cuda:0", 4, data_tree, monkeypatch)
+
+
+def _real_data_path(device, nframes, data_tree, monkeypatch):
     from test_preprocess import populate_stream
     from dynaboa_amd import benchmark as DB
     tree = populate_stream(data_tree["root"])
@@ -134,12 +155,17 @@ def test_adaptor_real_data_path_one_frame(emu_lib, data_tree, monkeypatch):
     o = DB.parser.parse_args([])
     o.model_file, o.pw3d_root, o.h36m_root = "data/basemodel.pt", tree["imgroot"], tree["h36root"]
     o.expdir = str(data_tree["root"] / "exps")
-    ad = DB.Adaptor(o, None, device="cpu")
+    if nframes > 1:
+        o.interval = 2
+    ad = DB.Adaptor(o, None, device=device)
     assert len(ad.dataloader) == 9 and len(ad.h36m_dataset) == 12 and tuple(ad.centers.shape) == (3, 2048)
-    first = next(iter(ad.dataloader))
+    it = iter(ad.dataloader)
+    frames = [next(it) for _ in range(nframes)]
     theta0 = ad.model.module.theta.detach().clone()
-    res = ad.excute([first], nframes=1)
-    assert np.isfinite(res["mpjpe"][0]).all() and np.isfinite(res["pampjpe"][0]).all()
+    res = ad.excute(frames, nframes=nframes)
+    assert np.isfinite(res["mpjpe"][0]).all() and np.isfinite(res["pampjpe"][0]).all() and len(res["mpjpe"]) == nframes
     assert float((ad.model.module.theta.detach() - theta0).abs().max()) > 0
-    assert "ll/labled_loss" in ad.last_summaries and "teacher/loss" in ad.last_summaries and len(ad.optim_step_record) == 1
+    assert "ll/labled_loss" in ad.last_summaries and "teacher/loss" in ad.last_summaries and len(ad.optim_step_record) == nframes
+    if nframes > 3:
+        assert "ul/motion_loss" in ad.last_summaries
     assert os.path.exists(os.path.join(o.expdir, o.expname, "seq_order.record"))

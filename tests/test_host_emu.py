@@ -492,3 +492,38 @@ def test_replica_group_on_emulator(emu_lib, throughput):
             worst = max(float((g1[k].double() - g0[k].double()).norm() / g0[k].double().norm().clamp_min(1e-30)) for k in g0)
             assert worst < 5e-3, worst
     assert not torch.equal(ads[0].model.module.theta.detach(), ads[1].model.module.theta.detach())
+
+
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~15 min under the emulator; set DYB_EMU_FULL=1")
+def test_full_term_replica_group_on_emulator(emu_lib):
+    """The reference's default term set for S = 2 sequence replicas (teacher forward, exemplar pass, per-replica dynamic-BOA gate:
+    dyb_stepper_adapt_frames_full) on the emulator against the same sequences adapted one at a time: identical weights, Adam
+    state, teacher and step counts (frame 0: no history pair yet)."""
+    from dynaboa_amd import assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    S = 2
+
+    def mk(r):
+        o = DB.parser.parse_args([])
+        o.inner_step, o.interval, o.optim_steps, o.cos_sim_threshold, o.deferred_metrics = 1, 2, 1, -1.0, 1
+        return DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cpu")
+    frames = [[assets.make_frame(100 * r, 1, seed=22)] for r in range(S)]
+    singles = []
+    for r in range(S):
+        ad = mk(r)
+        ad.excute(frames[r], nframes=1)
+        st = ad.optimizer.state[ad.model.module.theta]
+        singles.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), int(st["step"]),
+                        ad.teacher.theta.detach().clone(), list(ad.optim_step_record)))
+    ads = [mk(r) for r in range(S)]
+    grp = NS.ReplicaGroup(ads, 1)
+    assert grp.stepper.full
+    grp.step([frames[r][0] for r in range(S)], 0)
+    grp.flush_metrics()
+    for r in range(S):
+        a = ads[r]
+        st = a.optimizer.state[a.model.module.theta]
+        assert int(st["step"]) == singles[r][3] == 2 and list(a.optim_step_record) == singles[r][5]
+        assert torch.equal(a.model.module.theta.detach(), singles[r][0]), r
+        assert torch.equal(st["exp_avg"], singles[r][1]) and torch.equal(st["exp_avg_sq"], singles[r][2]), r
+        assert torch.equal(a.teacher.theta.detach(), singles[r][4]), r

@@ -226,6 +226,14 @@ def test_rotations(be):
     K.case_projection(be)
 
 
+def test_perspective_projection_and_gmm_prior(be):
+    """The module-level forms the reference's import surface names (utils/geometry.py perspective_projection,
+    MaxMixturePrior.forward) on their own kernels."""
+    from dynaboa_amd import assets
+    K.case_perspective_projection(be)
+    K.case_gmm_prior(be, assets.load_gmm_prior())
+
+
 def test_lbs(be, smpl_tabs):
     K.case_lbs(be, smpl_tabs, B=2, with_dverts=True)
     K.case_lbs(be, smpl_tabs, B=1, with_dverts=False)

@@ -160,6 +160,20 @@ def test_rotations(be):
     K.case_projection(be, B=8)
 
 
+def test_pa_mpjpe_vs_reference_procrustes(be):
+    """dyb_pa_mpjpe (Jacobi-SVD Procrustes on the device) against golden g6 = the reference's reconstruction_error
+    (utils/pose_utils.py) incl. the reflection sample, and against numpy on random poses."""
+    K.case_pa_mpjpe(be, golden)
+
+
+def test_perspective_projection_and_gmm_prior(be):
+    """The module-level forms the reference's import surface names (utils/geometry.py perspective_projection,
+    MaxMixturePrior.forward) on their own kernels."""
+    from dynaboa_amd import assets
+    K.case_perspective_projection(be)
+    K.case_gmm_prior(be, assets.load_gmm_prior())
+
+
 def test_lbs(be, smpl_tabs):
     K.case_lbs(be, smpl_tabs, B=1, with_dverts=False)
     K.case_lbs(be, smpl_tabs, B=8, with_dverts=True)

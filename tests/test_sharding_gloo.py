@@ -46,3 +46,55 @@ def test_ragged_gather_world2():
 def test_gather_is_identity_without_process_group():
     x = torch.arange(4.0)
     assert torch.equal(gather_frame_metrics(x), x)
+
+
+# ---- the sharded driver (dynaboa_amd/sharded.py) with a stand-in adaptor: sequence assignment, per-frame records, ragged gather
+class _FakeAdaptor:
+    """excute() 'adapts' a sequence by returning metrics that encode which frames it saw, in order."""
+
+    def __init__(self):
+        from types import SimpleNamespace
+        self.options, self.device = SimpleNamespace(deferred_metrics=0, batch_size=1), torch.device("cpu")
+
+    def excute(self, frames, nframes=None):
+        ids = [float(b["id"]) for b in frames]
+        return dict(mpjpe=[np.array([i + 0.25]) for i in ids], pampjpe=[np.array([2 * i]) for i in ids], pve=[i + 0.5 for i in ids])
+
+
+def _specs():
+    from dynaboa_amd.sharded import SequenceSpec
+    lens, first, out = [5, 2, 7, 1, 3], 0, []
+    for k, n in enumerate(lens):
+        out.append(SequenceSpec(f"seq{k}", first, n, (lambda first=first, n=n: [dict(id=first + j) for j in range(n)])))
+        first += n
+    return out
+
+
+def _driver_worker(rank, world, port, out):
+    from types import SimpleNamespace
+    from dynaboa_amd.sharded import run_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = run_sharded(SimpleNamespace(batch_size=1), _specs(), _FakeAdaptor, num_shards=world, shard_rank=rank, seqs_per_gpu=1)
+    out[rank] = {k: (np.asarray(v).tolist() if not isinstance(v, int) else v) for k, v in res.items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_driver_world2_gathers_every_frame_once():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_driver_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r]["global_index"] == list(range(18))                          # every frame of every sequence, once, in stream order
+        assert out[r]["mpjpe"] == [i + 0.25 for i in range(18)] and out[r]["pampjpe"] == [2.0 * i for i in range(18)]
+        assert out[r]["pve"] == [i + 0.5 for i in range(18)]
+    assert sorted(out[0]["owned"] + out[1]["owned"]) == [0, 1, 2, 3, 4]
+    assert out[0]["frames_local"] + out[1]["frames_local"] == 18 and abs(out[0]["frames_local"] - out[1]["frames_local"]) <= 7
+
+
+def test_sharded_driver_single_process_is_the_whole_stream():
+    from types import SimpleNamespace
+    from dynaboa_amd.sharded import run_sharded
+    res = run_sharded(SimpleNamespace(batch_size=1), _specs(), _FakeAdaptor)
+    assert res["global_index"].tolist() == list(range(18)) and res["owned"] == [0, 1, 2, 3, 4]
