@@ -92,7 +92,7 @@ def conv_roofline(run, lo, hi, main_stream):
     from dynaboa_amd import _lib
     lib = _lib.load()
     nfr = hi - lo
-    if lib.dyb_conv_timing_begin(int(nfr * 1500)) != 0:
+    if lib.dyb_conv_timing_begin(int(nfr * 6000)) != 0:
         return None
     with torch.cuda.stream(main_stream):
         run(lo, hi)
@@ -346,17 +346,25 @@ def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
     return out
 
 
-def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, **kw):
+def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, seqs=1, **kw):
     """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each; with
-    roofline_peak (TFLOP/s) also the conv family's in-path achieved rate against that peak (2 extra steps)."""
+    roofline_peak (TFLOP/s) also the conv family's in-path achieved rate against that peak (2 extra steps).  seqs > 1: that many
+    sequences in lockstep (a ReplicaGroup), value = aggregate frames/s."""
     try:
         extra = 2 if roofline_peak else 0
-        rn = Runner(device, 1, batch, inner_step, warmup + steps + extra, frame_base=500_000, **kw)
+        rn = Runner(device, seqs, batch, inner_step, warmup + steps + extra, frame_base=500_000, **kw)
         st = torch.cuda.Stream(device=device)
         r = timed_stream(rn, warmup, steps, st)
-        out = dict(value=steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
+        out = dict(value=seqs * steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
                    native_stepper=rn.native(), config=note)
+        if seqs > 1:
+            out["sequences_per_gpu"] = seqs
+            ads = rn.ads
+            if getattr(ads[0], "optim_step_record", None):
+                out["dynamic_loop_extra_steps_mean"] = float(np.mean([np.mean(a.optim_step_record) for a in ads if a.optim_step_record]))
+        elif getattr(rn.ad, "optim_step_record", None):
+            out["dynamic_loop_extra_steps_mean"] = float(np.mean(rn.ad.optim_step_record))
         if roofline_peak:
             c = conv_roofline(r["run"], warmup + steps, warmup + steps + extra, st)
             rn.flush()
@@ -610,6 +618,13 @@ def main():
             out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)
+            torch.cuda.empty_cache()
+            out["full_default_losses_S32"] = sub_record(
+                device, "full_default_losses_S32", 10, 3, 1, 1, "the reference's default flags (inner_step 1, teacher + motion + labelled "
+                "exemplars + dynamic-BOA gate decided per sequence) for 32 sequences in lockstep on this GPU: teacher forward, history-frame "
+                "pass and exemplar pass are replica-batched launches; a sequence whose gate has closed leaves the launch set of the "
+                "remaining extra steps", roofline_peak=PEAK_FP32_MFMA_TFLOPS, seqs=32, full_losses=1)
+            torch.cuda.empty_cache()
             out["second_order_full_losses_exact_hvp"] = sub_record(
                 device, "so_full_exact", 4, 1, 1, 1, "the reference's default term set in second-order mode with exact Hessian-vector "
                 "products for every level (--hvp_terms all: multi-pass form, verified on the CPU emulator; this is its first GPU run - a "
