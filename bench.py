@@ -598,23 +598,34 @@ def main():
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
                                                  upper_level_mixtrain=1, sample_num=8)
+            # configs[4] arms at batch 16 (one sequence): the throughput schedule (igemm_tp kernels, materialised dy) is the default from
+            # batch 16 on (switch tp_batch_min = 16); the bf16 arm runs the bf16 form of the same kernel
             out["batch16_fp32_vs_bf16"] = dict(
                 fp32=sub_record(device, "b16_fp32", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, "
                                 "fp32 MFMA (exact)", roofline_peak=PEAK_FP32_MFMA_TFLOPS),
                 bf16=sub_record(device, "b16_bf16", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, "
-                                "bf16 MFMA for the convolutions (fp32 master weights / activations / statistics / accumulators)",
-                                roofline_peak=PEAK_BF16_MFMA_TFLOPS, bf16_mfma=1))
+                                "bf16 MFMA for the convolutions (v_mfma_f32_32x32x16_bf16 in the throughput kernel; fp32 master weights / "
+                                "activations / statistics / accumulators)", roofline_peak=PEAK_BF16_MFMA_TFLOPS, bf16_mfma=1))
             __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(16).set_bf16(False)
-            # the same fp32 arm on the throughput schedule (materialised dy, igemm_tp_kernel), selected by the batch size: a
-            # switch that is off by default because this line is its first measurement
+            out["bf16_S32"] = sub_record(
+                device, "bf16_S32", 10, 3, 1, args.inner_step, "the headline workload (32 sequences in lockstep, first-order, frame losses) with the "
+                "convolutions on the bf16 matrix cores - NOT the parity configuration (operands rounded to bf16; fp32 master weights / activations / "
+                "statistics / accumulators)", roofline_peak=PEAK_BF16_MFMA_TFLOPS, seqs=32, bf16_mfma=1)
+            __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(1).set_bf16(False)
+            torch.cuda.empty_cache()
+            out["batch16_first_vs_second_order"] = dict(
+                first_order=dict(value=out["batch16_fp32_vs_bf16"]["fp32"].get("value"), unit="adapted frames/s",
+                                 note="= batch16_fp32_vs_bf16.fp32"),
+                second_order=sub_record(device, "b16_so", 6, 2, 16, args.inner_step, "configs[4] arm: batch 16, SECOND-order outer gradient "
+                                        "(exact Hessian-vector products), frame losses, fp32", second_order=1, hvp="exact"))
             from dynaboa_amd import _lib as _L
             try:
-                _L.load().dyb_set_option(b"tp_batch_min", 16)
-                out["batch16_fp32_vs_bf16"]["fp32_throughput_schedule"] = sub_record(
-                    device, "b16_fp32_tp", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, fp32 MFMA, "
-                    "throughput schedule selected by the batch (switch tp_batch_min = 16; default off)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
-            finally:
                 _L.load().dyb_set_option(b"tp_batch_min", 0)
+                out["batch16_fp32_vs_bf16"]["fp32_latency_schedule"] = sub_record(
+                    device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
+                    "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
+            finally:
+                _L.load().dyb_set_option(b"tp_batch_min", 16)
             out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)

@@ -1109,8 +1109,8 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
 // "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles, 2 = its software-pipelined loop (default), 1 = round 2's
 // phase-separated loop; 0 = the 64x64 kernel), "tp_grid" (workgroups
-// its split-K aims for), "tp_batch_min" (> 0: the throughput schedule also for single-sequence launches of at least that batch;
-// off by default - emulator-checked, not yet measured), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
+// its split-K aims for), "tp_batch_min" (16; > 0: the throughput schedule also for single-sequence launches of at least that batch:
+// +13.5 % at batch 16 in BENCH_r02, and the schedule the bf16 form of igemm_tp_kernel needs), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ;
@@ -1126,7 +1126,7 @@ struct DybSwitches {
     tp_kernel = env("DYB_TP_KERNEL", 2);
     tp_grid = env("DYB_TP_GRID", 512);
     tp_xcd = env("DYB_TP_XCD", 1);
-    tp_batch_min = env("DYB_TP_BATCH_MIN", 0);
+    tp_batch_min = env("DYB_TP_BATCH_MIN", 16);
     tp_gn_wgs = env("DYB_TP_GN_WGS", 1024);
     tp_occ = env("DYB_TP_OCC", 0);
   }
@@ -1326,8 +1326,11 @@ static unsigned long long* probe_for(int mode, const ConvDesc& d, long wgs) {
 
 // The throughput form (igemm_tp.inc) of one mode; same contract as run_igemm below.
 static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
-  if (fuse || dyb_bf16_current() || !dyb_throughput_mode(d.N)) return false;
-  if (!switches().tp_kernel.load(std::memory_order_relaxed)) return false;
+  if (fuse || !dyb_throughput_mode(d.N)) return false;
+  const int tpk_ = switches().tp_kernel.load(std::memory_order_relaxed);
+  if (!tpk_) return false;
+  if (dyb_bf16_current() && (tpk_ < 2 || (mode == MODE_WGRAD && TPK / conv_out_dim(d.W, d.S, d.stride, d.pad) >= conv_out_dim(d.H, d.R, d.stride, d.pad))))
+    return false;                                  // the bf16 form exists for the pipelined loop only
   // buffer addressing: 32-bit byte offsets, one mask bit per filter tap
   const size_t lim = 0x7fffffffu / sizeof(float);
   const int Ho = conv_out_dim(d.H, d.R, d.stride, d.pad), Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
@@ -1386,6 +1389,8 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   // weight gradients over maps too small for the branch-free pixel walk use)
   const int tpk = switches().tp_kernel.load(std::memory_order_relaxed);
   const int pipe = (tpk >= 2 && !g.probe && !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho)) ? (tpk >= 3 ? 2 : 1) : 0;
+  const bool bf = dyb_bf16_current();
+  DYB_REQUIRE(!bf || pipe != 0, DYB_ERR_UNSUPPORTED);
   GnFwdFuse nf{};
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
@@ -1405,9 +1410,15 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   } while (0)
 #define DYB_TP_LAUNCH2(M_, FA_, WM_, WN_)                 \
   do {                                                    \
-    if (pipe == 2) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 2);  \
+    if (bf) DYB_TP_LAUNCH_BF(M_, FA_, WM_, WN_);          \
+    else if (pipe == 2) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 2);  \
     else if (pipe) DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 1);  \
     else DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, 0);            \
+  } while (0)
+#define DYB_TP_LAUNCH_BF(M_, FA_, WM_, WN_)                                                                                          \
+  do {                                                                                                                             \
+    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, 1, true>), grid, dim3(256), lds_pad, st, ev0, ev1, 0, g, nf, R); \
+    else hipLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, 1, true>), grid, dim3(256), lds_pad, st, g, nf, R);                     \
   } while (0)
 #define DYB_TP_LAUNCH(M_, FA_)                        \
   do {                                                \
@@ -1428,6 +1439,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
 #undef DYB_TP_LAUNCH
 #undef DYB_TP_LAUNCH2
 #undef DYB_TP_LAUNCH3
+#undef DYB_TP_LAUNCH_BF
   DYB_CHECK_LAUNCH();
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }

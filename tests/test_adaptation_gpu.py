@@ -800,3 +800,55 @@ def test_replica_group_with_replica_aware_split(restore_switches):
         a = ads[r]
         assert rel(a.model.module.theta.detach(), singles[r][0]) < 1e-6, r
         assert rel(a.optimizer.state[a.model.module.theta]["exp_avg"], singles[r][1]) < 5e-3, r
+
+
+def test_configs4_batch16_first_vs_second_order_and_bf16_vs_oracle(gmm_t, smpl_tabs):
+    """BASELINE configs[4] ("first-order vs second-order outer grad ablation at batch=16, fp32 vs bf16 MFMA") against the CPU
+    ORACLE: one bilevel frame at batch 16, inner_step 1, frame losses -
+      * fp32, first order and second order (exact Hessian-vector products): outer gradient vs the oracle's first_order=True /
+        create_graph=True gradient (norm 2e-2, cosine 0.999 on sampled tensors); the two gradients really differ;
+      * bf16 MFMA, first order: predictions within 1e-2 of the oracle, outer-gradient cosine > 0.99 from layer3 up, > 0.9 everywhere
+        sampled (operands rounded to bf16, fp32 accumulate / master weights / statistics)."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr import get_layout
+    from oracle import ref_cpu as O
+    B = 16
+    frame = assets.make_frame(5, B, seed=22)
+    names = ["conv1.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight", "layer4.2.conv3.weight", "fc1.weight", "decpose.weight"]
+    torch.set_num_threads(32)
+    sd, ref = None, {}
+    ours = {}
+    try:
+        for tag, over in (("fo", {}), ("so", dict(second_order=1)), ("bf16", dict(bf16_mfma=1))):
+            opts = dict(FRAME_ONLY, inner_step=1, batch_size=B, **over)
+            ad, bundle = make_adaptor(opts, False)
+            ad.reset_records(1)
+            ad.global_step = 0
+            ad.model.eval()
+            ad.adaptation({k: v.to(ad.device) for k, v in frame.items()})
+            hmr_m = ad.model.module
+            g = hmr_m._layout1.unpack(ad.optimizer.state[hmr_m.theta]["exp_avg"] / (1 - ad.options.beta1))
+            with torch.no_grad():
+                r, s, c = ad.model(frame["image"].to(ad.device))
+            ours[tag] = dict(g={k: g[k].cpu() for k in names}, pred=dict(rotmat=r.cpu(), shape=s.cpu(), cam=c.cpu()))
+            if sd is None:
+                sd = {k.replace("module.", ""): v for k, v in bundle.checkpoint["model"].items()}
+            get_layout(B).set_bf16(False)
+            del ad
+    finally:
+        get_layout(B).set_bf16(False)
+    for fo in (True, False):
+        o = O.Adapter(sd, O.smpl_tables_to_torch(smpl_tabs), gmm_t, dict(FRAME_ONLY, inner_step=1, batch_size=B), first_order=fo)
+        ref["fo" if fo else "so"] = o.adapt_frame(frame)
+    for tag in ("fo", "so"):
+        for k in names:
+            a, b = ours[tag]["g"][k].double().flatten(), ref[tag]["outer_grad"][k].double().flatten()
+            assert cosine(a, b) > 0.999, (tag, k, cosine(a, b))
+            assert abs(float(a.norm() / b.norm()) - 1) < 2e-2, (tag, k)
+    gap = max(rel_err(ref["fo"]["outer_grad"][k].numpy(), ref["so"]["outer_grad"][k].numpy()) for k in names)
+    assert gap > 1e-2, gap                                      # first and second order are different gradients here
+    for k, v in ours["bf16"]["pred"].items():
+        assert rel_err(v.numpy(), ref["fo"]["pred"][k].numpy()) < 1e-2, k
+    for k in names:
+        cs = cosine(ours["bf16"]["g"][k].double().flatten(), ref["fo"]["outer_grad"][k].double().flatten())
+        assert cs > (0.99 if k.startswith(("layer3", "layer4", "fc", "dec")) else 0.9), (k, cs)

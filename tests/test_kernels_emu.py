@@ -75,6 +75,13 @@ def test_conv_throughput_data_gradient_by_phase_class(be, throughput_mode, cfg, 
         be.lib.dyb_set_option(b"tp_grid", 512)
 
 
+@pytest.mark.parametrize("cfg", [(1, 12, 12, 128, 128, 1, 1, 0), (1, 7, 7, 128, 256, 3, 1, 1), (2, 10, 10, 64, 64, 3, 2, 1)])
+def test_conv_throughput_kernel_bf16(be, throughput_mode, cfg):
+    """bf16 form of the pipelined throughput kernel (operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16, fp32
+    accumulate): equal to an fp32 convolution of the bf16-rounded operands up to summation order."""
+    K.case_conv(be, *cfg, seed=sum(cfg), bf16=True)
+
+
 def test_conv_timing_table_and_probe(be, throughput_mode):
     """Measurement aids: the per-shape table of a timing scope names the throughput kernel's launches; the phase probe writes
     one record per wave of the matching launch (clocks are 0 on the emulator; the K-step count is real)."""
@@ -267,13 +274,13 @@ def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand):
 
 @pytest.mark.slow
 def test_hmr_engine_throughput_schedule_by_batch(be, ckpt_rand):
-    """The throughput schedule selected by the batch size of a single-sequence launch (switch tp_batch_min, off by default):
+    """The throughput schedule selected by the batch size of a single-sequence launch (switch tp_batch_min, 16 by default):
     the whole engine at batch 2 against the reference module's golden g3."""
     be.lib.dyb_set_option(b"tp_batch_min", 2)
     try:
         K.case_hmr_engine(be, golden, ckpt_rand)
     finally:
-        be.lib.dyb_set_option(b"tp_batch_min", 0)
+        be.lib.dyb_set_option(b"tp_batch_min", 16)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")

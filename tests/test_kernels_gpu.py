@@ -65,6 +65,13 @@ def test_conv_throughput_kernel_batch8(be, throughput_mode, shape):
     K.case_conv(be, 8, H, W, C, Kc, R, st, pad, seed=5)
 
 
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_throughput_kernel_bf16_all_resnet_shapes(be, throughput_mode, shape):
+    """bf16 form of the pipelined throughput kernel on every ResNet-50 conv shape (the stem stays on the latency-form kernel)."""
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc, c_real=3 if C == 4 else None, bf16=True)
+
+
 @pytest.mark.parametrize("tp_grid", [16, 4096])
 @pytest.mark.parametrize("shape", [(56, 56, 128, 128, 3, 2, 1), (14, 14, 1024, 2048, 1, 2, 0), (14, 14, 512, 512, 3, 2, 1),
                                    (14, 14, 256, 256, 3, 1, 1)])
