@@ -67,9 +67,10 @@ parser.add_argument('--motionloss_weight', type=float, default=0.8)
 # additions (not in the reference)
 parser.add_argument('--dump_predictions', type=int, default=0, choices=[0, 1])
 parser.add_argument('--hvp', type=str, default=os.environ.get("DYB_HVP", "exact"), choices=["fd", "exact"],
-                    help='second order only: Hessian-vector products exactly, forward-over-reverse through the tangent kernels '
-                         '(exact: levels made of the frame losses; other levels fall back) or as a central difference of '
-                         'first-order gradients of the whole level (fd)')
+                    help='second order only: Hessian-vector products forward-over-reverse through the tangent kernels - exact through '
+                         'the backbone and regressor; the 157-input loss head (rot6d -> SMPL -> projection / priors) is differentiated '
+                         'along the state tangent by a central difference of its analytic gradient (exact: levels made of the frame '
+                         'losses; other levels fall back) - or as a central difference of first-order gradients of the whole level (fd)')
 parser.add_argument('--hvp_terms', type=str, default="frame", choices=["all", "frame"],
                     help='--hvp exact for levels made of the frame losses only (frame: levels with teacher / motion / labelled '
                          'terms use fd) or for every level through the multi-pass form (all: checked against the oracle on the '

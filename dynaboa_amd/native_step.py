@@ -44,6 +44,11 @@ def coverage(o, have_bundle: bool = True):
         return "", "sample_num != batch_size"
     if mix and not have_bundle and B != 1:
         return "", "feature-driven retrieval is batch 1"
+    if mix and not have_bundle and bool(g("lower_level_mixtrain")) != bool(g("upper_level_mixtrain")):
+        # the reference calls self.retrieval() - a draw from the seeded random.sample stream - at EVERY level when --retrieval=1
+        # (base_adaptor.py:256,309); the stepper calls back only at levels with a labelled term, which consumes the stream at a
+        # different rate when the two switches differ
+        return "", "labelled term on one level only with feature-driven retrieval"
     if g("teacher_dropout"):
         return "", "train-mode teacher"
     return "full", None

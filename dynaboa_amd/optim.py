@@ -19,7 +19,7 @@ def materialize_grad(p):
     pend = getattr(p, "_so_pending", None)
     if pend is None:
         return p.grad
-    h, alpha = pend
+    h, alpha = pend[0], pend[1]
     return p.grad - alpha * h
 
 
@@ -62,7 +62,15 @@ class Adam:
             pend = getattr(p, "_so_pending", None)
             if pend is not None:
                 # second order: the gradient is still g - alpha * h (MAML deferred its last accumulation, maml.py) - one launch
-                h, alpha = pend
+                h, alpha = pend[0], pend[1]
+                # the pair belongs to the gradient MAML left in .grad.  An in-place edit of .grad since (gradient clipping, a second
+                # backward accumulating into it) would be combined with a stale H v: .grad arrives here untouched (version 0) in the
+                # supported flow - say so loudly otherwise (a .grad REPLACED by a new tensor cannot be told apart; use
+                # dynaboa_amd.optim.materialize_grad(p) before editing gradients, or MAML(defer_accumulate=False))
+                if p.grad._version != 0:
+                    import warnings
+                    warnings.warn("second-order gradient: .grad was modified in place after backward() while its last accumulation "
+                                  "(v - lr * H v) was still deferred to Adam.step", RuntimeWarning, stacklevel=2)
                 p._so_pending = None
                 check(lib.dyb_adam_step_accum(p.data_ptr(), g.data_ptr(), h.data_ptr(), float(alpha), st["exp_avg"].data_ptr(),
                                               st["exp_avg_sq"].data_ptr(), b1, b2, step_size, bc2_sqrt, eps, p.numel(), stream_of(p)),
