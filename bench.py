@@ -42,6 +42,19 @@ RESNET_CONVS = [
     (1, 14, 14, 1024, 2048, 1, 2, 0), (2, 7, 7, 2048, 512, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1)]
 
 
+def csrc_sha16():
+    """Content hash of the kernel sources (dynaboa_amd/csrc/*): PMC summaries under profiles/ carry the hash of the sources they were
+    measured on, and a summary of other sources is not quoted (there is no .git on the GPU box to ask for a commit)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dynaboa_amd", "csrc", "*.*"))):
+        if f.endswith((".hip", ".inc", ".h")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per launch (read + write) of the conv kernel family from the newest committed PMC summary
     (profiles/r*_pmc_igemm_traffic.json, written by tools/pmc_summarize.py from two rocprofv3 runs of THIS command:
@@ -52,9 +65,12 @@ def pmc_traffic():
     try:
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_igemm_traffic.json")))[-1]
         d = json.load(open(path))
+        if d.get("csrc_sha16") != csrc_sha16():
+            return dict(bytes=None, note="the newest PMC summary (%s) was measured on other kernel sources (csrc hash %s, now %s): not quoted" %
+                                         (os.path.relpath(path, ROOT), d.get("csrc_sha16", d.get("commit", "?")), csrc_sha16()))
         return dict(bytes=float(d["hbm_bytes_per_launch"]),
-                    note="HBM read (FETCH_SIZE x2) + write (WRITE_SIZE) bytes per conv launch from %s, measured at commit %s" %
-                         (os.path.relpath(path, ROOT), d.get("commit", "unknown (round 1, before the K4 data gradient)")))
+                    note="HBM read (FETCH_SIZE x2) + write (WRITE_SIZE) bytes per conv launch from %s, measured on these kernel sources "
+                         "(csrc hash %s)" % (os.path.relpath(path, ROOT), d["csrc_sha16"]))
     except Exception:      # noqa: BLE001
         return None
 
@@ -65,19 +81,20 @@ def mfma_busy():
     sum over launches of busy cycles / (kernel cycles x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
     import glob
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_A_tp.json")))[-1]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_tp.json")))[-1]
         d = json.load(open(path))
+        if d.get("_csrc_sha16") != csrc_sha16():
+            return dict(value=None, note="the newest SQ-counter summary (%s) was measured on other kernel sources: not quoted" % os.path.relpath(path, ROOT))
         busy = cyc = 0.0
         for k, v in d.items():
-            if k.startswith("igemm_tp_kernel") and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+            if k.startswith("igemm_tp_kernel") and isinstance(v, dict) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
                 busy += v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["launches"]
                 cyc += v["GRBM_GUI_ACTIVE"] * v["launches"]
         if cyc <= 0:
             return None
         return dict(value=busy / (cyc / 8.0 * 1024.0),
                     note="SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over every igemm_tp_kernel launch of a "
-                         "16-sequence run, from %s (PMC pass: kernels serialised; taken before the buffer-addressed loaders)"
-                         % os.path.relpath(path, ROOT))
+                         "32-sequence run, from %s (PMC pass: kernels serialised; padded tile rows count as busy)" % os.path.relpath(path, ROOT))
     except Exception:      # noqa: BLE001
         return None
 

@@ -9,6 +9,9 @@
 // sigma = max(0, (in/out - 1) / 2) per axis (scipy.ndimage.gaussian_filter, truncate 4.0, boundary 'mirror'), then a
 // bilinear warp sampling input coordinate (j + 0.5) * in/out - 0.5 with the same mirror boundary.  The integer box
 // corners (the reference's `transform(..., invert=1)` arithmetic) are host logic and arrive as arguments.
+// Parity status: box / paste / normalise are pinned to the reference's crop() (golden g7); the resize is written from the
+// documented skimage defaults above and checked against the oracle's restatement of them + known answers - skimage itself is
+// absent from the build image, so resize parity against scikit-image 0.17.2 is unverified (tests/test_preprocess.py header).
 //
 // Three small kernels (the Gaussian is separable; axis 0 first, as scipy does): blur along rows reading the frame with
 // the zero fill of the paste, blur along columns, bilinear + normalise.  fp32 throughout (the reference computes the

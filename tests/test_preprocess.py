@@ -3,7 +3,14 @@ reference's on-disk formats, and the real retrieval path - on the kernel emulato
 
 Pins: golden g7 = the reference's own utils/dataprocess.py crop() / transform() run in the build container (with the
 oracle's restatement of scikit-image 0.17.2 `resize` plugged in, skimage being absent: tools/make_golden.py g7), plus
-first-principles known answers for that restatement."""
+first-principles known answers for that restatement.
+
+WHAT THIS DOES NOT PIN: the resize half.  scikit-image is not installed here, so the golden's resize is the oracle's
+restatement (oracle/ref_cpu.py skimage_resize: order 1, mode 'reflect', Gaussian anti-aliasing sigma = (s - 1) / 2, truncate 4), the
+same restatement csrc/preprocess.hip was written from - kernel vs golden is circular for that step.  Pinned by the reference's own
+code: the box / paste / keypoint arithmetic of crop() and transform().  Pinned by known answers only: the resize (constants,
+identity, linear ramps, energy of a blurred impulse).  Resize parity against real scikit-image 0.17.2 is UNVERIFIED until the g7
+arrays are regenerated where skimage exists (tools/make_golden.py g7 picks the real one up when importable)."""
 import ctypes
 import os
 import random

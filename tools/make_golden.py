@@ -421,7 +421,16 @@ def g7(out):
     restatement of scikit-image 0.17.2's defaults, so the fixtures pin the box / paste / keypoint arithmetic to the reference
     and the resize to the restatement."""
     dp = load_file("ref_dataprocess", "utils/dataprocess.py")
-    dp.resize = O.skimage_resize
+    real = False
+    try:                                        # the real scikit-image where it exists: then g7 pins the resize too
+        import importlib
+        for m in ("skimage", "skimage.transform"):
+            sys.modules.pop(m, None)
+        dp.resize = importlib.import_module("skimage.transform").resize
+        real = True
+    except Exception:      # noqa: BLE001
+        dp.resize = O.skimage_resize
+    print("g7 resize:", "scikit-image" if real else "oracle restatement (scikit-image absent: resize parity unpinned)")
     rng = np.random.default_rng(707)
     H, W = 150, 200
     yy, xx = np.mgrid[0:H, 0:W]

@@ -17,7 +17,7 @@ def fam(name):
     return name.startswith("igemm_mfma_kernel") or name.startswith("igemm_k4_") or name.startswith("igemm_tp_kernel")
 
 
-def main(fetch_json, write_json, commit, out, seqs=1):
+def main(fetch_json, write_json, commit, out, seqs=1, csrc_sha16=None):
     seqs = int(seqs)                      # sequences per launch of the profiled command: the streaming kernels move seqs arenas
     F, W = json.load(open(fetch_json))["kernels"], json.load(open(write_json))["kernels"]
     cal = {}
@@ -38,7 +38,7 @@ def main(fetch_json, write_json, commit, out, seqs=1):
         wr += w.get("total", w["per_launch"] * f["launches"]) * 1024
     res = dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) on "
                       "`bench.py --seqs %d --steps 2 --warmup 1 --no_roofline --no_sub_records --no_cpu_baseline --percentile_frames 0`" % seqs,
-               commit=commit, calibration=cal,
+               commit=commit, csrc_sha16=csrc_sha16, calibration=cal,
                kernel="every conv instantiation on the path (igemm_tp_kernel<...>, igemm_mfma_kernel<...>, igemm_k4_fwd_kernel, igemm_k4_dgrad_kernel)",
                launches=n, hbm_read_bytes_per_launch=rd / max(n, 1), hbm_write_bytes_per_launch=wr / max(n, 1),
                hbm_bytes_per_launch=(rd + wr) / max(n, 1), per_variant=per)
@@ -48,4 +48,4 @@ def main(fetch_json, write_json, commit, out, seqs=1):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
