@@ -61,6 +61,9 @@ struct IgemmArgs {
   int ktiles, tiles_per_split, nsplit;
   int xcd;               // throughput form: XCD-contiguous workgroup order
   int cls_tile0[4];      // throughput data gradient: first tile (grid x) of each phase class (stride 2)
+  int compact;           // throughput data gradient of a 1x1 stride-2 conv: only the one class that has a tap is computed, rows written
+                         // COMPACT (class-local index) into slabs of slab_rows rows; a scatter fold places them (run_igemm_tp)
+  int slab_rows;         // rows of one split-K slab (M unless compact)
   unsigned long long* probe;   // throughput form: per-wave phase clocks (dyb_conv_probe_set), normally NULL
 };
 
@@ -1322,6 +1325,38 @@ static unsigned long long* probe_for(int mode, const ConvDesc& d, long wgs) {
   return (p.buf && p.mode == mode && p.H == d.H && p.C == d.C && p.K == d.K && p.R == d.R && wgs <= p.cap_wgs) ? p.buf : nullptr;
 }
 
+// Fold of a COMPACT stride-2 1x1 data gradient: out[n][h][w][:] = (h, w both even ? sum_z slab[z][(n, h/2, w/2)][:] : 0) (+ addend).
+// The other three phase classes of such a conv receive no tap at all: they used to be tiles of their own that wrote zeros into
+// every split's slab (75 % of the slab traffic, and workgroups that only stored) - now the zeros are written once, here.
+__global__ __launch_bounds__(256) void fold_scatter_s2_kernel(const float4* __restrict__ slabs, int nsplit, size_t slab4,
+                                                               const float4* __restrict__ addend, float4* __restrict__ out, int N, int H,
+                                                               int W, int C4, int Hc, int Wc, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, slabs); DYB_RB(R, addend); DYB_RB(R, out);
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int w = (int)(pix % W);
+    const size_t t = pix / W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (((h | w) & 1) == 0) {
+      const size_t src = ((size_t)(n * Hc + (h >> 1)) * Wc + (w >> 1)) * C4 + c4;
+      s = slabs[src];
+      for (int z = 1; z < nsplit; ++z) {
+        const float4 v = slabs[(size_t)z * slab4 + src];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if (addend) {
+      const float4 a = addend[i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    out[i] = s;
+  }
+}
+
 #include "igemm_tp.inc"
 
 // The throughput form (igemm_tp.inc) of one mode; same contract as run_igemm below.
@@ -1368,20 +1403,31 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
     }
     g.ktiles = ((d.R + 1) >> 1) * ((d.S + 1) >> 1) * (d.K / TPK);      // the deepest class (split policy)
   }
+  // 1x1 stride-2 (the downsample convs): one class has the tap, three have none - compute that class alone into compact slabs
+  g.compact = 0;
+  g.slab_rows = g.M;
+  const int Hc = (d.H + 1) >> 1, Wc = (d.W + 1) >> 1;
+  if (classes && d.R == 1 && d.S == 1 && d.pad == 0 && ws && (size_t)d.N * Hc * Wc * g.Ncols * sizeof(float) <= ws_bytes) {
+    g.compact = 1;
+    g.slab_rows = d.N * Hc * Wc;
+    mtiles = work_mtiles = dyb_cdiv(g.slab_rows, TM);
+    g.cls_tile0[0] = 0;
+    g.cls_tile0[1] = g.cls_tile0[2] = g.cls_tile0[3] = 0x7fffffff;
+  }
   const long tiles = (long)work_mtiles * dyb_cdiv(g.Ncols, TN) * R.n;
   int s = (int)(switches().tp_grid.load(std::memory_order_relaxed) / tiles);
   const int maxs = g.ktiles / 4 > 0 ? g.ktiles / 4 : 1;                 // every split keeps >= 4 K-steps
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
-  const size_t per = (size_t)g.M * g.Ncols, ws_floats = ws ? ws_bytes / sizeof(float) : 0;
+  const size_t per = (size_t)g.slab_rows * g.Ncols, ws_floats = ws ? ws_bytes / sizeof(float) : 0;
   while (s > 1 && (size_t)s * per > ws_floats) --s;
   g.nsplit = s;
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);
   if (raw_slabs_out) *raw_slabs_out = 1;
   const bool split = g.nsplit > 1;
-  g.out = split ? reinterpret_cast<float*>(ws) : out;
-  g.addend = split ? nullptr : addend;
+  g.out = (split || g.compact) ? reinterpret_cast<float*>(ws) : out;          // (compact: always through the scatter fold)
+  g.addend = (split || g.compact) ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);
@@ -1441,6 +1487,15 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
 #undef DYB_TP_LAUNCH3
 #undef DYB_TP_LAUNCH_BF
   DYB_CHECK_LAUNCH();
+  if (g.compact) {
+    const size_t tot4 = (size_t)g.M * g.Ncols / 4;
+    int blocks = (int)((tot4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fold_scatter_s2_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(ws), g.nsplit, per / 4,
+                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), d.N, d.H, d.W, g.Ncols / 4, Hc, Wc, R);
+    DYB_CHECK_LAUNCH();
+    return DYB_OK;
+  }
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
     size_t n4 = per / 4;
@@ -1543,6 +1598,32 @@ extern "C" int dyb_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
                                      int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
   ConvDesc d{N, H, W, C, K, R, S, stride, pad};
   return run_igemm(MODE_WGRAD, d, x, dy, dw, nullptr, ws, ws_bytes, nullptr, st);
+}
+
+// Diagnostic (tools/tp_lab.py): one convolution mode for `nrep` sequence replicas in ONE launch, the way the native stepper issues
+// them - x / w / dy / out are [nrep][...] stacks (replica stride = one tensor), each replica with its own weights.  mode 0 forward
+// (out = y), 1 data gradient (x unused, out = dx), 2 weight gradient (w unused, out = dw).  ws: nrep equal slices.
+extern "C" int dyb_debug_conv_replicas(int mode, const float* x, const float* w, const float* dy, float* out, int nrep, int N, int H,
+                                       int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(mode >= 0 && mode <= 2 && nrep >= 1 && nrep <= DYB_MAX_REPLICAS && out, DYB_ERR_ARG);
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  const int Ho = conv_out_dim(H, R, stride, pad), Wo = conv_out_dim(W, S, stride, pad);
+  const size_t nx = (size_t)N * H * W * C, nw = (size_t)R * S * C * K, ny = (size_t)N * Ho * Wo * K;
+  DybRep Rp{};
+  Rp.n = nrep;
+  dyb_rep_identity(Rp);
+  auto arena = [&](const void* lo, size_t bytes) {
+    if (!lo) return;
+    Rp.lo[Rp.narenas] = reinterpret_cast<const char*>(lo); Rp.span[Rp.narenas] = bytes; Rp.stride[Rp.narenas] = bytes; ++Rp.narenas;
+  };
+  arena(x, nx * 4); arena(w, nw * 4); arena(dy, ny * 4);
+  arena(out, (mode == 0 ? ny : mode == 1 ? nx : nw) * 4);
+  const size_t wsl = (ws_bytes / (size_t)nrep) & ~(size_t)255;
+  arena(ws, wsl);
+  DybRepScope scope(Rp);
+  if (mode == 0) return run_igemm(MODE_FWD, d, x, w, out, nullptr, ws, wsl, nullptr, st);
+  if (mode == 1) return run_igemm(MODE_DGRAD, d, dy, w, out, nullptr, ws, wsl, nullptr, st);
+  return run_igemm(MODE_WGRAD, d, x, dy, out, nullptr, ws, wsl, nullptr, st);
 }
 
 // ---- data / weight gradient with the GroupNorm backward of the conv's output formed in the loader ----

@@ -290,6 +290,11 @@ int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* o
  * DYB_K4_BATCH, DYB_K4_MAXC) once at first use - never on the dispatch path - and changed here afterwards.
  * names: "k4" single-launch 1x1 forward conv + statistics; "k4_bwd" 1x1 data gradient carrying the producer's
  * GroupNorm-backward reduce; "k4_batch" both at batch > 1; "k4_maxc" their channel limit. */
+/* Diagnostic: one convolution mode (0 forward, 1 data gradient, 2 weight gradient) for `nrep` sequence replicas in one launch -
+ * x / w / dy / out are [nrep][...] stacks, every replica with its own weights (what the native stepper's launches look like); used by
+ * tools/tp_lab.py to time a layer's kernels alone. */
+int dyb_debug_conv_replicas(int mode, const float* x, const float* w, const float* dy, float* out, int nrep, int N, int H, int W, int C,
+                            int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 
