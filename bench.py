@@ -595,7 +595,7 @@ def main():
                 if S == seqs:
                     continue
                 try:
-                    reps[f"S{S}"] = replica_run(device, S, max(20, args.steps // 2), 6, args.batch, args.inner_step)
+                    reps[f"S{S}"] = replica_run(device, S, max(12, args.steps // 2), 4, args.batch, args.inner_step)
                 except Exception as e:      # noqa: BLE001
                     reps[f"S{S}"] = dict(value=None, error=f"{type(e).__name__}: {e}")
                 torch.cuda.empty_cache()
@@ -603,15 +603,15 @@ def main():
                 note="aggregate frames/s with S independent sequences adapted in lockstep on this ONE GPU (batch 1 each, own weights / "
                      "Adam state / records; every launch of the per-frame chain covers all S); S1 = one sequence alone (the latency "
                      "configuration); the headline `value` uses S = %d" % seqs, **reps)
-            out["second_order"] = sub_record(device, "second_order", 12, 3, 1, args.inner_step,
+            out["second_order"] = sub_record(device, "second_order", 8, 2, 1, args.inner_step,
                                              "configs[1] second-order arm: one sequence, second_order=1, exact Hessian-vector products "
                                              "(tangent passes through the network, forward-over-reverse; the default)", second_order=1,
                                              hvp="exact")
-            out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 24, 4, 1, args.inner_step,
+            out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 12, 3, 1, args.inner_step,
                                                     "the same with --hvp fd: Hessian-vector products as central differences of two "
                                                     "first-order gradients of the level (+2 forward+backward per inner step)",
                                                     second_order=1, hvp="fd")
-            out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 16, 4, 8, args.inner_step,
+            out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 10, 3, 8, args.inner_step,
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
                                                  upper_level_mixtrain=1, sample_num=8)
@@ -643,7 +643,7 @@ def main():
                     "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
             finally:
                 _L.load().dyb_set_option(b"tp_batch_min", 16)
-            out["full_default_losses"] = sub_record(device, "full_default_losses", 40, 8, 1, 1,
+            out["full_default_losses"] = sub_record(device, "full_default_losses", 24, 6, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)
             torch.cuda.empty_cache()

@@ -909,8 +909,7 @@ static int stage_inputs(Stepper& S, const void* const* src, int ld, int k0, int 
 static DybRep make_scope(const Stepper& S, const int* idx, int n) {
   DybRep R{};
   dyb_rep_identity(R);
-  R.n = n;
-  for (int i = 0; i < n; ++i) R.map[i] = (unsigned char)idx[i];
+  dyb_rep_set_map(R, idx, n);
   auto arena = [&](const void* lo, size_t bytes) {
     if (!lo || !bytes || R.narenas >= DYB_MAX_ARENAS) return;
     R.lo[R.narenas] = reinterpret_cast<const char*>(lo);
@@ -1004,8 +1003,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
       {
         // the replicas still adapting get a scope of their own (one replica without replica machinery: the scope it came with)
         DybRep sub = outer;
-        sub.n = ncont;
-        for (int i = 0; i < ncont; ++i) sub.map[i] = (unsigned char)cont[i];
+        dyb_rep_set_map(sub, cont, ncont);
         DybRepScope scope(sub);
         C.level_row = K + step;
         RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));

@@ -70,6 +70,8 @@ __device__ __forceinline__ float dyb_wave_sum(float v) {
 struct DybRep {
   int n;                                        // replicas covered by the launch
   int narenas;
+  int ident;                                    // map[] is the identity: kernels skip the lookup (one dependent scalar load at the
+  int pad_;                                     // top of EVERY kernel - 0.9 ms over the ~1700 launches of a one-sequence frame)
   const char* lo[DYB_MAX_ARENAS];               // replica 0's range of each arena
   unsigned long long span[DYB_MAX_ARENAS];      // bytes
   unsigned long long stride[DYB_MAX_ARENAS];    // bytes between consecutive replicas
@@ -77,6 +79,15 @@ struct DybRep {
 };
 static inline void dyb_rep_identity(DybRep& R) {
   for (int i = 0; i < DYB_MAX_REPLICAS; ++i) R.map[i] = (unsigned char)i;
+  R.ident = 1;
+}
+static inline void dyb_rep_set_map(DybRep& R, const int* idx, int n) {
+  R.n = n;
+  R.ident = 1;
+  for (int i = 0; i < n; ++i) {
+    R.map[i] = (unsigned char)idx[i];
+    if (idx[i] != i) R.ident = 0;
+  }
 }
 template <class T>
 __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
@@ -92,7 +103,7 @@ __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
 #define DYB_REP_PROLOGUE(R)                                   \
   const unsigned dyb_gz = gridDim.z / (unsigned)(R).n;        \
   const int dyb_lrep = (int)(blockIdx.z / dyb_gz);            \
-  const int dyb_rep = (int)(R).map[dyb_lrep];                 \
+  const int dyb_rep = (R).ident ? dyb_lrep : (int)(R).map[dyb_lrep]; \
   const unsigned dyb_bz = blockIdx.z - (unsigned)dyb_lrep * dyb_gz; \
   (void)dyb_bz
 #define DYB_RB(R, p) \
