@@ -251,6 +251,8 @@ struct Stepper {
   const float *gmm_means = nullptr, *gmm_prec = nullptr, *gmm_logw = nullptr, *j_h36m = nullptr;
   const int* j14 = nullptr;
   float *records = nullptr, *loss_log = nullptr;
+  const char* logs_base = nullptr;    // replica 0's block holding records | loss_log | gate_log | feat5_out (one replica arena for all four)
+  size_t logs_bytes = 0;
   int record_capacity = 0, loss_capacity = 0;
   // workspace
   char* wsp = nullptr;
@@ -435,6 +437,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
     DYB_REQUIRE(v >= 1 && v <= DYB_MAX_REPLICAS && !S->bound, DYB_ERR_ARG);
     S->nrep = (int)v;
   }
+  else if (k == "logs_bytes") S->logs_bytes = (size_t)v;
   else if (k == "record_capacity") S->record_capacity = (int)v;
   else if (k == "loss_capacity") S->loss_capacity = (int)v;
   else return DYB_ERR_ARG;
@@ -475,6 +478,7 @@ extern "C" int dyb_stepper_set_p(void* stepper, const char* key, const void* p) 
   else if (k == "gmm_log_weights") S->gmm_logw = (const float*)p;
   else if (k == "j_regressor_h36m") S->j_h36m = (const float*)p;
   else if (k == "j14") S->j14 = (const int*)p;
+  else if (k == "logs_base") S->logs_base = (const char*)p;
   else if (k == "records") S->records = (float*)p;
   else if (k == "loss_log") S->loss_log = (float*)p;
   else if (k == "teacher") S->teacher = (float*)p;
@@ -659,7 +663,7 @@ static int adam_scope(Stepper& S, hipStream_t st) {
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
   for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
   for (int i = 0; i < R.n; ++i) {
-    const int r = R.map[i];
+    const int r = dyb_rep_phys(R, i);
     const double t = (double)(++S.adam_t_rep[r]);
     ss[r] = (float)(S.lr / (1.0 - pow(S.beta1, t)));
     bc[r] = (float)sqrt(1.0 - pow(S.beta2, t));
@@ -815,7 +819,7 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
       const void* exin[5 * DYB_MAX_REPLICAS];
       for (int k = 0; k < 5 * DYB_MAX_REPLICAS; ++k) exin[k] = nullptr;
       for (int i = 0; i < R.n; ++i) {
-        const int r = R.map[i];
+        const int r = dyb_rep_phys(R, i);
         const void* one[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if (S.retrieve_rep(S.retrieve_user, level_index, r, one) != 0) return DYB_ERR_ARG;
         for (int k = 0; k < 5; ++k) {
@@ -879,7 +883,7 @@ static int gate_cosine(Stepper& S, const float* actsA, const float* actsB, float
   // the one host wait of the dynamic loop (the reference's `.item()`, dynaboa_benchmark.py:165): a poll of pinned memory the
   // kernel writes, no stream synchronise / device-to-host copy call
   for (int i = 0; i < R.n; ++i) {
-    const int r = R.map[i];
+    const int r = dyb_rep_phys(R, i);
     long spins = 0;
     while (S.gate_host[16 * r + 15] != S.gate_seq) {
       if (++spins > 2000000000L) return DYB_ERR_LAUNCH;
@@ -899,7 +903,7 @@ static int stage_inputs(Stepper& S, const void* const* src, int ld, int k0, int 
     DYB_REQUIRE(S.in_stage[k0 + k], DYB_ERR_ARG);
     g.dst[k] = S.in_stage[k0 + k];
     g.n[k] = (unsigned)cnt[k0 + k];
-    for (int i = 0; i < R.n; ++i) g.src[k][R.map[i]] = reinterpret_cast<const float*>(src[(size_t)k * ld + R.map[i]]);
+    for (int i = 0; i < R.n; ++i) g.src[k][dyb_rep_phys(R, i)] = reinterpret_cast<const float*>(src[(size_t)k * ld + dyb_rep_phys(R, i)]);
   }
   hipLaunchKernelGGL(gather_inputs_kernel, dim3(64, nk, R.n), dim3(256), 0, st, g, R);
   DYB_CHECK_LAUNCH();
@@ -922,13 +926,17 @@ static DybRep make_scope(const Stepper& S, const int* idx, int n) {
   arena(S.theta, S.n_params * sizeof(float));
   arena(S.adam_m, S.n_params * sizeof(float));
   arena(S.adam_v, S.n_params * sizeof(float));
-  arena(S.records, (size_t)S.record_capacity * a64((size_t)S.B * 85 + 1) * sizeof(float));
-  arena(S.loss_log, (size_t)S.loss_capacity * (S.full ? 16 : 4) * rows * sizeof(float));
-  if (S.full) {
-    arena(S.teacher, S.n_params * sizeof(float));
-    arena(S.gate_log, (size_t)S.loss_capacity * (1 + S.optim_steps) * 16 * sizeof(float));
-    arena(S.feat5_out, (size_t)S.B * 2048 * sizeof(float));
+  if (S.logs_base && S.logs_bytes) {
+    arena(S.logs_base, S.logs_bytes);              // records, loss_log, gate_log, feat5_out: sub-buffers of one per-replica block
+  } else {
+    arena(S.records, (size_t)S.record_capacity * a64((size_t)S.B * 85 + 1) * sizeof(float));
+    arena(S.loss_log, (size_t)S.loss_capacity * (S.full ? 16 : 4) * rows * sizeof(float));
+    if (S.full) {
+      arena(S.gate_log, (size_t)S.loss_capacity * (1 + S.optim_steps) * 16 * sizeof(float));
+      arena(S.feat5_out, (size_t)S.B * 2048 * sizeof(float));
+    }
   }
+  if (S.full) arena(S.teacher, S.n_params * sizeof(float));
   return R;
 }
 // the replicas the next frame step covers (ascending physical indices; n = 0: all).  Sequences of different lengths: a replica
@@ -966,7 +974,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
   C.level_row = 0;
   int slot = record_slot;
   const DybRep outer = dyb_rep_current();                 // (copy: nested scopes below replace the thread's current one)
-  for (int i = 0; i < outer.n; ++i) extra[outer.map[i]] = 0;
+  for (int i = 0; i < outer.n; ++i) extra[dyb_rep_phys(outer, i)] = 0;
   if (metrics) RUN(gt_meshes(S, (const float*)C.in[IN_GT_POSE], (const float*)C.in[IN_GT_BETAS], st));
   const float* cur = S.theta;
   for (int i = 0; i <= K; ++i) {
@@ -992,7 +1000,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
     RUN(gate_cosine(S, S.lvl0.acts, S.fin.acts, glog, cos12, st));     // (inner_step 0: the upper level's own forward is lvl0)
     int cont[DYB_MAX_REPLICAS], ncont = 0;
     for (int i = 0; i < outer.n; ++i)
-      if (1.f - cos12[outer.map[i]] > (float)S.cos_thr) cont[ncont++] = outer.map[i];
+      if (1.f - cos12[dyb_rep_phys(outer, i)] > (float)S.cos_thr) cont[ncont++] = dyb_rep_phys(outer, i);
     int step = 0;
     while (ncont > 0) {
       ++step;

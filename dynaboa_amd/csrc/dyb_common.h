@@ -65,29 +65,42 @@ __device__ __forceinline__ float dyb_wave_sum(float v) {
 // A launch may also cover a SUBSET of the replicas (the "active set": sequences still inside the dynamic-BOA loop, sequences
 // that have frames left): `map[i]` is the physical replica - the index its arenas are addressed with - of the launch's i-th
 // replica.  Identity outside such a scope.
-#define DYB_MAX_ARENAS 12
+#define DYB_MAX_ARENAS 8       // (every arena is three 64-bit kernel-argument words each kernel compares its pointers against: 12 of them pushed
+                               // five register-heavy kernels past the scalar-register file and their DybRep argument into scratch)
 #define DYB_MAX_REPLICAS 64
 struct DybRep {
   int n;                                        // replicas covered by the launch
   int narenas;
-  int ident;                                    // map[] is the identity: kernels skip the lookup (one dependent scalar load at the
-  int pad_;                                     // top of EVERY kernel - 0.9 ms over the ~1700 launches of a one-sequence frame)
+  int ident;                                    // the map is the identity: kernels skip the decode
+  int pad_;
   const char* lo[DYB_MAX_ARENAS];               // replica 0's range of each arena
   unsigned long long span[DYB_MAX_ARENAS];      // bytes
   unsigned long long stride[DYB_MAX_ARENAS];    // bytes between consecutive replicas
-  unsigned char map[DYB_MAX_REPLICAS];          // launch replica -> physical replica
+  // launch replica -> physical replica, ten 6-bit entries per word.  (Not a byte array: a dynamically indexed member of a by-value
+  // kernel argument made the compiler copy the whole struct to scratch in three register-heavy kernels - GroupNorm apply ran 2x
+  // slower; the decode below only ever indexes with constants.)
+  unsigned long long mapw[7];
 };
+static inline int dyb_rep_phys(const DybRep& R, int i) { return (int)((R.mapw[i / 10] >> (6 * (i % 10))) & 63ull); }
 static inline void dyb_rep_identity(DybRep& R) {
-  for (int i = 0; i < DYB_MAX_REPLICAS; ++i) R.map[i] = (unsigned char)i;
+  for (int w = 0; w < 7; ++w) R.mapw[w] = 0;
+  for (int i = 0; i < DYB_MAX_REPLICAS; ++i) R.mapw[i / 10] |= (unsigned long long)i << (6 * (i % 10));
   R.ident = 1;
 }
 static inline void dyb_rep_set_map(DybRep& R, const int* idx, int n) {
   R.n = n;
   R.ident = 1;
   for (int i = 0; i < n; ++i) {
-    R.map[i] = (unsigned char)idx[i];
+    R.mapw[i / 10] = (R.mapw[i / 10] & ~(63ull << (6 * (i % 10)))) | ((unsigned long long)(idx[i] & 63) << (6 * (i % 10)));
     if (idx[i] != i) R.ident = 0;
   }
+}
+__device__ __forceinline__ int dyb_rep_phys_dev(const DybRep& R, int l) {
+  const int q = (l * 205) >> 11, r = l - 10 * q;                  // l / 10 for l < 64
+  unsigned long long w = R.mapw[0];
+  w = q == 1 ? R.mapw[1] : w; w = q == 2 ? R.mapw[2] : w; w = q == 3 ? R.mapw[3] : w;
+  w = q == 4 ? R.mapw[4] : w; w = q == 5 ? R.mapw[5] : w; w = q == 6 ? R.mapw[6] : w;
+  return (int)((w >> (6 * r)) & 63ull);
 }
 template <class T>
 __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
@@ -103,7 +116,7 @@ __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
 #define DYB_REP_PROLOGUE(R)                                   \
   const unsigned dyb_gz = gridDim.z / (unsigned)(R).n;        \
   const int dyb_lrep = (int)(blockIdx.z / dyb_gz);            \
-  const int dyb_rep = (R).ident ? dyb_lrep : (int)(R).map[dyb_lrep]; \
+  const int dyb_rep = (R).ident ? dyb_lrep : dyb_rep_phys_dev((R), dyb_lrep); \
   const unsigned dyb_bz = blockIdx.z - (unsigned)dyb_lrep * dyb_gz; \
   (void)dyb_bz
 #define DYB_RB(R, p) \

@@ -159,8 +159,18 @@ class NativeStepper:
         if self.full:
             self.slots_per_frame = int(lib.dyb_stepper_get_i(h, b"slots_per_frame"))
         cap = max(1, nframes)
-        self.records = torch.zeros(S, cap * self.slots_per_frame, self.rec_floats, device=dev)
-        self.loss_log = torch.zeros(S, cap, self.loss_floats, device=dev)
+        # records | loss log | gate log | pooled feature of every replica live in ONE [S][block] tensor: one replica arena for the
+        # kernels' pointer rebasing instead of four (the arena table is kernel-argument state: csrc/dyb_common.h)
+        n_rec, n_loss = cap * self.slots_per_frame * self.rec_floats, cap * self.loss_floats
+        n_gate = cap * (1 + self.optim_steps) * 16 if self.full else 0
+        n_feat = B * 2048 if self.full else 0
+        pad64 = lambda n: (n + 63) // 64 * 64
+        o_loss, o_gate, o_feat = pad64(n_rec), pad64(n_rec) + pad64(n_loss), pad64(n_rec) + pad64(n_loss) + pad64(n_gate)
+        self.logs = torch.zeros(S, o_feat + pad64(n_feat), device=dev)
+        self.records = self.logs[:, :n_rec].view(S, cap * self.slots_per_frame, self.rec_floats)
+        self.loss_log = self.logs[:, o_loss:o_loss + n_loss].view(S, cap, self.loss_floats)
+        sp("logs_base", self.logs)
+        si("logs_bytes", self.logs.shape[1] * 4)
         si("record_capacity", cap * self.slots_per_frame); si("loss_capacity", cap)
         sp("records", self.records); sp("loss_log", self.loss_log)
         if self.full:
@@ -174,8 +184,8 @@ class NativeStepper:
                         a.teacher.theta.data = self.teacher[r]
                     sp("teacher", self.teacher)
             self.gate_host = torch.zeros(16 * S).pin_memory() if dev.type == "cuda" else torch.zeros(16 * S)
-            self.gate_log = torch.zeros(S, cap, 1 + self.optim_steps, 16, device=dev)
-            self.feat5 = torch.zeros(S, B, 2048, device=dev)
+            self.gate_log = self.logs[:, o_gate:o_gate + n_gate].view(S, cap, 1 + self.optim_steps, 16)
+            self.feat5 = self.logs[:, o_feat:o_feat + n_feat].view(S, B, 2048)
             sp("gate_host", self.gate_host); sp("gate_log", self.gate_log); sp("feat5_out", self.feat5)
             self._cb = None
             if (o.lower_level_mixtrain or o.upper_level_mixtrain) and getattr(adaptor, "bundle", None) is None:
