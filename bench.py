@@ -42,14 +42,19 @@ RESNET_CONVS = [
     (1, 14, 14, 1024, 2048, 1, 2, 0), (2, 7, 7, 2048, 512, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1)]
 
 
+# sources of the second-order-only kernels: the measured (first-order, 32-sequence) run never launches them
+PMC_HASH_EXCLUDE = ("hvp_kernels.hip", "hvp_engine.inc")
+
+
 def csrc_sha16():
-    """Content hash of the kernel sources (dynaboa_amd/csrc/*): PMC summaries under profiles/ carry the hash of the sources they were
-    measured on, and a summary of other sources is not quoted (there is no .git on the GPU box to ask for a commit)."""
+    """Content hash of the kernel sources the benchmarked path is built from (dynaboa_amd/csrc/* minus PMC_HASH_EXCLUDE): PMC summaries
+    under profiles/ carry the hash of the sources they were measured on, and a summary of other sources is not quoted (there is no
+    .git on the GPU box to ask for a commit)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "dynaboa_amd", "csrc", "*.*"))):
-        if f.endswith((".hip", ".inc", ".h")):
+        if f.endswith((".hip", ".inc", ".h")) and os.path.basename(f) not in PMC_HASH_EXCLUDE:
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
