@@ -536,7 +536,9 @@ def main():
                                       "faithful), %d HMR forwards + %d backwards executed per frame%s; native frame stepper: %s; "
                                       "metric flush (Procrustes + D2H) inside the clock" %
                                       (args.batch, args.inner_step,
-                                       "second-order (finite-difference Hessian-vector products: +2 forward+backward per inner step)"
+                                       ("second-order (exact Hessian-vector products: one tangent pass through the forward and one through the "
+                                        "backward per inner step, beside the first-order passes)" if args.hvp == "exact" else
+                                        "second-order (finite-difference Hessian-vector products: +2 forward+backward per inner step)")
                                        if args.second_order else "first-order (reference parity mode)",
                                        "reference default loss set" if args.full_losses else "frame losses only", how,
                                        args.schedule, fwd_ref, fwd_pf, args.inner_step + 1,

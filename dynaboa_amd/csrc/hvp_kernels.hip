@@ -5,8 +5,10 @@
 // the first-order kernels on tangent operands; what is left is GroupNorm(+ReLU, +residual) - forward tangent and the tangent
 // of its backward - and the max-pool gather.  These are those kernels; hvp_engine.inc walks the network with them.
 //
-// One workgroup per (image, group) sweeps its HW x C/4 slab twice (sums, then outputs): the second-order path is a
-// verification-grade mode, not the throughput path, and the slab is L2-hot on the second sweep.
+// A (image, group) slab of HW x C/4 values is cut into `chunks` row ranges, one workgroup each: a sums launch leaves per-chunk
+// partial sums (double) in scratch, the apply launch adds them up in chunk order (the same order in every workgroup: results do not
+// depend on the chunk count's scheduling) and writes its rows.  At one image per call a layer has 4 slabs - 4 workgroups on a
+// 256-CU part without the cut (profiles/r03_so_kernel_stats_S1.csv: 50 / 70 us per launch, 34 % of the second-order frame).
 #include "dyb_common.h"
 
 #define G DYB_GN_GROUPS
@@ -27,37 +29,93 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* s_red) {
   __syncthreads();
 }
 
+// chunk geometry of a slab: rows per chunk (>= 1) and the chunk count, from a target of ~1024 float4 per workgroup; images x chunks
+// stays <= 128 so that the per-channel column sums stay a short loop
+struct GnJvpGeom { int chunks, rows; };
+static GnJvpGeom gn_jvp_geom(int N, int HW, int C) {
+  const int cq = C / G / 4;
+  int want = dyb_cdiv(HW * cq, 1024);
+  int cap = 128 / N;
+  if (cap > 64) cap = 64;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  GnJvpGeom g;
+  g.rows = dyb_cdiv(HW, want);
+  g.chunks = dyb_cdiv(HW, g.rows);
+  return g;
+}
+// floats of scratch the two entry points need: partial sums [N][G][chunks][4] (double) + per-chunk channel sums [N][chunks][2][C]
+extern "C" size_t dyb_gn_jvp_scratch_floats(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0 || C % 16) return 0;
+  const GnJvpGeom g = gn_jvp_geom(N, HW, C);
+  return (size_t)N * G * g.chunks * 4 * 2 + (size_t)N * g.chunks * 2 * C;
+}
+
+// sum of K doubles over the chunks of slab (n, g), in chunk order
+template <int K>
+__device__ __forceinline__ void chunk_total(const double* __restrict__ part, int slab, int chunks, double (&v)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int ch = 0; ch < chunks; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += part[((size_t)slab * chunks + ch) * K + k];
+}
+
 // out = relu?(gamma * xhat + beta + res), tangent tout = mask * (tgamma * xhat + gamma * txhat + tbeta + tres) with
 // xhat = (y - mu) r, txhat = r (ty - tmu - xhat a), tmu = mean(ty), a = mean(xhat ty) over the group; (tmu, a) saved for the
-// backward tangent.  grid (G, N), block 256.
-__global__ __launch_bounds__(256) void gn_jvp_fwd_kernel(const float* __restrict__ y, const float* __restrict__ ty,
-                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ tgamma,
-                                                         const float* __restrict__ tbeta, const float* __restrict__ res,
-                                                         const float* __restrict__ tres, float* __restrict__ out,
-                                                         float* __restrict__ tout, float* __restrict__ tstats, int HW, int C,
-                                                         int relu) {
+// backward tangent.  grid (chunks, G, N), block 256.  Sums: part[slab][chunk][2] = (sum ty, sum xhat ty) of the chunk's rows;
+// with ty2 the tangent is ty + ty2 (the two halves of a convolution's tangent), summed into ty on the way.
+__global__ __launch_bounds__(256) void gn_jvp_fwd_sums_kernel(const float* __restrict__ y, float* __restrict__ ty,
+                                                              const float* __restrict__ ty2, const float* __restrict__ stats,
+                                                              double* __restrict__ part, int HW, int C, int rows) {
   __shared__ double s_red[4 * 2];
-  const int g = blockIdx.x, n = blockIdx.y, Cg = C / G, cq = Cg >> 2;
-  const float mu = stats[((size_t)n * G + g) * 2], r = stats[((size_t)n * G + g) * 2 + 1];
+  const int ch = blockIdx.x, g = blockIdx.y, n = blockIdx.z, Cg = C / G, cq = Cg >> 2;
+  const int slab = n * G + g;
+  const float mu = stats[(size_t)slab * 2], r = stats[(size_t)slab * 2 + 1];
   const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
-  const int total = HW * cq;
+  const int r0 = ch * rows, r1 = (r0 + rows < HW) ? r0 + rows : HW;
   double acc[2] = {0.0, 0.0};
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = r0 * cq + threadIdx.x; i < r1 * cq; i += 256) {
     const size_t off = base + (size_t)(i / cq) * C + (size_t)(i % cq) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
+    const float4 v = *reinterpret_cast<const float4*>(y + off);
+    float4 t = *reinterpret_cast<const float4*>(ty + off);
+    if (ty2) {
+      const float4 u = *reinterpret_cast<const float4*>(ty2 + off);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      *reinterpret_cast<float4*>(ty + off) = t;
+    }
     acc[0] += (double)t.x + (double)t.y + (double)t.z + (double)t.w;
     acc[1] += (double)((v.x - mu) * r) * t.x + (double)((v.y - mu) * r) * t.y + (double)((v.z - mu) * r) * t.z +
               (double)((v.w - mu) * r) * t.w;
   }
   block_sum<2>(acc, s_red);
+  if (threadIdx.x == 0) {
+    part[((size_t)slab * gridDim.x + ch) * 2] = acc[0];
+    part[((size_t)slab * gridDim.x + ch) * 2 + 1] = acc[1];
+  }
+}
+__global__ __launch_bounds__(256) void gn_jvp_fwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ ty,
+                                                               const float* __restrict__ stats, const double* __restrict__ part,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ tgamma, const float* __restrict__ tbeta,
+                                                               const float* __restrict__ res, const float* __restrict__ tres,
+                                                               float* __restrict__ out, float* __restrict__ tout,
+                                                               float* __restrict__ tstats, int HW, int C, int rows, int relu) {
+  const int ch = blockIdx.x, g = blockIdx.y, n = blockIdx.z, Cg = C / G, cq = Cg >> 2;
+  const int slab = n * G + g;
+  const float mu = stats[(size_t)slab * 2], r = stats[(size_t)slab * 2 + 1];
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
+  double acc[2];
+  chunk_total<2>(part, slab, gridDim.x, acc);
   const double cnt = (double)HW * (double)Cg;
   const float tmu = (float)(acc[0] / cnt), a = (float)(acc[1] / cnt);
-  if (threadIdx.x == 0 && tstats) {
-    tstats[((size_t)n * G + g) * 2] = tmu;
-    tstats[((size_t)n * G + g) * 2 + 1] = a;
+  if (threadIdx.x == 0 && ch == 0 && tstats) {
+    tstats[(size_t)slab * 2] = tmu;
+    tstats[(size_t)slab * 2 + 1] = a;
   }
-  for (int i = threadIdx.x; i < total; i += 256) {
+  const int r0 = ch * rows, r1 = (r0 + rows < HW) ? r0 + rows : HW;
+  for (int i = r0 * cq + threadIdx.x; i < r1 * cq; i += 256) {
     const int c = g * Cg + (i % cq) * 4;
     const size_t off = base + (size_t)(i / cq) * C + (size_t)(i % cq) * 4;
     const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
@@ -97,52 +155,57 @@ __global__ __launch_bounds__(256) void gn_jvp_fwd_kernel(const float* __restrict
 // dxh = gamma dm, c1 = mean(dxh), c2 = mean(dxh xhat), dy = r (dxh - c1 - xhat c2);
 // tdxh = tgamma dm + gamma tdm, tc1 = mean(tdxh), tc2 = mean(tdxh xhat + dxh txhat), tr = -r^2 a,
 // tdy = tr (dxh - c1 - xhat c2) + r (tdxh - tc1 - txhat c2 - xhat tc2);
-// per image and channel: tdgb[n][0][c] = sum_p tdm (tangent of dbeta), tdgb[n][1][c] = sum_p (tdm xhat + dm txhat) (of dgamma).
-// grid (G, N), block 256.
-__global__ __launch_bounds__(256) void gn_jvp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ tdout,
-                                                         const float* __restrict__ out_mask, const float* __restrict__ y,
-                                                         const float* __restrict__ ty, const float* __restrict__ stats,
-                                                         const float* __restrict__ tstats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ tgamma, float* __restrict__ dm,
-                                                         float* __restrict__ tdm, float* __restrict__ dy, float* __restrict__ tdy,
-                                                         float* __restrict__ tdgb, int HW, int C, int relu) {
+// per chunk and channel: tdgb[n][chunk][0][c] = sum_p tdm (tangent of dbeta), tdgb[n][chunk][1][c] = sum_p (tdm xhat + dm txhat)
+// (of dgamma).  grid (chunks, G, N), block 256: sums (part[slab][chunk][4] + the channel sums), then apply.
+struct GnJvpBwdIn {
+  const float *dout, *tdout, *out_mask, *y, *ty;
+  float mu, r, tmu, a;
+  int relu;
+};
+__device__ __forceinline__ void gn_jvp_bwd_fetch(const GnJvpBwdIn& in, size_t off, float (&d)[4], float (&td)[4], float (&xh)[4],
+                                                 float (&txh)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(in.y + off), t = *reinterpret_cast<const float4*>(in.ty + off);
+  const float4 d4 = *reinterpret_cast<const float4*>(in.dout + off), t4 = *reinterpret_cast<const float4*>(in.tdout + off);
+  const float vv[4] = {v.x, v.y, v.z, v.w}, tt[4] = {t.x, t.y, t.z, t.w};
+  d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+  td[0] = t4.x; td[1] = t4.y; td[2] = t4.z; td[3] = t4.w;
+  if (in.relu) {
+    const float4 m = *reinterpret_cast<const float4*>(in.out_mask + off);
+    const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (!(mm[k] > 0.f)) { d[k] = 0.f; td[k] = 0.f; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xh[k] = (vv[k] - in.mu) * in.r;
+    txh[k] = in.r * (tt[k] - in.tmu - xh[k] * in.a);
+  }
+}
+__global__ __launch_bounds__(256) void gn_jvp_bwd_sums_kernel(const float* __restrict__ dout, const float* __restrict__ tdout,
+                                                              const float* __restrict__ out_mask, const float* __restrict__ y,
+                                                              const float* __restrict__ ty, const float* __restrict__ stats,
+                                                              const float* __restrict__ tstats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ tgamma, double* __restrict__ part,
+                                                              float* __restrict__ tdgb, int HW, int C, int rows, int relu) {
   __shared__ double s_red[4 * 4];
   __shared__ float s_ch[256][8];
-  const int g = blockIdx.x, n = blockIdx.y, Cg = C / G, cq = Cg >> 2;
-  const float mu = stats[((size_t)n * G + g) * 2], r = stats[((size_t)n * G + g) * 2 + 1];
-  const float tmu = tstats[((size_t)n * G + g) * 2], a = tstats[((size_t)n * G + g) * 2 + 1];
-  const float tr = -r * r * a;
+  const int ch = blockIdx.x, g = blockIdx.y, n = blockIdx.z, Cg = C / G, cq = Cg >> 2;
+  const int slab = n * G + g;
+  const GnJvpBwdIn in{dout, tdout, out_mask, y, ty, stats[(size_t)slab * 2], stats[(size_t)slab * 2 + 1], tstats[(size_t)slab * 2],
+                      tstats[(size_t)slab * 2 + 1], relu};
   const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
-  const int total = HW * cq;
-  const int q = threadIdx.x % cq;                     // this thread's channel quad (cq divides 256)
+  const int q = threadIdx.x % cq;                     // this thread's channel quad (cq divides 256, chunks start on a row)
   const int c = g * Cg + q * 4;
   const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c), tg4 = *reinterpret_cast<const float4*>(tgamma + c);
   const float gg[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, tgg[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
-  auto fetch = [&](size_t off, float (&d)[4], float (&td)[4], float (&xh)[4], float (&txh)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(y + off), t = *reinterpret_cast<const float4*>(ty + off);
-    const float4 d4 = *reinterpret_cast<const float4*>(dout + off), t4 = *reinterpret_cast<const float4*>(tdout + off);
-    const float vv[4] = {v.x, v.y, v.z, v.w}, tt[4] = {t.x, t.y, t.z, t.w};
-    d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
-    td[0] = t4.x; td[1] = t4.y; td[2] = t4.z; td[3] = t4.w;
-    if (relu) {
-      const float4 m = *reinterpret_cast<const float4*>(out_mask + off);
-      const float mm[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (!(mm[k] > 0.f)) { d[k] = 0.f; td[k] = 0.f; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      xh[k] = (vv[k] - mu) * r;
-      txh[k] = r * (tt[k] - tmu - xh[k] * a);
-    }
-  };
+  const int r0 = ch * rows, r1 = (r0 + rows < HW) ? r0 + rows : HW;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   float chb[4] = {0.f, 0.f, 0.f, 0.f}, chg[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = r0 * cq + threadIdx.x; i < r1 * cq; i += 256) {
     const size_t off = base + (size_t)(i / cq) * C + (size_t)q * 4;
     float d[4], td[4], xh[4], txh[4];
-    fetch(off, d, td, xh, txh);
+    gn_jvp_bwd_fetch(in, off, d, td, xh, txh);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float dxh = gg[k] * d[k], tdxh = tgg[k] * d[k] + gg[k] * td[k];
@@ -155,26 +218,51 @@ __global__ __launch_bounds__(256) void gn_jvp_bwd_kernel(const float* __restrict
     }
   }
   block_sum<4>(acc, s_red);
-  const double cnt = (double)HW * (double)Cg;
-  const float c1 = (float)(acc[0] / cnt), c2 = (float)(acc[1] / cnt), tc1 = (float)(acc[2] / cnt), tc2 = (float)(acc[3] / cnt);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[((size_t)slab * gridDim.x + ch) * 4 + k] = acc[k];
+  }
   // per-channel sums: threads with the same channel quad sit 'cq' apart
 #pragma unroll
   for (int k = 0; k < 4; ++k) { s_ch[threadIdx.x][k] = chb[k]; s_ch[threadIdx.x][4 + k] = chg[k]; }
   __syncthreads();
-  if ((int)threadIdx.x < cq && tdgb) {
+  if ((int)threadIdx.x < cq) {
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = threadIdx.x; j < 256; j += cq)
 #pragma unroll
       for (int k = 0; k < 4; ++k) { sb[k] += s_ch[j][k]; sg[k] += s_ch[j][4 + k]; }
-    float* ob = tdgb + ((size_t)n * 2 + 0) * C + c;
-    float* og = tdgb + ((size_t)n * 2 + 1) * C + c;
+    float* ob = tdgb + (((size_t)n * gridDim.x + ch) * 2 + 0) * C + c;
+    float* og = tdgb + (((size_t)n * gridDim.x + ch) * 2 + 1) * C + c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ob[k] = sb[k]; og[k] = sg[k]; }
   }
-  for (int i = threadIdx.x; i < total; i += 256) {
+}
+__global__ __launch_bounds__(256) void gn_jvp_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ tdout,
+                                                               const float* __restrict__ out_mask, const float* __restrict__ y,
+                                                               const float* __restrict__ ty, const float* __restrict__ stats,
+                                                               const float* __restrict__ tstats, const float* __restrict__ gamma,
+                                                               const float* __restrict__ tgamma, const double* __restrict__ part,
+                                                               float* __restrict__ dm, float* __restrict__ tdm, float* __restrict__ dy,
+                                                               float* __restrict__ tdy, int HW, int C, int rows, int relu) {
+  const int ch = blockIdx.x, g = blockIdx.y, n = blockIdx.z, Cg = C / G, cq = Cg >> 2;
+  const int slab = n * G + g;
+  const GnJvpBwdIn in{dout, tdout, out_mask, y, ty, stats[(size_t)slab * 2], stats[(size_t)slab * 2 + 1], tstats[(size_t)slab * 2],
+                      tstats[(size_t)slab * 2 + 1], relu};
+  const float r = in.r, tr = -r * r * in.a;
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg;
+  const int q = threadIdx.x % cq;
+  const int c = g * Cg + q * 4;
+  const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c), tg4 = *reinterpret_cast<const float4*>(tgamma + c);
+  const float gg[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, tgg[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+  double acc[4];
+  chunk_total<4>(part, slab, gridDim.x, acc);
+  const double cnt = (double)HW * (double)Cg;
+  const float c1 = (float)(acc[0] / cnt), c2 = (float)(acc[1] / cnt), tc1 = (float)(acc[2] / cnt), tc2 = (float)(acc[3] / cnt);
+  const int r0 = ch * rows, r1 = (r0 + rows < HW) ? r0 + rows : HW;
+  for (int i = r0 * cq + threadIdx.x; i < r1 * cq; i += 256) {
     const size_t off = base + (size_t)(i / cq) * C + (size_t)q * 4;
     float d[4], td[4], xh[4], txh[4];
-    fetch(off, d, td, xh, txh);
+    gn_jvp_bwd_fetch(in, off, d, td, xh, txh);
     float o[4], to[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -227,30 +315,44 @@ __global__ __launch_bounds__(256) void maxpool_jvp_fwd_kernel(const float* __res
   }
 }
 
-extern "C" int dyb_gn_jvp_fwd(const float* y, const float* ty, const float* stats, const float* gamma, const float* beta,
+// ty2 (may be NULL): second half of the tangent, added into ty by the sums launch; scratch: dyb_gn_jvp_scratch_floats floats
+extern "C" int dyb_gn_jvp_fwd(const float* y, float* ty, const float* ty2, const float* stats, const float* gamma, const float* beta,
                               const float* tgamma, const float* tbeta, const float* res, const float* tres, float* out, float* tout,
-                              float* tstats, int N, int HW, int C, int relu, hipStream_t st) {
-  DYB_REQUIRE(y && ty && stats && gamma && beta && tgamma && tbeta && tout, DYB_ERR_ARG);
+                              float* tstats, float* scratch, int N, int HW, int C, int relu, hipStream_t st) {
+  DYB_REQUIRE(y && ty && stats && gamma && beta && tgamma && tbeta && tout && scratch, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && 256 % (C / G / 4) == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
-  hipLaunchKernelGGL(gn_jvp_fwd_kernel, dim3(G, N), dim3(256), 0, st, y, ty, stats, gamma, beta, tgamma, tbeta, res, tres, out, tout,
-                     tstats, HW, C, relu);
+  const GnJvpGeom ge = gn_jvp_geom(N, HW, C);
+  double* part = reinterpret_cast<double*>(scratch);
+  const dim3 grid(ge.chunks, G, N);
+  hipLaunchKernelGGL(gn_jvp_fwd_sums_kernel, grid, dim3(256), 0, st, y, ty, ty2, stats, part, HW, C, ge.rows);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_jvp_fwd_apply_kernel, grid, dim3(256), 0, st, y, (const float*)ty, stats, (const double*)part, gamma, beta,
+                     tgamma, tbeta, res, tres, out, tout, tstats, HW, C, ge.rows, relu);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
-// tdgb: scratch [N][2][C]; tdbeta / tdgamma [C] receive its sums over the batch
+// scratch: dyb_gn_jvp_scratch_floats floats; tdbeta / tdgamma [C] receive the channel sums over images and chunks
 extern "C" int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty,
                               const float* stats, const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm,
-                              float* dy, float* tdy, float* tdgb, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu,
+                              float* dy, float* tdy, float* scratch, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu,
                               hipStream_t st) {
-  DYB_REQUIRE(dout && tdout && y && ty && stats && tstats && gamma && tgamma && dy && tdy && tdgb && tdgamma && tdbeta, DYB_ERR_ARG);
+  DYB_REQUIRE(dout && tdout && y && ty && stats && tstats && gamma && tgamma && dy && tdy && scratch && tdgamma && tdbeta, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out_mask, DYB_ERR_ARG);
   DYB_REQUIRE(C % 16 == 0 && 256 % (C / G / 4) == 0 && N > 0 && HW > 0, DYB_ERR_UNSUPPORTED);
   DYB_REQUIRE(dyb_rep_current().n == 1, DYB_ERR_UNSUPPORTED);
-  hipLaunchKernelGGL(gn_jvp_bwd_kernel, dim3(G, N), dim3(256), 0, st, dout, tdout, out_mask, y, ty, stats, tstats, gamma, tgamma, dm,
-                     tdm, dy, tdy, tdgb, HW, C, relu);
+  const GnJvpGeom ge = gn_jvp_geom(N, HW, C);
+  double* part = reinterpret_cast<double*>(scratch);
+  float* tdgb = scratch + (size_t)N * G * ge.chunks * 4 * 2;
+  const dim3 grid(ge.chunks, G, N);
+  hipLaunchKernelGGL(gn_jvp_bwd_sums_kernel, grid, dim3(256), 0, st, dout, tdout, out_mask, y, ty, stats, tstats, gamma, tgamma, part,
+                     tdgb, HW, C, ge.rows, relu);
   DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_jvp_colsum_kernel, dim3(dyb_cdiv(C, 256)), dim3(256), 0, st, (const float*)tdgb, tdbeta, tdgamma, N, C);
+  hipLaunchKernelGGL(gn_jvp_bwd_apply_kernel, grid, dim3(256), 0, st, dout, tdout, out_mask, y, ty, stats, tstats, gamma, tgamma,
+                     (const double*)part, dm, tdm, dy, tdy, HW, C, ge.rows, relu);
+  DYB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_jvp_colsum_kernel, dim3(dyb_cdiv(C, 256)), dim3(256), 0, st, (const float*)tdgb, tdbeta, tdgamma, N * ge.chunks,
+                     C);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib, constants as C
 from ._abi import check
-from .hmr import STATE_LD, get_layout, get_workspace, stream_of
+from .hmr import STATE_LD, aux_stream_of, get_layout, get_workspace, stream_of
 
 HEAD_FD_REL = 2e-3          # |e * tstate| / |state| of the head's central difference
 
@@ -73,18 +73,23 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
     init_state = hmr.make_init_state(B).contiguous().float()
     if hmr.training:
         raise NotImplementedError("exact Hessian-vector products are the eval-mode path")
+    from .fused_level import last_forward_acts
+    # the level was just evaluated at these weights: its activations are the primal pass (nothing writes to them afterwards)
+    level_acts = last_forward_acts(theta, image, init_state, n_iter)
 
     def hvp(v):
         v = v.detach().contiguous().float()
         dev = theta.device
         st = stream_of(theta)
         ws = get_workspace(L, dev)
-        acts = torch.empty(L.act_floats, dtype=torch.float32, device=dev)
-        check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter, acts.data_ptr(),
-                                  ws.data_ptr(), L.ws_bytes, st), "dyb_hmr_forward")
+        acts = level_acts
+        if acts is None:
+            acts = torch.empty(L.act_floats, dtype=torch.float32, device=dev)
+            check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), image.data_ptr(), init_state.data_ptr(), n_iter, acts.data_ptr(),
+                                      ws.data_ptr(), L.ws_bytes, st), "dyb_hmr_forward")
         dual = torch.empty(int(lib.dyb_hmr_hvp_dual_floats(L.plan)), dtype=torch.float32, device=dev)
         check(lib.dyb_hmr_jvp_forward(L.plan, theta.data_ptr(), v.data_ptr(), acts.data_ptr(), dual.data_ptr(), n_iter, ws.data_ptr(),
-                                      L.ws_bytes, st), "dyb_hmr_jvp_forward")
+                                      L.ws_bytes, st, aux_stream_of(theta)), "dyb_hmr_jvp_forward")
         state = acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD)
         off = int(lib.dyb_hmr_hvp_offset_tstate(L.plan))
         tstate = dual[off:off + B * STATE_LD].view(B, STATE_LD)
@@ -98,7 +103,8 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
         td = ((gp - gm) / (2 * eps)).contiguous()
         hv = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
         check(lib.dyb_hmr_jvp_backward(L.plan, theta.data_ptr(), v.data_ptr(), acts.data_ptr(), dual.data_ptr(), g0.data_ptr(),
-                                       td.data_ptr(), n_iter, hv.data_ptr(), ws.data_ptr(), L.ws_bytes, st), "dyb_hmr_jvp_backward")
+                                       td.data_ptr(), n_iter, hv.data_ptr(), ws.data_ptr(), L.ws_bytes, st, aux_stream_of(theta)),
+              "dyb_hmr_jvp_backward")
         return hv
     return hvp
 
@@ -138,7 +144,7 @@ class _Pass:
         L, lib = self.L, self.lib
         self.dual = torch.empty(int(lib.dyb_hmr_hvp_dual_floats(L.plan)), dtype=torch.float32, device=theta.device)
         check(lib.dyb_hmr_jvp_forward(L.plan, theta.data_ptr(), v.data_ptr(), self.acts.data_ptr(), self.dual.data_ptr(), self.n_iter,
-                                      self.ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_jvp_forward")
+                                      self.ws.data_ptr(), L.ws_bytes, stream_of(theta), aux_stream_of(theta)), "dyb_hmr_jvp_forward")
         off = int(lib.dyb_hmr_hvp_offset_tstate(L.plan))
         return self.dual[off:off + self.B * STATE_LD].view(self.B, STATE_LD).clone()
 
@@ -147,8 +153,8 @@ class _Pass:
         out = torch.zeros(L.n_params, dtype=torch.float32, device=theta.device)
         g, tg = g.contiguous().float(), tg.contiguous().float()
         check(lib.dyb_hmr_jvp_backward(L.plan, theta.data_ptr(), v.data_ptr(), self.acts.data_ptr(), self.dual.data_ptr(), g.data_ptr(),
-                                       tg.data_ptr(), self.n_iter, out.data_ptr(), self.ws.data_ptr(), L.ws_bytes, stream_of(theta)),
-              "dyb_hmr_jvp_backward")
+                                       tg.data_ptr(), self.n_iter, out.data_ptr(), self.ws.data_ptr(), L.ws_bytes, stream_of(theta),
+                                       aux_stream_of(theta)), "dyb_hmr_jvp_backward")
         return out
 
 

@@ -118,27 +118,32 @@ int dyb_conv_probe_set(void* buf, long cap_wgs, int mode, int H, int C, int K, i
 /* ---- second-order building blocks (exact Hessian-vector products, hvp_kernels.hip / hvp_engine.inc) ----
  * Tangent ("t" prefix = directional derivative along a parameter direction) of GroupNorm(4, C)(+ReLU)(+residual) and of its
  * backward; NHWC [N][HW][C]; stats = the forward's [N][4][2] (mean, rstd); tstats [N][4][2] receives / supplies the tangent
- * statistics.  out may be NULL.  dyb_gn_jvp_bwd: dout / tdout = gradient w.r.t. the layer's output and its tangent, out_mask =
+ * statistics.  out may be NULL.  ty2 (may be NULL): a second half of the tangent, added into ty first (the two halves of a
+ * convolution's tangent).  dyb_gn_jvp_bwd: dout / tdout = gradient w.r.t. the layer's output and its tangent, out_mask =
  * the primal output (ReLU mask, relu = 1); writes the masked gradients (dm, tdm; may be NULL), the gradient w.r.t. y and its
- * tangent (dy, tdy) and the tangents of dgamma / dbeta ([C]); tdgb = scratch [N][2][C].  Not replica-aware. */
-int dyb_gn_jvp_fwd(const float* y, const float* ty, const float* stats, const float* gamma, const float* beta, const float* tgamma,
-                   const float* tbeta, const float* res, const float* tres, float* out, float* tout, float* tstats, int N, int HW,
-                   int C, int relu, dyb_stream_t stream);
+ * tangent (dy, tdy) and the tangents of dgamma / dbeta ([C]).  scratch: dyb_gn_jvp_scratch_floats(N, HW, C) floats, 8-byte aligned
+ * (each (image, group) slab is cut into row chunks, one workgroup each; partial sums meet there).  Not replica-aware. */
+size_t dyb_gn_jvp_scratch_floats(int N, int HW, int C);
+int dyb_gn_jvp_fwd(const float* y, float* ty, const float* ty2, const float* stats, const float* gamma, const float* beta,
+                   const float* tgamma, const float* tbeta, const float* res, const float* tres, float* out, float* tout, float* tstats,
+                   float* scratch, int N, int HW, int C, int relu, dyb_stream_t stream);
 int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty, const float* stats,
                    const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm, float* dy, float* tdy,
-                   float* tdgb, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu, dyb_stream_t stream);
+                   float* scratch, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu, dyb_stream_t stream);
 /* Exact Hessian-vector product through HMR, forward-over-reverse (hvp_engine.inc).  acts = the arena dyb_hmr_forward filled at
  * (params, image); tparams = the direction v (parameter arena layout); dual = scratch of dyb_hmr_hvp_dual_floats floats shared by
  * the two passes.  _jvp_forward leaves the tangent of the regressor's final state [B][160] at dual + dyb_hmr_hvp_offset_tstate;
  * the caller differentiates the head (rot6d -> SMPL -> losses) along it; _jvp_backward takes the head's gradient w.r.t. that state
  * (d_state, rot6d folded in) and its tangent (td_state) and writes hv = H v in the parameter arena layout (tensor spans only: zero
- * hv first).  Eval mode, fp32, one sequence per call. */
+ * hv first).  Eval mode, fp32, one sequence per call.  aux (may be NULL): a side stream; the halves of every tangent pair that
+ * are off the dependency chain (conv(x, tw), the weight-gradient pairs, dgrad(dy, tw)) are issued there, ordered by events, and
+ * everything has joined `stream` again when a call returns. */
 size_t dyb_hmr_hvp_dual_floats(const void* plan);
 long long dyb_hmr_hvp_offset_tstate(const void* plan);
 int dyb_hmr_jvp_forward(void* plan, const float* params, const float* tparams, const float* acts, float* dual, int n_iter, void* ws,
-                        size_t ws_bytes, dyb_stream_t stream);
+                        size_t ws_bytes, dyb_stream_t stream, dyb_stream_t aux);
 int dyb_hmr_jvp_backward(void* plan, const float* params, const float* tparams, const float* acts, float* dual, const float* d_state,
-                         const float* td_state, int n_iter, float* hv, void* ws, size_t ws_bytes, dyb_stream_t stream);
+                         const float* td_state, int n_iter, float* hv, void* ws, size_t ws_bytes, dyb_stream_t stream, dyb_stream_t aux);
 /* tangent of MaxPool2d(3,2,1): ty = tx gathered at the tap indices dyb_maxpool3x3s2_fwd stored */
 int dyb_maxpool3x3s2_jvp(const float* tx, const uint32_t* idx, float* ty, int N, int H, int W, int C, dyb_stream_t stream);
 

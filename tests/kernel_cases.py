@@ -972,7 +972,7 @@ def case_aux_terms(be, B=3, seed=91):
 
 
 # ---------------------------------------------------------------------------------------- tangent (JVP) kernels
-def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
+def case_gn_jvp(be, N, HW, C, relu, with_res, split_ty=False, seed=31):
     """dyb_gn_jvp_fwd / dyb_gn_jvp_bwd against torch (float64): forward tangent of relu?(GN(y) + res) along (ty, tgamma, tbeta,
     tres), and the tangent of its backward (dy, dgamma, dbeta, dres) along the same direction plus tdout."""
     rng = _rng(seed)
@@ -1013,12 +1013,17 @@ def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
     GA, BE_, TG, TB = be.dev(gamma), be.dev(beta), be.dev(tgamma), be.dev(tbeta)
     RES, TRES = (be.dev(res), be.dev(tres)) if with_res else (None, None)
     OUT, TOUT, TST = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, 4, 2))
-    check(be.lib.dyb_gn_jvp_fwd(be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(TG), be.ptr(TB),
-                                be.ptr(RES) if with_res else None, be.ptr(TRES) if with_res else None, be.ptr(OUT), be.ptr(TOUT),
-                                be.ptr(TST), N, HW, C, relu, be.stream), "gn jvp fwd")
+    SCR = be.empty((int(be.lib.dyb_gn_jvp_scratch_floats(N, HW, C)),))
+    TY2 = None
+    if split_ty:            # the tangent arrives as two halves (a convolution's conv(tx, w) + conv(x, tw)); the sums launch adds them
+        h = f32(N, HW, C)
+        TY, TY2 = be.dev(ty - h), be.dev(h)
+    check(be.lib.dyb_gn_jvp_fwd(be.ptr(Y), be.ptr(TY), be.ptr(TY2) if split_ty else None, be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(TG),
+                                be.ptr(TB), be.ptr(RES) if with_res else None, be.ptr(TRES) if with_res else None, be.ptr(OUT),
+                                be.ptr(TOUT), be.ptr(TST), be.ptr(SCR), N, HW, C, relu, be.stream), "gn jvp fwd")
     e = dict(out=rel_err(be.host(OUT), out_ref.numpy()), tout=rel_err(be.host(TOUT), tout_ref.numpy()))
     DM, TDM, DY, TDY = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C))
-    SCR, TDG, TDB = be.empty((N, 2, C)), be.empty((C,)), be.empty((C,))
+    TDG, TDB = be.empty((C,)), be.empty((C,))
     check(be.lib.dyb_gn_jvp_bwd(be.ptr(be.dev(dout)), be.ptr(be.dev(tdout)), be.ptr(OUT), be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(TST),
                                 be.ptr(GA), be.ptr(TG), be.ptr(DM), be.ptr(TDM), be.ptr(DY), be.ptr(TDY), be.ptr(SCR), be.ptr(TDG),
                                 be.ptr(TDB), N, HW, C, relu, be.stream), "gn jvp bwd")
@@ -1030,7 +1035,7 @@ def case_gn_jvp(be, N, HW, C, relu, with_res, seed=31):
     return e
 
 
-def case_hmr_hvp(be, ckpt, seed=5, B=1):
+def case_hmr_hvp(be, ckpt, seed=5, B=1, side=True):
     """dyb_hmr_jvp_forward / dyb_hmr_jvp_backward (exact Hessian-vector product through HMR) against the oracle differentiated
     twice by torch (CPU, float32): scalar s(theta) = <c, state(theta)>, direction v; checks the tangent of the state and
     H v = grad_theta(<grad_theta s, v>) per tensor."""
@@ -1077,8 +1082,11 @@ def case_hmr_hvp(be, ckpt, seed=5, B=1):
           "hmr forward")
     nd = int(be.lib.dyb_hmr_hvp_dual_floats(L.plan))
     dual = be.empty((nd,))
+    # side stream: a real one on the GPU; on the emulator (streams are ignored, launches run in issue order) any non-null handle
+    # takes the engine through its side-stream schedule
+    aux = (be.aux_stream() or 1) if side else None
     check(be.lib.dyb_hmr_jvp_forward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), 3, be.ptr(ws), L.ws_bytes,
-                                     be.stream), "jvp forward")
+                                     be.stream, aux), "jvp forward")
     off = int(be.lib.dyb_hmr_hvp_offset_tstate(L.plan))
     tstate = be.host(dual)[off:off + B * 160].reshape(B, 160)[:, :157]
     e = dict(tstate=rel_err(tstate, tstate_ref))
@@ -1088,7 +1096,7 @@ def case_hmr_hvp(be, ckpt, seed=5, B=1):
     hv = be.zeros((L.n_params,))
     DS, TDS = be.dev(d_state), be.zeros((B, 160))          # named: the buffers must outlive the call
     check(be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(DS), be.ptr(TDS), 3,
-                                      be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream), "jvp backward")
+                                      be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream, aux), "jvp backward")
     H = L.unpack(torch.from_numpy(be.host(hv)))
     worst = {}
     for k in names:

@@ -517,6 +517,53 @@ def test_second_order_inner3_exact_hvp_matches_reference_second_order():
     assert min(sl.values()) > 0.9999, sl
 
 
+@pytest.mark.parametrize("hvp_terms", ["all", "frame"])
+def test_second_order_full_loss_set_matches_reference_second_order(hvp_terms):
+    """Second order on the reference's DEFAULT term set (labelled exemplars in the lower level; teacher + motion + exemplars in the
+    upper; motion from frame 3 on) against the reference itself run with learn2learn first_order=False (golden g5_so_inner1_full,
+    4 frames): upper losses, predictions, the first frame's outer gradient per tensor, final Adam state.  hvp_terms=all: exact
+    Hessian-vector products for every level (the multi-pass form, dynaboa_amd/hvp.py general_level_hvp); hvp_terms=frame: levels
+    with teacher / motion / labelled terms take the difference quotient (looser gradient bounds).  The first-order golden of the
+    same stream (g5_fo_inner1_full) shows which gradient is being followed."""
+    from dynaboa_amd import assets
+    gso, gfo = golden("g5_so_inner1_full.npz"), golden("g5_fo_inner1_full.npz")
+    opts = dict(inner_step=1, interval=2, optim_steps=2, second_order=1, hvp="exact", hvp_terms=hvp_terms)
+    ad, _ = make_adaptor(opts, False)
+    n = int(gso["nframes"])
+    ad.reset_records(n)
+    hmr = ad.model.module
+    theta0 = hmr.theta.detach().clone()
+    names = [str(x) for x in gso["names"]]
+    for step in range(n):
+        ad.global_step = step
+        ad.fit_losses = {}
+        batch = {k: v.to(ad.device) for k, v in assets.make_frame(step, 1, seed=22).items()}
+        ad.model.eval()
+        ad.adaptation(batch)
+        up = float(ad.fit_losses["ul/total"])
+        assert abs(up - gso["upper_loss"][step]) < 1e-4 * abs(gso["upper_loss"][step]), (step, up, gso["upper_loss"][step])
+        assert ad.optim_step_record[-1] == int(gso["extra_steps"][step])
+        with torch.no_grad():
+            r, s, c = ad.model(batch["image"])
+        for k, v in dict(rotmat=r, shape=s, cam=c).items():
+            assert rel_err(v.cpu().numpy(), gso[f"pred{step}_{k}"]) < 1e-3, (step, k)
+        if step == 0:
+            st = ad.optimizer.state[hmr.theta]
+            g1 = hmr._layout1.unpack((st["exp_avg"] / (1 - ad.options.beta1)).cpu())
+            gn = np.array([float(g1[k].double().norm()) for k in names])
+            err = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
+            gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
+            sl = {k[3:]: cosine(g1[k[3:]].flatten()[:256].numpy(), gso[k]) for k in gso.files if k.startswith("g1_") and k != "g1_norms"}
+            print("SO full set, hvp_terms=%s: grad-norm error median %.2e max %.2e (FO-SO gap median %.2e), min slice cosine %.6f" % (
+                hvp_terms, np.median(err), err.max(), np.median(gap), min(sl.values())))
+            if hvp_terms == "all":
+                assert np.median(err) < 5e-4 and err.max() < 5e-3, (np.median(err), err.max())
+                assert min(sl.values()) > 0.999, sl
+            else:
+                assert np.median(err) < 0.1 * np.median(gap) and err.max() < 6e-2, (np.median(err), err.max(), np.median(gap))
+    assert_final_state_matches_golden(ad, gso, theta0, opts)
+
+
 @pytest.mark.parametrize("overlap", [0, 1])
 def test_native_stepper_is_bit_identical_to_autograd_path(overlap):
     """One C call per frame (csrc/adapt_step.hip, the default for the frame-loss configurations) against the

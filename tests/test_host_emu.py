@@ -343,6 +343,47 @@ def test_second_order_exact_hvp_first_frame_vs_reference_second_order(emu_lib):
     assert all(b > 0.9999 for _, b in sl.values()), sl
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~10 min under the emulator; set DYB_EMU_FULL=1")
+def test_second_order_full_loss_set_exact_hvp_vs_reference_second_order(emu_lib):
+    """--second_order 1 --hvp exact --hvp_terms all on the reference's default term set, first two frames on the emulator, against
+    the reference run with learn2learn first_order=False (golden g5_so_inner1_full; the GPU test runs all four frames)."""
+    from dynaboa_amd import assets
+    from dynaboa_amd import benchmark as DB
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    from conftest import cosine
+    gso, gfo = golden("g5_so_inner1_full.npz"), golden("g5_fo_inner1_full.npz")
+    o = DB.parser.parse_args([])
+    for k, v in dict(inner_step=1, interval=2, optim_steps=2, second_order=1, hvp="exact", hvp_terms="all").items():
+        setattr(o, k, v)
+    ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=False, randomize_norm=True, smpl_seed=0), device="cpu")
+    ad.reset_records(2)
+    hmr = ad.model.module
+    names = [str(x) for x in gso["names"]]
+    for step in range(2):
+        ad.global_step = step
+        ad.fit_losses = {}
+        batch = assets.make_frame(step, 1, seed=22)
+        ad.model.eval()
+        ad.adaptation(batch)
+        up = float(ad.fit_losses["ul/total"])
+        assert abs(up - gso["upper_loss"][step]) < 1e-4 * abs(gso["upper_loss"][step]), (step, up, gso["upper_loss"][step])
+        with torch.no_grad():
+            r, s, c = ad.model(batch["image"])
+        for k, v in dict(rotmat=r, shape=s, cam=c).items():
+            assert rel_err(v.numpy(), gso[f"pred{step}_{k}"]) < 1e-3, (step, k)
+        if step == 0:
+            st = ad.optimizer.state[hmr.theta]
+            g1 = hmr._layout1.unpack(st["exp_avg"] / (1 - ad.options.beta1))
+            gn = np.array([float(g1[k].double().norm()) for k in names])
+            err = np.abs(gn - gso["g1_norms"]) / gso["g1_norms"]
+            gap = np.abs(gfo["g1_norms"] - gso["g1_norms"]) / gso["g1_norms"]
+            sl = {k[3:]: cosine(g1[k[3:]].flatten()[:256].numpy(), gso[k]) for k in gso.files if k.startswith("g1_") and k != "g1_norms"}
+            print("SO full set exact: grad-norm error median %.2e max %.2e (FO-SO gap median %.2e max %.2e), min slice cosine %.6f" % (
+                np.median(err), err.max(), np.median(gap), gap.max(), min(sl.values())))
+            assert np.median(err) < 5e-4 and err.max() < 5e-3, (np.median(err), err.max())
+            assert min(sl.values()) > 0.999, sl
+
+
 def test_exact_hvp_selection_rules(emu_lib):
     """--hvp exact serves levels made of the frame losses; levels with teacher / motion / labelled terms (and --hvp fd) get no
     factory, i.e. MAML.adapt differences the closure's gradient."""

@@ -307,7 +307,8 @@ def test_aux_loss_terms(be):
     K.case_aux_terms(be, B=1, seed=5)
 
 
-@pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True), (2, 30, 128, 1, False), (1, 12, 2048, 0, False), (3, 20, 256, 0, True)])
+@pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True), (2, 30, 128, 1, False), (1, 12, 2048, 0, False), (3, 20, 256, 0, True),
+                                 (1, 3136, 64, 1, True, True), (2, 200, 512, 1, False, True)])      # 13 / 7 row chunks per slab, ragged tails
 def test_groupnorm_tangent_kernels(be, cfg):
     """Forward tangent of GroupNorm(+ReLU)(+residual) and the tangent of its backward (the building blocks of the exact
     Hessian-vector product) against torch's forward-over-reverse in float64."""

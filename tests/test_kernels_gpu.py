@@ -286,14 +286,16 @@ def test_aux_loss_terms(be):
     K.case_aux_terms(be, B=16, seed=3)
 
 
-@pytest.mark.parametrize("cfg", [(1, 3136, 64, 1, False), (1, 784, 512, 1, True), (2, 196, 1024, 0, False), (1, 49, 2048, 1, True)])
+@pytest.mark.parametrize("cfg", [(1, 3136, 64, 1, False), (1, 784, 512, 1, True, True), (2, 196, 1024, 0, False), (1, 49, 2048, 1, True),
+                                 (1, 12544, 64, 1, False, True), (16, 196, 1024, 1, True)])
 def test_groupnorm_tangent_kernels(be, cfg):
     """Forward tangent of GroupNorm(+ReLU)(+residual) and the tangent of its backward (exact Hessian-vector product building
     blocks) against torch's forward-over-reverse in float64, at ResNet-50 layer sizes."""
     K.case_gn_jvp(be, *cfg)
 
 
-def test_hmr_exact_hessian_vector_product(be, ckpt_rand):
+@pytest.mark.parametrize("side", [True, False])
+def test_hmr_exact_hessian_vector_product(be, ckpt_rand, side):
     """dyb_hmr_jvp_forward / _backward: tangent of the regressor state and every tensor of H v against torch differentiating
-    the oracle twice (CPU)."""
-    print(K.case_hmr_hvp(be, ckpt_rand))
+    the oracle twice (CPU); with the side stream (the pairs' off-chain halves beside the chain) and with everything in line."""
+    print(K.case_hmr_hvp(be, ckpt_rand, side=side))

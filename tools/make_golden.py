@@ -386,6 +386,13 @@ def g5so3(out):
     run_stream("so_inner3_frameonly", out, dict(frame_only, inner_step=3), 2, first_order=False)
 
 
+def g5so_full(out):
+    """Second order (learn2learn first_order=False) with the reference's DEFAULT term set - labelled exemplars in the lower level,
+    teacher + motion + exemplars in the upper (motion from frame 3 on at interval 2); its first-order twin is g5_fo_inner1_full
+    (same stream, same seeds).  Pins --hvp exact --hvp_terms all (the multi-pass exact Hessian-vector products)."""
+    run_stream("so_inner1_full", out, dict(inner_step=1, interval=2, optim_steps=2), 4, first_order=False)
+
+
 def g5fo3(out):
     """The first-order twin of g5so3 alone (same call as in g5; regenerates g5_fo_inner3_frameonly incl. its g1_* keys)."""
     frame_only = dict(retrieval=0, lower_level_mixtrain=0, upper_level_mixtrain=0, use_meanteacher=0,
