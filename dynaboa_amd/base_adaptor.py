@@ -28,7 +28,8 @@ from . import assets as A
 from . import constants
 from .hmr import hmr
 from .fused_level import level_forward
-from .losses import MaxMixturePrior, frame_losses, pose_prior, projection_normed
+from .losses import (AUX_MAX_BATCH, MaxMixturePrior, frame_losses, labelled_term, motion_term, pose_prior, projection_normed,
+                     teacher_term)
 from .maml import MAML
 from .optim import Adam, ema_update
 from .smpl import SMPL
@@ -256,20 +257,44 @@ class BaseAdaptor:
         self.fit_losses[f"{prefix}/motion_loss"] = loss
         return loss
 
-    def adapt_on_labeled_data(self, model, batch, prefix="ll"):
+    def _teacher_term(self, image, rot, shape, cam, s3d):
+        """cal_teacher_loss on the term kernel (same logging keys)."""
+        with torch.no_grad():
+            t_rot, t_shape, t_cam = self.teacher(image)
+            t_s3d = self.decode_smpl_params(t_rot, t_shape)["s3d"]
+        loss, comps = teacher_term(rot, shape, cam, s3d, t_rot, t_shape, t_cam, t_s3d)
+        for i, k in enumerate(("s2dloss", "s3dloss", "shape_loss", "pose_loss")):
+            self.fit_losses[f"teacher/{k}"] = comps[i]
+        self.fit_losses["teacher/loss"] = loss
+        return loss
+
+    def _motion_term(self, model, rot, shape, cam, s3d, gt_keypoints_2d, prefix="ul"):
+        """cal_motion_loss on the term kernel: the history frame through the same weights, both passes differentiable."""
+        hist_image, hist_s2d = self.get_hist()
+        h_rot, h_shape, h_cam = model(hist_image)
+        h_s3d = self.decode_smpl_params(h_rot, h_shape)["s3d"]
+        loss, _ = motion_term(rot, shape, cam, s3d, h_cam, h_s3d, gt_keypoints_2d, hist_s2d)
+        self.fit_losses[f"{prefix}/motion_loss"] = loss
+        return loss
+
+    def adapt_on_labeled_data(self, model, batch, prefix="ll", kernels=False):
         from .geometry import batch_rodrigues
         gt_s2d = batch["keypoints"]
         conf = gt_s2d[:, 25:, -1:].clone()
         rot, shape, cam, feats = model(batch["img"], need_feature=True)
         s3d = self.decode_smpl_params(rot, shape)["s3d"]
         gt_rot = batch_rodrigues(batch["pose"].view(-1, 3)).view(-1, 24, 3, 3)
-        s2d = self.projection(cam, s3d)["normed"]
-        terms = dict(labled_s2dloss=(((s2d[:, 25:] - gt_s2d[:, 25:, :-1]) ** 2) * conf).mean(),
-                     labled_s3dloss=self.cal_s3d_loss(s3d[:, 25:], batch["pose_3d"][:, :, :-1], conf),
-                     labled_shape_loss=F.mse_loss(shape, batch["betas"]), labled_pose_loss=F.mse_loss(rot, gt_rot))
         assert batch["pose_3d"].shape[1] == 24
-        loss = (terms["labled_s2dloss"] * 5 + terms["labled_s3dloss"] * 5 + terms["labled_shape_loss"] * 0.001
-                + terms["labled_pose_loss"] * 1)
+        if kernels:
+            loss, comps = labelled_term(rot, shape, cam, s3d, gt_s2d, gt_rot, batch["betas"], batch["pose_3d"])
+            terms = dict(labled_s2dloss=comps[0], labled_s3dloss=comps[1], labled_shape_loss=comps[2], labled_pose_loss=comps[3])
+        else:
+            s2d = self.projection(cam, s3d)["normed"]
+            terms = dict(labled_s2dloss=(((s2d[:, 25:] - gt_s2d[:, 25:, :-1]) ** 2) * conf).mean(),
+                         labled_s3dloss=self.cal_s3d_loss(s3d[:, 25:], batch["pose_3d"][:, :, :-1], conf),
+                         labled_shape_loss=F.mse_loss(shape, batch["betas"]), labled_pose_loss=F.mse_loss(rot, gt_rot))
+            loss = (terms["labled_s2dloss"] * 5 + terms["labled_s3dloss"] * 5 + terms["labled_shape_loss"] * 0.001
+                    + terms["labled_pose_loss"] * 1)
         for k, v in terms.items():
             self.fit_losses[f"{prefix}/{k}"] = v
         self.fit_losses[f"{prefix}/labled_loss"] = loss
@@ -308,18 +333,26 @@ class BaseAdaptor:
             log[f"{tag}/pose_prior"], log[f"{tag}/unlabelloss"] = comps[2], loss.detach()
         keep, self.fit_losses = self.fit_losses, log           # the term helpers below log into self.fit_losses
         try:
+            # teacher / motion / labelled terms: one value + gradient launch each (losses._AuxTerms) - the same kernel the native
+            # stepper issues; --term_kernels 0 (or a batch beyond its 16 samples) composes them from torch ops as the reference does
+            kern = bool(getattr(o, "term_kernels", 1)) and image.shape[0] <= AUX_MAX_BATCH
             if getattr(o, f"use_temporal_losses_{level}"):
-                s2d = self.projection(cam, s3d)["normed"]
+                if not kern:
+                    s2d = self.projection(cam, s3d)["normed"]
                 if o.use_meanteacher:
-                    t = self.cal_teacher_loss(image, rot, shape, s2d, s3d) * o.teacherloss_weight
+                    t = (self._teacher_term(image, rot, shape, cam, s3d) if kern else self.cal_teacher_loss(image, rot, shape, s2d, s3d))
+                    t = t * o.teacherloss_weight
                     loss = t if loss is None else loss + t
                 if o.use_motion and (self.global_step - o.interval) > 0:
-                    loss = loss + self.cal_motion_loss(learner, s2d[:, 25:], gt_keypoints_2d[:, 25:], prefix="ul") * o.motionloss_weight
+                    m = (self._motion_term(learner, rot, shape, cam, s3d, gt_keypoints_2d, prefix="ul") if kern else
+                         self.cal_motion_loss(learner, s2d[:, 25:], gt_keypoints_2d[:, 25:], prefix="ul"))
+                    loss = loss + m * o.motionloss_weight
             if o.retrieval:
                 h36m_batch = self._replay["h36m"] if quiet else self.retrieval(feats[5])
             self._last_h36m = h36m_batch
             if getattr(o, f"{level}_level_mixtrain"):
-                lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag)
+                lab, _ = self.adapt_on_labeled_data(learner, h36m_batch, prefix=tag,
+                                                    kernels=kern and h36m_batch["img"].shape[0] <= AUX_MAX_BATCH)
                 loss = loss + lab * o.labelloss_weight
         finally:
             self.fit_losses = keep

@@ -87,6 +87,9 @@ parser.add_argument('--share_forwards', type=int, default=1, choices=[0, 1],
 parser.add_argument('--fused_level', type=int, default=1, choices=[0, 1],
                     help='1: model -> SMPL -> frame-loss head of each adaptation level as one autograd node (same results); '
                          '0: the three-module composition')
+parser.add_argument('--term_kernels', type=int, default=1, choices=[0, 1],
+                    help='autograd path: 1 = the mean-teacher / motion / labelled-exemplar terms as one value+gradient launch each '
+                         '(dyb_aux_loss_terms, what the native stepper issues); 0 = composed from torch ops as the reference writes them')
 parser.add_argument('--deferred_metrics', type=int, default=0, choices=[0, 1])
 parser.add_argument('--overlap_metrics', type=int, default=0, choices=[0, 1, 2],
                     help='with --deferred_metrics 1: run the no-grad metric / feature forwards on a side HIP stream, '

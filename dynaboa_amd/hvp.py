@@ -126,17 +126,19 @@ def rot6d_to_rotmat(x6: torch.Tensor) -> torch.Tensor:
 class _Pass:
     """One network pass of a level (an image batch evaluated with the level's weights): primal activations, tangent arena."""
 
-    def __init__(self, lib, hmr, theta, image, n_iter):
+    def __init__(self, lib, hmr, theta, image, n_iter, acts=None):
         self.lib, self.n_iter = lib, n_iter
         self.image = image.contiguous().float()
         B, _, H, W = self.image.shape
         self.B, self.L = B, get_layout(B, H, W)
         L, dev = self.L, theta.device
         self.ws = get_workspace(L, dev)
-        self.acts = torch.empty(L.act_floats, dtype=torch.float32, device=dev)
         self.init_state = hmr.make_init_state(B).contiguous().float()
-        check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), self.image.data_ptr(), self.init_state.data_ptr(), n_iter, self.acts.data_ptr(),
-                                  self.ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
+        self.acts = acts                                 # the level's own forward of this image, when the caller still has it
+        if self.acts is None:
+            self.acts = torch.empty(L.act_floats, dtype=torch.float32, device=dev)
+            check(lib.dyb_hmr_forward(L.plan, theta.data_ptr(), self.image.data_ptr(), self.init_state.data_ptr(), n_iter,
+                                      self.acts.data_ptr(), self.ws.data_ptr(), L.ws_bytes, stream_of(theta)), "dyb_hmr_forward")
         self.state = self.acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD).clone()
         self.dual = None
 
@@ -186,6 +188,9 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
             t_s3d = ad.decode_smpl_params(t_rot, t_shape)["s3d"]
             teacher_t = (t_rot, t_shape, t_s3d, ad.projection(t_cam, t_s3d)["normed"])
     hist = ad.get_hist() if use_motion else None
+    from .fused_level import last_forward_acts
+    # the frame's forward at these weights was just evaluated by the level: its activations are the primal pass of "img"
+    img_acts = last_forward_acts(theta, image.contiguous().float(), hmr.make_init_state(image.shape[0]).contiguous().float(), n_iter)
 
     def preds(state):
         rot = rot6d_to_rotmat(state[:, :144])
@@ -235,7 +240,7 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
     def hvp(v):
         v = v.detach().contiguous().float()
         with torch.no_grad():
-            passes = {"img": _Pass(lib, hmr, theta, image, n_iter)}
+            passes = {"img": _Pass(lib, hmr, theta, image, n_iter, acts=img_acts)}
             if use_motion:
                 passes["hist"] = _Pass(lib, hmr, theta, hist[0], n_iter)
             if use_label:

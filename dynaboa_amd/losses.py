@@ -138,3 +138,64 @@ class _Projection(torch.autograd.Function):
 def projection_normed(cam, s3d):
     """[-1,1]-normalised weak-perspective projection, focal 5000, crop 224 (base_adaptor.py:160-170)."""
     return _Projection.apply(cam, s3d)
+
+
+class _AuxTerms(torch.autograd.Function):
+    """One of the three non-frame terms of a level (csrc/losses.hip dyb_aux_loss_terms: value + gradient in one launch) as an autograd
+    node.  Differentiable in the student pass's (rot, shape, cam, joints) and, for the motion term, in the history pass's
+    (cam2, joints2)."""
+
+    @staticmethod
+    def forward(ctx, mode, rot, shape, cam, joints, rot2, shape2, cam2, joints2, kp, kp2, gt_rot, gt_betas, gt_s3d):
+        lib = _lib.load()
+        B = rot.shape[0]
+        dev = rot.device
+        rows = lambda t: None if t is None else (t.float() if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous().float())
+        full = lambda t: None if t is None else t.contiguous().float()
+        ld = lambda t: 0 if t is None else t.stride(0)
+        p = lambda t: None if t is None else t.data_ptr()
+        rot, joints, rot2, joints2 = full(rot), full(joints), full(rot2), full(joints2)
+        shape, cam, shape2, cam2 = rows(shape), rows(cam), rows(shape2), rows(cam2)
+        kp, kp2, gt_rot, gt_betas, gt_s3d = full(kp), full(kp2), full(gt_rot), full(gt_betas), full(gt_s3d)
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        vals, d_rot, d_shape, d_cam, d_joints = f(5), f(B, 24, 3, 3), f(B, 10), f(B, 3), f(B, 49, 3)
+        d_cam2, d_joints2 = (f(B, 3), f(B, 49, 3)) if mode == 1 else (None, None)
+        check(lib.dyb_aux_loss_terms(mode, B, 0, 1.0, rot.data_ptr(), shape.data_ptr(), ld(shape), cam.data_ptr(), ld(cam), joints.data_ptr(),
+                                     p(rot2), p(shape2), ld(shape2), p(cam2), ld(cam2), p(joints2), p(kp), p(kp2), p(gt_rot), p(gt_betas),
+                                     p(gt_s3d), vals.data_ptr(), d_rot.data_ptr(), d_shape.data_ptr(), d_cam.data_ptr(),
+                                     d_joints.data_ptr(), p(d_cam2), p(d_joints2), stream_of(rot)), "dyb_aux_loss_terms")
+        ctx.mode = mode
+        ctx.save_for_backward(*(t for t in (d_rot, d_shape, d_cam, d_joints, d_cam2, d_joints2) if t is not None))
+        comps = vals[:4].clone()
+        ctx.mark_non_differentiable(comps)
+        return vals[4], comps
+
+    @staticmethod
+    def backward(ctx, g, _g_comps):
+        saved = ctx.saved_tensors
+        d_rot, d_shape, d_cam, d_joints = saved[:4]
+        out = [None, d_rot * g, d_shape * g, d_cam * g, d_joints * g, None, None, None, None]
+        if ctx.mode == 1:
+            out[7], out[8] = saved[4] * g, saved[5] * g
+        return tuple(out) + (None,) * 5
+
+
+AUX_MAX_BATCH = 16          # dyb_aux_loss_terms: one workgroup per sample set, B <= 16
+
+
+def teacher_term(rot, shape, cam, joints49, t_rot, t_shape, t_cam, t_joints49):
+    """Mean-teacher consistency (reference base_adaptor.py:320-343): 5 mse(s2d) + 5 mse(s3d) + 0.001 mse(shape) + mse(rotmat) against
+    the teacher's outputs, the normalised projections formed inside -> (loss, tensor(s2d, s3d, shape, pose) for logging)."""
+    return _AuxTerms.apply(0, rot, shape, cam, joints49, t_rot, t_shape, t_cam, t_joints49, None, None, None, None, None)
+
+
+def motion_term(rot, shape, cam, joints49, h_cam, h_joints49, kp2d, hist_kp2d):
+    """Motion term (base_adaptor.py:379-398): confidence-masked mse between the predicted and the annotated keypoint motion from the
+    history frame to this one; differentiable in both passes -> (loss, components)."""
+    return _AuxTerms.apply(1, rot, shape, cam, joints49, None, None, h_cam, h_joints49, kp2d, hist_kp2d, None, None, None)
+
+
+def labelled_term(rot, shape, cam, joints49, kp2d, gt_rot, gt_betas, gt_s3d):
+    """Labelled-exemplar term (base_adaptor.py:346-376 with the hip-centred 3-D loss of :412-422) -> (loss, tensor(s2d, s3d, shape,
+    pose))."""
+    return _AuxTerms.apply(2, rot, shape, cam, joints49, None, None, None, None, kp2d, None, gt_rot, gt_betas, gt_s3d)

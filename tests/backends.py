@@ -16,7 +16,8 @@ class EmuBackend:
     def __init__(self):
         from emu.build_emu import build
         from dynaboa_amd import _abi
-        self.lib = _abi.bind(ctypes.CDLL(build()))
+        self.raw = ctypes.CDLL(build())      # also carries the emulator's own hooks (emu_lazy / emu_flush: stream-ordering checks)
+        self.lib = _abi.bind(self.raw)
         self.stream = None
         self._keep = []          # buffers stay alive for the backend's lifetime (module-scoped fixture)
 

@@ -10,7 +10,10 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <algorithm>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdio>
 #include <mutex>
 #include <thread>
@@ -332,4 +335,100 @@ void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx) {
   std::unique_lock<std::mutex> lk(g_pool_mu);
   g_cv_done.wait(lk, [&] { return g_active == 0; });
 }
+
+// ---- streams: immediate execution, or per-stream queues drained by emu_flush (see hip_runtime.h) ----------------------------------
+struct Event {
+  unsigned long long submitted = 0, completed = 0;
+};
+namespace {
+struct Op {
+  int kind;                            // 0 work, 1 record, 2 wait
+  std::function<void()> fn;
+  Event* ev;
+  unsigned long long gen;
+};
+struct Queue {
+  void* stream;
+  std::deque<Op> ops;
+  bool draining = false;
+};
+std::mutex& q_mu = *new std::mutex();
+bool g_lazy = false;
+std::vector<Queue*>& g_queues = *new std::vector<Queue*>();      // in order of first use
+
+Queue& queue_of(void* stream) {
+  for (Queue* q : g_queues)
+    if (q->stream == stream) return *q;
+  g_queues.push_back(new Queue{stream});
+  return *g_queues.back();
+}
+// run q until its record of (until, gen) has executed (until == nullptr: to the end)
+void drain(Queue& q, Event* until, unsigned long long gen) {
+  if (q.draining) { fprintf(stderr, "emu: circular wait between streams\n"); abort(); }
+  q.draining = true;
+  while (!q.ops.empty()) {
+    Op op = std::move(q.ops.front());
+    q.ops.pop_front();
+    if (op.kind == 0) {
+      op.fn();
+    } else if (op.kind == 1) {
+      op.ev->completed = op.gen;
+      if (op.ev == until && op.gen >= gen) break;
+    } else if (op.ev->completed < op.gen) {
+      Queue* src = nullptr;
+      for (Queue* o : g_queues)
+        for (const Op& c : o->ops)
+          if (c.kind == 1 && c.ev == op.ev && c.gen == op.gen) src = o;
+      if (!src) { fprintf(stderr, "emu: wait on an event record that no stream holds\n"); abort(); }
+      drain(*src, op.ev, op.gen);
+    }
+  }
+  q.draining = false;
+}
+}  // namespace
+void submit(void* stream, std::function<void()> op) {
+  {
+    std::lock_guard<std::mutex> lk(q_mu);
+    if (g_lazy) {
+      queue_of(stream).ops.push_back(Op{0, std::move(op), nullptr, 0});
+      return;
+    }
+  }
+  op();
+}
+Event* event_new() { return new Event(); }
+void event_delete(Event* e) { delete e; }
+void event_record(Event* e, void* stream) {
+  std::lock_guard<std::mutex> lk(q_mu);
+  if (!g_lazy || !e) return;
+  queue_of(stream).ops.push_back(Op{1, {}, e, ++e->submitted});
+}
+void stream_wait(void* stream, Event* e) {
+  std::lock_guard<std::mutex> lk(q_mu);
+  if (!g_lazy || !e || e->submitted == 0) return;                // never recorded: no dependency (as on the device)
+  queue_of(stream).ops.push_back(Op{2, {}, e, e->submitted});
+}
 }  // namespace emu
+
+// test hooks (exported next to the product's C ABI in libdynaboa_emu.so)
+extern "C" void emu_lazy(int on) {
+  std::lock_guard<std::mutex> lk(emu::q_mu);
+  emu::g_lazy = on != 0;
+}
+// order 0: streams in order of first use, each to completion (later ones only run ahead where a wait demands it); 1: the reverse.
+// Returns the number of streams that held work.
+extern "C" int emu_flush(int order) {
+  std::vector<emu::Queue*> qs;
+  {
+    std::lock_guard<std::mutex> lk(emu::q_mu);
+    qs = emu::g_queues;
+  }
+  int n = 0;
+  for (emu::Queue* q : qs) n += q->ops.empty() ? 0 : 1;
+  if (order) std::reverse(qs.begin(), qs.end());
+  const bool was = emu::g_lazy;
+  emu::g_lazy = false;                 // operations issued by running work (none today) would run at once
+  for (emu::Queue* q : qs) emu::drain(*q, nullptr, 0);
+  emu::g_lazy = was;
+  return n;
+}

@@ -13,6 +13,7 @@
 // lane -> element maps.  The resulting library (tests/emu/_build/libdynaboa_emu.so) is loaded
 // only by tests; dynaboa_amd/_lib.py never looks for it.
 #pragma once
+#include <functional>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -44,23 +45,37 @@ typedef int hipError_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
-  memcpy(d, s, n);
+// Streams.  By default every operation runs at once, in issue order (one implicit queue).  In "lazy" mode (emu_lazy(1), tests only)
+// operations are queued per stream and run when emu_flush(order) drains the queues - one stream to completion first, the others only
+// as far as its event waits demand - so that a missing cross-stream wait shows up as a wrong result: order 0 runs the first-used
+// stream as early and the others as late as the recorded waits allow, order 1 the other way round (see emu_runtime.cpp).
+namespace emu {
+struct Event;
+void submit(void* stream, std::function<void()> op);
+Event* event_new();
+void event_delete(Event* e);
+void event_record(Event* e, void* stream);
+void stream_wait(void* stream, Event* e);
+}  // namespace emu
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
+  emu::submit(st, [=]() { memcpy(d, s, n); });
   return hipSuccess;
 }
-static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
-  memset(d, v, n);
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
+  emu::submit(st, [=]() { memset(d, v, n); });
   return hipSuccess;
 }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind,
-                                          hipStream_t) {
-  for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+                                          hipStream_t st) {
+  emu::submit(st, [=]() {
+    for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+  });
   return hipSuccess;
 }
 
-typedef void* hipEvent_t;
+typedef emu::Event* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = emu::event_new(); return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, sync) ((void)0)
 static inline long long clock64() { return 0; }
@@ -82,11 +97,11 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
 }
 static inline void __threadfence_system() {}
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { emu::event_delete(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) { emu::event_record(e, st); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned) { emu::stream_wait(st, e); return hipSuccess; }
 
 // graphs are not emulated: capture reports failure and the engine stays on its eager path
 typedef void* hipGraph_t;
@@ -110,6 +125,11 @@ void run_grid(dim3 grid, dim3 block, void (*call)(void*), void* ctx);
 template <class F>
 void launch(dim3 grid, dim3 block, F body) {
   run_grid(grid, block, [](void* p) { (*static_cast<F*>(p))(); }, &body);
+}
+// kernel arguments are taken by value at the launch call (as a real launch copies them into the kernel-argument segment)
+template <class K, class... A>
+void launch_on(void* stream, dim3 grid, dim3 block, K kernel, A... args) {
+  submit(stream, [=]() { launch(grid, block, [=]() { kernel(args...); }); });
 }
 }  // namespace emu
 
@@ -181,4 +201,4 @@ static inline unsigned __float_as_uint(float f) {
 }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+  emu::launch_on((void*)(stream), (grid), (block), kernel, __VA_ARGS__)

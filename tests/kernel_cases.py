@@ -1110,3 +1110,81 @@ def case_hmr_hvp(be, ckpt, seed=5, B=1, side=True):
     e["hv_max_rel"] = max(v[0] for v in worst.values())
     e["hv_min_cos"] = min(v[1] for v in worst.values())
     return e
+
+
+# ---------------------------------------------------------------------------------------- stream ordering (emulator only)
+def case_stream_order(be, ckpt, seed=5):
+    """The engine's side-stream schedules under the emulator's lazy stream mode (tests/emu: operations queue per stream and run
+    when flushed, one stream to completion first and the others only as far as the recorded event waits demand): the first-order
+    backward with its weight gradients on the side stream, and the two tangent passes of the exact Hessian-vector product with
+    the off-chain halves of every pair there, must give bit-identical results to the in-line run under both drain orders (chain
+    first: side-stream work as late as the waits allow; side stream first: as early as they allow).  A missing wait in either
+    direction (a result read before it exists, a buffer overwritten while another stream still reads it) changes the numbers."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr_layout import HmrLayout
+    assert be.name == "emu"
+    raw = be.raw
+    rng = _rng(seed)
+    B = 1
+    L = HmrLayout(be.lib, B)
+    names = [k for k in ckpt if k not in ("init_pose", "init_shape", "init_cam")]
+    vdict = {k: torch.from_numpy(rng.standard_normal(tuple(ckpt[k].shape)).astype(np.float32)) * (0.02 if ckpt[k].dim() > 1 else 0.05)
+             for k in names}
+    for k in ("init_pose", "init_shape", "init_cam"):
+        vdict[k] = torch.zeros_like(ckpt[k])
+    params, tparams = be.dev(L.pack(ckpt).numpy()), be.dev(L.pack(vdict).numpy())
+    IMG = be.dev(assets.make_frame(3, batch_size=B, seed=22)["image"].numpy())
+    INIT = be.dev(np.repeat(HmrLayout.init_state(ckpt).numpy(), B, 0))
+    acts, ws = be.empty((L.act_floats,)), be.empty((L.ws_bytes // 4,))
+    check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(IMG), be.ptr(INIT), 3, be.ptr(acts), be.ptr(ws), L.ws_bytes, be.stream),
+          "hmr forward")
+    d_state = np.zeros((B, 160), np.float32)
+    d_state[:, :157] = rng.standard_normal((B, 157)).astype(np.float32)
+    DS, TDS = be.dev(d_state), be.dev(0.1 * rng.standard_normal((B, 160)).astype(np.float32))
+    DROT = be.dev(rng.standard_normal((B, 24, 3, 3)).astype(np.float32))
+    nd = int(be.lib.dyb_hmr_hvp_dual_floats(L.plan))
+    off = int(be.lib.dyb_hmr_hvp_offset_tstate(L.plan))
+
+    def run(aux, order):
+        lazy = order is not None
+        grads, hv, dual = be.zeros((L.n_params,)), be.zeros((L.n_params,)), be.empty((nd,))
+        used = []
+        for call in (lambda: be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(DROT), be.ptr(DS), 3, be.ptr(grads),
+                                                     be.ptr(ws), L.ws_bytes, be.stream, aux),
+                     lambda: be.lib.dyb_hmr_jvp_forward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), 3, be.ptr(ws),
+                                                        L.ws_bytes, be.stream, aux),
+                     lambda: be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(DS),
+                                                         be.ptr(TDS), 3, be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream, aux)):
+            if lazy:
+                raw.emu_lazy(1)
+            try:
+                check(call(), "engine call")
+            finally:
+                if lazy:
+                    used.append(raw.emu_flush(order))
+                    raw.emu_lazy(0)
+        return be.host(grads), be.host(hv), be.host(dual)[off:off + B * 160].copy(), used
+
+    g0, h0, t0, _ = run(None, None)
+    assert np.isfinite(g0).all() and np.isfinite(h0).all() and np.abs(h0).max() > 0
+    out = {}
+    import os
+    old = os.environ.get("DYB_HVP_OVERLAP")
+    try:
+        # 7: everything off-chain on the side stream (the default); 3: dgrad(dy, tw) in line - the (dy, tdy) ring is then the only
+        # thing between the chain and the side stream's weight gradients
+        for ov in ((7, 3) if os.environ.get("DYB_EMU_FULL") else (7,)):       # the second setting is opt-in (+1 min)
+            os.environ["DYB_HVP_OVERLAP"] = str(ov)
+            for order in (0, 1):
+                g, h, t, used = run(1, order)                 # any non-null handle is a second stream to the emulator
+                assert used == [2, 2, 2], used                # both queues held work in every call
+                assert np.array_equal(g, g0), ("first-order backward", ov, order, float(np.abs(g - g0).max()))
+                assert np.array_equal(t, t0), ("tangent forward", ov, order, float(np.abs(t - t0).max()))
+                assert np.array_equal(h, h0), ("tangent backward", ov, order, float(np.abs(h - h0).max()))
+                out[(ov, order)] = used
+    finally:
+        if old is None:
+            os.environ.pop("DYB_HVP_OVERLAP", None)
+        else:
+            os.environ["DYB_HVP_OVERLAP"] = old
+    return out

@@ -384,6 +384,66 @@ def test_second_order_full_loss_set_exact_hvp_vs_reference_second_order(emu_lib)
             assert min(sl.values()) > 0.999, sl
 
 
+def test_term_kernel_autograd_nodes_match_torch_composition(emu_lib):
+    """losses.teacher_term / motion_term / labelled_term (dyb_aux_loss_terms as autograd nodes, what BaseAdaptor._level uses by default
+    on the autograd path) against the torch composition of the reference's formulas (base_adaptor.py:320-343, :379-398, :346-376 +
+    :412-422): value, logged components and the gradients autograd routes to both passes, with strided (state-slice) inputs."""
+    import torch.nn.functional as F
+    from dynaboa_amd import losses as LS
+    from kernel_cases import _proj_t
+    B = 3
+    g = torch.Generator().manual_seed(17)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    def pass_():
+        rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3)).clone().requires_grad_(True)
+        state = torch.zeros(B, 160)
+        state[:, 144:154] = rn(B, 10) * 0.5
+        state[:, 154:157] = torch.tensor([0.9, 0.02, -0.03]) + 0.05 * rn(B, 3)
+        state = state.requires_grad_(True)
+        return rot, state, (rn(B, 49, 3) * 0.3).requires_grad_(True)
+    kp = torch.cat([torch.rand(B, 49, 2, generator=g) * 2 - 1, (torch.rand(B, 49, 1, generator=g) < 0.7).float()], -1)
+    kp2 = torch.cat([torch.rand(B, 49, 2, generator=g) * 2 - 1, (torch.rand(B, 49, 1, generator=g) < 0.7).float()], -1)
+    gt_rot, gt_betas = torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3), rn(B, 10) * 0.5
+    gt_s3d = torch.cat([rn(B, 24, 3) * 0.3, torch.ones(B, 24, 1)], -1)
+    for mode in (0, 1, 2):
+        rot, state, joints = pass_()
+        rot2, state2, joints2 = pass_()
+        shape, cam, shape2, cam2 = state[:, 144:154], state[:, 154:157], state2[:, 144:154], state2[:, 154:157]
+        s2d = _proj_t(cam, joints)
+        if mode == 0:
+            comps = [F.mse_loss(s2d, _proj_t(cam2, joints2).detach()), F.mse_loss(joints2.detach(), joints), F.mse_loss(shape, shape2.detach()),
+                     F.mse_loss(rot, rot2.detach())]
+            ref = comps[0] * 5 + comps[1] * 5 + comps[2] * 0.001 + comps[3]
+            got, gc = LS.teacher_term(rot, shape, cam, joints, rot2.detach(), shape2.detach(), cam2.detach(), joints2.detach())
+            leaves = [rot, state, joints]
+        elif mode == 1:
+            pm = s2d[:, 25:] - _proj_t(cam2, joints2)[:, 25:]
+            gm = kp[:, 25:, :2] - kp2[:, 25:, :2]
+            conf = ((kp2[:, 25:, 2:] + kp[:, 25:, 2:]) == 2).float()
+            ref = (((pm - gm) ** 2) * conf).mean()
+            comps = [ref]
+            got, gc = LS.motion_term(rot, shape, cam, joints, cam2, joints2, kp, kp2)
+            leaves = [state, joints, state2, joints2]
+        else:
+            conf = kp[:, 25:, 2:]
+            p24, g24 = joints[:, 25:], gt_s3d[:, :, :3]
+            pc, gcn = p24 - ((p24[:, 2] + p24[:, 3]) / 2)[:, None], g24 - ((g24[:, 2] + g24[:, 3]) / 2)[:, None]
+            comps = [(((s2d[:, 25:] - kp[:, 25:, :2]) ** 2) * conf).mean(), (conf * (pc - gcn) ** 2).mean(), F.mse_loss(shape, gt_betas),
+                     F.mse_loss(rot, gt_rot)]
+            ref = comps[0] * 5 + comps[1] * 5 + comps[2] * 0.001 + comps[3]
+            got, gc = LS.labelled_term(rot, shape, cam, joints, kp, gt_rot, gt_betas, gt_s3d)
+            leaves = [rot, state, joints]
+        assert abs(float(got) - float(ref)) < 1e-5 * abs(float(ref)), (mode, float(got), float(ref))
+        for i, c in enumerate(comps):
+            assert abs(float(gc[i]) - float(c)) < 1e-5 * abs(float(c)) + 1e-12, (mode, i)
+        w = 0.37
+        g_ref = torch.autograd.grad(ref * w, leaves)
+        g_got = torch.autograd.grad(got * w, leaves)
+        for a, b in zip(g_got, g_ref):
+            assert rel_err(a.numpy(), b.numpy()) < 2e-5, (mode, rel_err(a.numpy(), b.numpy()))
+
+
 def test_exact_hvp_selection_rules(emu_lib):
     """--hvp exact serves levels made of the frame losses; levels with teacher / motion / labelled terms (and --hvp fd) get no
     factory, i.e. MAML.adapt differences the closure's gradient."""

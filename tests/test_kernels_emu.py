@@ -315,6 +315,13 @@ def test_groupnorm_tangent_kernels(be, cfg):
     K.case_gn_jvp(be, *cfg)
 
 
+def test_side_stream_schedules_hold_under_adversarial_stream_order(be, ckpt_rand):
+    """The first-order backward (weight gradients on the side stream) and the exact Hessian-vector product's two tangent passes (the
+    off-chain halves of every pair on the side stream) in the emulator's lazy stream mode, drained chain-first and side-stream-first:
+    bit-identical to the in-line run, i.e. every cross-stream dependency is covered by an event wait."""
+    print(K.case_stream_order(be, ckpt_rand))
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("B", [1, pytest.param(2, marks=pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1",
                                                                             reason="opt-in (DYB_EMU_FULL=1): +75 s"))])

@@ -2,9 +2,9 @@
 # second-order session: parity tests of the tangent kernels / passes (with and without the side stream), the one-sequence second-order
 # frame under the three overlap settings, its kernel trace, and the batch-16 second-order arm
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 400 python -m pytest tests -m gpu -q -x -k "groupnorm_tangent or hessian or exact_hvp or second_order" > gpurun_out/so_pytest.txt 2>&1; tail -3 gpurun_out/so_pytest.txt
+timeout 400 python -m pytest tests -m gpu -q -x -k "groupnorm_tangent or hessian or exact_hvp or second_order or native_full_term_set" > gpurun_out/so_pytest.txt 2>&1; tail -3 gpurun_out/so_pytest.txt
 Q="--no_cpu_baseline --no_roofline --no_sub_records --percentile_frames 0"
-for OV in 7 0 3 1; do
+for OV in 7 0 3; do
   DYB_HVP_OVERLAP=$OV timeout 120 python bench.py --seqs 1 --second_order 1 --hvp exact --steps 12 --warmup 3 $Q > gpurun_out/so_bench_ov$OV.json 2> gpurun_out/so_bench_ov$OV.err
   python - <<PY
 import json
