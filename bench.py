@@ -662,8 +662,8 @@ def main():
             torch.cuda.empty_cache()
             out["second_order_full_losses_exact_hvp"] = sub_record(
                 device, "so_full_exact", 4, 1, 1, 1, "the reference's default term set in second-order mode with exact Hessian-vector "
-                "products for every level (--hvp_terms all: multi-pass form, verified on the CPU emulator; this is its first GPU run - a "
-                "timing, not a parity check)", full_losses=1, second_order=1, hvp="exact", hvp_terms="all")
+                "products for every level (--hvp_terms all, the default: multi-pass form; parity: tests/test_adaptation_gpu.py "
+                "test_second_order_full_loss_set_matches_reference_second_order)", full_losses=1, second_order=1, hvp="exact", hvp_terms="all")
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
         print(json.dumps(out))

@@ -388,8 +388,8 @@ class BaseAdaptor:
             # frame losses only (the benchmarked second-order configuration): the head's gradient straight from the kernels
             return lambda theta: frame_level_hvp(hmr, self.smpl_neutral, self.gmm_f, theta, image, gt_keypoints_2d, o.s2dloss_weight,
                                                  o.shape_prior_weight, o.pose_prior_weight)
-        if getattr(o, "hvp_terms", "frame") != "all":
-            return None                      # --hvp_terms frame (default): teacher / motion / labelled levels keep the difference quotient
+        if getattr(o, "hvp_terms", "all") != "all":
+            return None                      # --hvp_terms frame: teacher / motion / labelled levels keep the difference quotient
         used = getattr(self, "_last_h36m", None)
         return lambda theta: general_level_hvp(self, level, hmr, theta, image, gt_keypoints_2d, used)
 

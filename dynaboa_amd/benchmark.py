@@ -71,10 +71,10 @@ parser.add_argument('--hvp', type=str, default=os.environ.get("DYB_HVP", "exact"
                          'the backbone and regressor; the 157-input loss head (rot6d -> SMPL -> projection / priors) is differentiated '
                          'along the state tangent by a central difference of its analytic gradient (exact: levels made of the frame '
                          'losses; other levels fall back) - or as a central difference of first-order gradients of the whole level (fd)')
-parser.add_argument('--hvp_terms', type=str, default="frame", choices=["all", "frame"],
-                    help='--hvp exact for levels made of the frame losses only (frame: levels with teacher / motion / labelled '
-                         'terms use fd) or for every level through the multi-pass form (all: checked against the oracle on the '
-                         'CPU emulator, not yet on the GPU - hence not the default)')
+parser.add_argument('--hvp_terms', type=str, default="all", choices=["all", "frame"],
+                    help='--hvp exact for every level through the multi-pass form (all, the default: on MI355X the 4-frame second-order '
+                         'stream on the default term set matches the reference\'s first_order=False run element-wise) or only for levels '
+                         'made of the frame losses (frame: levels with teacher / motion / labelled terms take the difference quotient)')
 parser.add_argument('--fused_so_adam', type=int, default=1, choices=[0, 1],
                     help='second order: fold the last accumulation of the outer gradient (v - lr*Hv) into the Adam launch')
 parser.add_argument('--second_order', type=int, default=0, choices=[0, 1],

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void gn_jvp_fwd_apply_kernel(const float* __re
 // tdxh = tgamma dm + gamma tdm, tc1 = mean(tdxh), tc2 = mean(tdxh xhat + dxh txhat), tr = -r^2 a,
 // tdy = tr (dxh - c1 - xhat c2) + r (tdxh - tc1 - txhat c2 - xhat tc2);
 // per chunk and channel: tdgb[n][chunk][0][c] = sum_p tdm (tangent of dbeta), tdgb[n][chunk][1][c] = sum_p (tdm xhat + dm txhat)
-// (of dgamma).  grid (chunks, G, N), block 256: sums (part[slab][chunk][4] + the channel sums), then apply.
+// (of dgamma).  grid (chunks, G, N), block 256: sums (part[slab][chunk][4] + the channel sums), then apply (whose first workgroup
+// per group also adds the channel sums up over images and chunks).
 struct GnJvpBwdIn {
   const float *dout, *tdout, *out_mask, *y, *ty;
   float mu, r, tmu, a;
@@ -243,9 +244,25 @@ __global__ __launch_bounds__(256) void gn_jvp_bwd_apply_kernel(const float* __re
                                                                const float* __restrict__ tstats, const float* __restrict__ gamma,
                                                                const float* __restrict__ tgamma, const double* __restrict__ part,
                                                                float* __restrict__ dm, float* __restrict__ tdm, float* __restrict__ dy,
-                                                               float* __restrict__ tdy, int HW, int C, int rows, int relu) {
+                                                               float* __restrict__ tdy, const float* __restrict__ tdgb,
+                                                               float* __restrict__ tdbeta, float* __restrict__ tdgamma, int HW, int C,
+                                                               int rows, int relu) {
   const int ch = blockIdx.x, g = blockIdx.y, n = blockIdx.z, Cg = C / G, cq = Cg >> 2;
   const int slab = n * G + g;
+  if (ch == 0 && n == 0) {
+    // the group's channel sums over images and chunks (rows of tdgb in (image, chunk) order): tangents of dbeta / dgamma
+    const int nrows = gridDim.x * gridDim.z;
+    for (int cc = threadIdx.x; cc < Cg; cc += 256) {
+      const int c = g * Cg + cc;
+      float sb = 0.f, sg = 0.f;
+      for (int rw = 0; rw < nrows; ++rw) {
+        sb += tdgb[((size_t)rw * 2 + 0) * C + c];
+        sg += tdgb[((size_t)rw * 2 + 1) * C + c];
+      }
+      tdbeta[c] = sb;
+      tdgamma[c] = sg;
+    }
+  }
   const GnJvpBwdIn in{dout, tdout, out_mask, y, ty, stats[(size_t)slab * 2], stats[(size_t)slab * 2 + 1], tstats[(size_t)slab * 2],
                       tstats[(size_t)slab * 2 + 1], relu};
   const float r = in.r, tr = -r * r * in.a;
@@ -276,20 +293,6 @@ __global__ __launch_bounds__(256) void gn_jvp_bwd_apply_kernel(const float* __re
     *reinterpret_cast<float4*>(dy + off) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(tdy + off) = make_float4(to[0], to[1], to[2], to[3]);
   }
-}
-
-// dst[c] (+)= sum_n src[n][row][c] for the two rows of a [N][2][C] block: dst_b from row 0, dst_g from row 1
-__global__ __launch_bounds__(256) void gn_jvp_colsum_kernel(const float* __restrict__ src, float* __restrict__ dst_b,
-                                                            float* __restrict__ dst_g, int N, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float sb = 0.f, sg = 0.f;
-  for (int n = 0; n < N; ++n) {
-    sb += src[((size_t)n * 2 + 0) * C + c];
-    sg += src[((size_t)n * 2 + 1) * C + c];
-  }
-  dst_b[c] = sb;
-  dst_g[c] = sg;
 }
 
 // tangent of MaxPool2d(3, 2, 1): ty[j] = tx[winning tap of j] (the tap index the forward stored, one byte per channel)
@@ -349,10 +352,7 @@ extern "C" int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float
                      tdgb, HW, C, ge.rows, relu);
   DYB_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_jvp_bwd_apply_kernel, grid, dim3(256), 0, st, dout, tdout, out_mask, y, ty, stats, tstats, gamma, tgamma,
-                     (const double*)part, dm, tdm, dy, tdy, HW, C, ge.rows, relu);
-  DYB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_jvp_colsum_kernel, dim3(dyb_cdiv(C, 256)), dim3(256), 0, st, (const float*)tdgb, tdbeta, tdgamma, N * ge.chunks,
-                     C);
+                     (const double*)part, dm, tdm, dy, tdy, (const float*)tdgb, tdbeta, tdgamma, HW, C, ge.rows, relu);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

@@ -16,8 +16,9 @@ while the 50-layer ReLU / GroupNorm backbone, where a difference quotient of the
 ``frame_level_hvp`` covers levels made of the frame losses only (2-D keypoints + shape prior + pose prior) - the benchmarked
 second-order configuration, checked on the GPU against the reference's second-order golden.  ``general_level_hvp`` covers any
 level (teacher / motion / labelled terms: up to three network passes sharing the weights, head assembled from the adaptor's
-differentiable pieces); checked against the oracle's create_graph gradient on the CPU emulator (1e-4 at layer2, 1e-6 above,
-where the difference quotient gave 2e-2 / 6e-3), opt-in (``--hvp_terms all``) until it has run on the GPU."""
+differentiable pieces); checked on MI355X against the reference's own second-order run on its default term set (golden
+g5_so_inner1_full, 4 frames, element-wise slices of Adam's moments included) and against the oracle's create_graph gradient on the
+CPU emulator (1e-4 at layer2, 1e-6 above, where the difference quotient gave 2e-2 / 6e-3); the default (``--hvp_terms all``)."""
 from __future__ import annotations
 
 import torch

@@ -445,8 +445,8 @@ def test_term_kernel_autograd_nodes_match_torch_composition(emu_lib):
 
 
 def test_exact_hvp_selection_rules(emu_lib):
-    """--hvp exact serves levels made of the frame losses; levels with teacher / motion / labelled terms (and --hvp fd) get no
-    factory, i.e. MAML.adapt differences the closure's gradient."""
+    """--hvp exact serves every level by default (--hvp_terms all); with --hvp_terms frame levels with teacher / motion / labelled
+    terms (and any level with --hvp fd) get no factory, i.e. MAML.adapt differences the closure's gradient."""
     from dynaboa_amd import assets, benchmark as DB
     from dynaboa_amd.base_adaptor import synthetic_bundle
     assert DB.parser.parse_args([]).hvp in ("exact", "fd")
@@ -459,11 +459,12 @@ def test_exact_hvp_selection_rules(emu_lib):
     assert ad.level_hvp_factory("lower", img, kp, learner) is None
     full = DB.parser.parse_args([])                      # the reference's default term set: labelled exemplars in the lower level
     full.second_order, full.hvp = 1, "exact"
+    assert full.hvp_terms == "all"                       # the multi-pass form is the default (checked on MI355X against the reference)
     ad2 = DB.Adaptor(full, bundle, device="cpu")
+    assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is not None
+    ad2.options.hvp_terms = "frame"                      # exact products for frame-loss levels only
     assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is None
     assert ad2.level_hvp_factory("upper", img, kp, ad2.model.clone()) is None
-    ad2.options.hvp_terms = "all"                        # the multi-pass form (opt-in)
-    assert ad2.level_hvp_factory("lower", img, kp, ad2.model.clone()) is not None
 
 
 def test_fused_adam_accumulate_matches_separate_accumulate(emu_lib):
