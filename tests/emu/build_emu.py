@@ -18,7 +18,8 @@ def sources():
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
-    deps = sources() + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
+    deps = sources() + [os.path.join(HERE, "emu_runtime.cpp"),
+                        *sorted(os.path.join(HERE, "include", "hip", f) for f in os.listdir(os.path.join(HERE, "include", "hip"))),
                         *sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))),
                         os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dynaboa_hip.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):

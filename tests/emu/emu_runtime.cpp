@@ -346,7 +346,12 @@ struct Op {
   std::function<void()> fn;
   Event* ev;
   unsigned long long gen;
+  const char* what = "";
 };
+bool trace_on() {
+  static const bool v = getenv("EMU_STREAM_TRACE") != nullptr;
+  return v;
+}
 struct Queue {
   void* stream;
   std::deque<Op> ops;
@@ -369,6 +374,9 @@ void drain(Queue& q, Event* until, unsigned long long gen) {
   while (!q.ops.empty()) {
     Op op = std::move(q.ops.front());
     q.ops.pop_front();
+    if (trace_on())
+      fprintf(stderr, "emu stream %p: %s %s ev %p gen %llu\n", q.stream, op.kind == 0 ? "run" : op.kind == 1 ? "record" : "wait", op.what,
+              (void*)op.ev, op.gen);
     if (op.kind == 0) {
       op.fn();
     } else if (op.kind == 1) {
@@ -386,11 +394,11 @@ void drain(Queue& q, Event* until, unsigned long long gen) {
   q.draining = false;
 }
 }  // namespace
-void submit(void* stream, std::function<void()> op) {
+void submit(void* stream, std::function<void()> op, const char* what) {
   {
     std::lock_guard<std::mutex> lk(q_mu);
     if (g_lazy) {
-      queue_of(stream).ops.push_back(Op{0, std::move(op), nullptr, 0});
+      queue_of(stream).ops.push_back(Op{0, std::move(op), nullptr, 0, what});
       return;
     }
   }

@@ -51,7 +51,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 // stream as early and the others as late as the recorded waits allow, order 1 the other way round (see emu_runtime.cpp).
 namespace emu {
 struct Event;
-void submit(void* stream, std::function<void()> op);
+void submit(void* stream, std::function<void()> op, const char* what = "copy");
 Event* event_new();
 void event_delete(Event* e);
 void event_record(Event* e, void* stream);
@@ -128,8 +128,8 @@ void launch(dim3 grid, dim3 block, F body) {
 }
 // kernel arguments are taken by value at the launch call (as a real launch copies them into the kernel-argument segment)
 template <class K, class... A>
-void launch_on(void* stream, dim3 grid, dim3 block, K kernel, A... args) {
-  submit(stream, [=]() { launch(grid, block, [=]() { kernel(args...); }); });
+void launch_on(const char* what, void* stream, dim3 grid, dim3 block, K kernel, A... args) {
+  submit(stream, [=]() { launch(grid, block, [=]() { kernel(args...); }); }, what);
 }
 }  // namespace emu
 
@@ -201,4 +201,4 @@ static inline unsigned __float_as_uint(float f) {
 }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  emu::launch_on((void*)(stream), (grid), (block), kernel, __VA_ARGS__)
+  emu::launch_on(#kernel, (void*)(stream), (grid), (block), kernel, __VA_ARGS__)

@@ -1147,22 +1147,31 @@ def case_stream_order(be, ckpt, seed=5):
 
     def run(aux, order):
         lazy = order is not None
+        ws[...] = np.nan                              # nothing a previous run left in the workspace may stand in for a result not yet produced
         grads, hv, dual = be.zeros((L.n_params,)), be.zeros((L.n_params,)), be.empty((nd,))
+        gcopy, hcopy = be.empty((L.n_params,)), be.empty((L.n_params,))
         used = []
-        for call in (lambda: be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(DROT), be.ptr(DS), 3, be.ptr(grads),
+        # each call is followed, before the flush, by a consumer on the chain (a copy of its result): the call's own final join is
+        # what orders it after the side stream's last weight gradient
+        consumer = {0: lambda: be.lib.dyb_scale_add(None, be.ptr(grads), None, be.ptr(gcopy), L.n_params, be.stream),
+                    2: lambda: be.lib.dyb_scale_add(None, be.ptr(hv), None, be.ptr(hcopy), L.n_params, be.stream)}
+        for ci, call in enumerate((lambda: be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(DROT), be.ptr(DS), 3, be.ptr(grads),
                                                      be.ptr(ws), L.ws_bytes, be.stream, aux),
                      lambda: be.lib.dyb_hmr_jvp_forward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), 3, be.ptr(ws),
                                                         L.ws_bytes, be.stream, aux),
                      lambda: be.lib.dyb_hmr_jvp_backward(L.plan, be.ptr(params), be.ptr(tparams), be.ptr(acts), be.ptr(dual), be.ptr(DS),
-                                                         be.ptr(TDS), 3, be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream, aux)):
+                                                         be.ptr(TDS), 3, be.ptr(hv), be.ptr(ws), L.ws_bytes, be.stream, aux))):
             if lazy:
                 raw.emu_lazy(1)
             try:
                 check(call(), "engine call")
+                if ci in consumer:
+                    check(consumer[ci](), "consumer")
             finally:
                 if lazy:
                     used.append(raw.emu_flush(order))
                     raw.emu_lazy(0)
+        assert np.array_equal(be.host(gcopy), be.host(grads)) and np.array_equal(be.host(hcopy), be.host(hv)), "a consumer ran before the join"
         return be.host(grads), be.host(hv), be.host(dual)[off:off + B * 160].copy(), used
 
     g0, h0, t0, _ = run(None, None)

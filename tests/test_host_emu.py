@@ -217,6 +217,49 @@ def test_native_stepper_is_bit_identical_to_autograd_path(emu_lib):
     assert abs(a[6]["ul/total"] - g["upper_loss"][0]) < 1e-4 * abs(g["upper_loss"][0])
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~4 min under the emulator; set DYB_EMU_FULL=1")
+def test_native_stepper_side_stream_schedule_under_adversarial_stream_order(emu_lib, monkeypatch):
+    """The native frame step with its weight-gradient convolutions on the auxiliary stream, in the emulator's lazy stream mode (see
+    kernel_cases.case_stream_order): two frames drained chain-first and side-stream-first give the weights / Adam state / records of
+    the in-line run bit for bit - every consumer of a side-stream result (fast-weight update, Adam, the next frame) waits for it."""
+    from types import SimpleNamespace
+    from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    raw = _lib.load()
+    frames = [assets.make_frame(s, 1, seed=22) for s in range(2)]
+    orig = NS.NativeStepper.adapt_frames
+    outs = []
+    for order in (None, 0, 1):
+        used = []
+
+        def wrapped(self, batches, side_stream=None, order=order, used=used):
+            if order is None:
+                return orig(self, batches, side_stream)
+            self._aux = SimpleNamespace(cuda_stream=1)          # any non-null handle is a second stream to the emulator
+            raw.emu_lazy(1)
+            try:
+                return orig(self, batches, side_stream)
+            finally:
+                used.append(raw.emu_flush(order))
+                raw.emu_lazy(0)
+        monkeypatch.setattr(NS.NativeStepper, "adapt_frames", wrapped)
+        o = DB.frame_only_options(inner_step=1)
+        o.native_step, o.deferred_metrics = 1, 1
+        ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True, randomize_norm=True), device="cpu")
+        res = ad.excute(frames, nframes=2)
+        assert ad._native is not None
+        if order is not None:
+            assert used == [2, 2], used                          # both queues held work in both frame steps
+        st = ad.optimizer.state[ad.model.module.theta]
+        outs.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                     np.ravel(np.array(res["pampjpe"], np.float64)), np.ravel(np.array(res["mpjpe"], np.float64))))
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:3], other[:3]):
+            assert torch.equal(a, b)
+        np.testing.assert_array_equal(outs[0][3], other[3])
+        np.testing.assert_array_equal(outs[0][4], other[4])
+
+
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
     assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None
