@@ -114,14 +114,10 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
 # Any level: frame losses + mean-teacher + motion + labelled-exemplar terms (reference base_adaptor.py:222-398)
 # ---------------------------------------------------------------------------------------------------------------------
 def rot6d_to_rotmat(x6: torch.Tensor) -> torch.Tensor:
-    """reference utils/geometry.py:47-61 on the regressor's 144 pose numbers -> (B, 24, 3, 3); torch ops, differentiable."""
-    m = x6.reshape(-1, 3, 2)
-    a1, a2 = m[:, :, 0], m[:, :, 1]
-    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-12)
-    u = a2 - (b1 * a2).sum(1, keepdim=True) * b1
-    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-12)
-    b3 = torch.cross(b1, b2, dim=1)
-    return torch.stack([b1, b2, b3], dim=2).view(-1, 24, 3, 3)
+    """reference utils/geometry.py:47-61 on the regressor's 144 pose numbers -> (B, 24, 3, 3), on the library's kernel pair
+    (geometry._Rot6d: forward + hand-derived backward)."""
+    from .geometry import rot6d_to_rotmat as r6
+    return r6(x6.reshape(-1, 144)).view(-1, 24, 3, 3)
 
 
 class _Pass:
@@ -169,8 +165,7 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
     from the same differentiable pieces - is differentiated by torch for its gradient and by a central difference of that
     gradient along the joint state tangent for its second derivative; per pass the tangent of the backward gives its share of
     H v.  Exemplars, teacher targets and history are those of the level evaluation (nothing is re-drawn)."""
-    import torch.nn.functional as F
-    from .losses import frame_losses
+    from .losses import frame_losses, labelled_term, motion_term, teacher_term
     lib = _lib.load()
     o = ad.options
     theta = theta.detach()
@@ -187,7 +182,7 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
         with torch.no_grad():
             t_rot, t_shape, t_cam = ad.teacher(image)
             t_s3d = ad.decode_smpl_params(t_rot, t_shape)["s3d"]
-            teacher_t = (t_rot, t_shape, t_s3d, ad.projection(t_cam, t_s3d)["normed"])
+            teacher_t = (t_rot, t_shape, t_cam, t_s3d)
     hist = ad.get_hist() if use_motion else None
     from .fused_level import last_forward_acts
     # the frame's forward at these weights was just evaluated by the level: its activations are the primal pass of "img"
@@ -203,32 +198,21 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
         loss = None
         if use_frame:
             loss = frame_losses(rot, shape, cam, s3d, kp2d, ad.gmm_f, o.s2dloss_weight, o.shape_prior_weight, o.pose_prior_weight)[0]
+        # teacher / motion / labelled terms: the value+gradient kernel nodes `_level` uses (losses._AuxTerms)
         if temporal:
-            s2d = ad.projection(cam, s3d)["normed"]
             if use_teacher:                             # base_adaptor.py:320-343
-                t_rot, t_shape, t_s3d, t_s2d = teacher_t
-                t = (F.mse_loss(s2d, t_s2d) * 5 + F.mse_loss(t_s3d, s3d) * 5 + F.mse_loss(shape, t_shape) * 0.001
-                     + F.mse_loss(rot, t_rot)) * o.teacherloss_weight
+                t_rot, t_shape, t_cam, t_s3d = teacher_t
+                t = teacher_term(rot, shape, cam, s3d, t_rot, t_shape, t_cam, t_s3d)[0] * o.teacherloss_weight
                 loss = t if loss is None else loss + t
             if use_motion:                              # base_adaptor.py:379-398
                 h_rot, h_shape, h_cam, h_s3d = preds(states["hist"])
-                h_s2d = ad.projection(h_cam, h_s3d)["normed"]
-                gt, hist_s2d = kp2d[:, 25:], hist[1]
-                pm = s2d[:, 25:] - h_s2d[:, 25:]
-                gm = gt[:, :, :-1] - hist_s2d[:, 25:, :-1]
-                conf = ((hist_s2d[:, 25:, -1:] + gt[:, :, -1:]) == 2).float()
-                loss = loss + (((pm - gm) ** 2) * conf).mean() * o.motionloss_weight
+                loss = loss + motion_term(rot, shape, cam, s3d, h_cam, h_s3d, kp2d, hist[1])[0] * o.motionloss_weight
         if use_label:                                   # base_adaptor.py:346-376
             from .geometry import batch_rodrigues
             b = h36m_batch
             e_rot, e_shape, e_cam, e_s3d = preds(states["ex"])
-            g2d = b["keypoints"]
-            conf = g2d[:, 25:, -1:].clone()
             gt_rot = batch_rodrigues(b["pose"].view(-1, 3)).view(-1, 24, 3, 3)
-            e_s2d = ad.projection(e_cam, e_s3d)["normed"]
-            lab = ((((e_s2d[:, 25:] - g2d[:, 25:, :-1]) ** 2) * conf).mean() * 5
-                   + ad.cal_s3d_loss(e_s3d[:, 25:], b["pose_3d"][:, :, :-1], conf) * 5 + F.mse_loss(e_shape, b["betas"]) * 0.001
-                   + F.mse_loss(e_rot, gt_rot) * 1)
+            lab = labelled_term(e_rot, e_shape, e_cam, e_s3d, b["keypoints"], gt_rot, b["betas"], b["pose_3d"])[0]
             loss = loss + lab * o.labelloss_weight
         return loss
 

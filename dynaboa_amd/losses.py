@@ -180,22 +180,38 @@ class _AuxTerms(torch.autograd.Function):
         return tuple(out) + (None,) * 5
 
 
-AUX_MAX_BATCH = 16          # dyb_aux_loss_terms: one workgroup per sample set, B <= 16
+AUX_MAX_BATCH = 16          # dyb_aux_loss_terms: one launch covers up to 16 samples
+
+
+def _aux(mode, batched, const):
+    """`batched`: 13 per-sample tensors (or None) in _AuxTerms.forward's order.  Every component is a mean over the batch, so a batch
+    beyond one launch's 16 samples is the size-weighted sum of its chunks."""
+    B = batched[0].shape[0]
+    if B <= AUX_MAX_BATCH:
+        return _AuxTerms.apply(mode, *batched)
+    loss, comps = None, None
+    for i in range(0, B, AUX_MAX_BATCH):
+        part = [None if t is None else t[i:i + AUX_MAX_BATCH] for t in batched]
+        l, c = _AuxTerms.apply(mode, *part)
+        wgt = part[0].shape[0] / B
+        loss = l * wgt if loss is None else loss + l * wgt
+        comps = c * wgt if comps is None else comps + c * wgt
+    return loss, comps
 
 
 def teacher_term(rot, shape, cam, joints49, t_rot, t_shape, t_cam, t_joints49):
     """Mean-teacher consistency (reference base_adaptor.py:320-343): 5 mse(s2d) + 5 mse(s3d) + 0.001 mse(shape) + mse(rotmat) against
     the teacher's outputs, the normalised projections formed inside -> (loss, tensor(s2d, s3d, shape, pose) for logging)."""
-    return _AuxTerms.apply(0, rot, shape, cam, joints49, t_rot, t_shape, t_cam, t_joints49, None, None, None, None, None)
+    return _aux(0, [rot, shape, cam, joints49, t_rot, t_shape, t_cam, t_joints49, None, None, None, None, None], None)
 
 
 def motion_term(rot, shape, cam, joints49, h_cam, h_joints49, kp2d, hist_kp2d):
     """Motion term (base_adaptor.py:379-398): confidence-masked mse between the predicted and the annotated keypoint motion from the
     history frame to this one; differentiable in both passes -> (loss, components)."""
-    return _AuxTerms.apply(1, rot, shape, cam, joints49, None, None, h_cam, h_joints49, kp2d, hist_kp2d, None, None, None)
+    return _aux(1, [rot, shape, cam, joints49, None, None, h_cam, h_joints49, kp2d, hist_kp2d, None, None, None], None)
 
 
 def labelled_term(rot, shape, cam, joints49, kp2d, gt_rot, gt_betas, gt_s3d):
     """Labelled-exemplar term (base_adaptor.py:346-376 with the hip-centred 3-D loss of :412-422) -> (loss, tensor(s2d, s3d, shape,
     pose))."""
-    return _AuxTerms.apply(2, rot, shape, cam, joints49, None, None, None, None, kp2d, None, gt_rot, gt_betas, gt_s3d)
+    return _aux(2, [rot, shape, cam, joints49, None, None, None, None, kp2d, None, gt_rot, gt_betas, gt_s3d], None)

@@ -434,9 +434,16 @@ def test_term_kernel_autograd_nodes_match_torch_composition(emu_lib):
     import torch.nn.functional as F
     from dynaboa_amd import losses as LS
     from kernel_cases import _proj_t
-    B = 3
     g = torch.Generator().manual_seed(17)
     rn = lambda *s: torch.randn(*s, generator=g)
+    for B in (3, 20):                      # 20: beyond one launch's 16 samples (size-weighted chunks)
+        _term_nodes_vs_torch(B, g, rn)
+
+
+def _term_nodes_vs_torch(B, g, rn):
+    import torch.nn.functional as F
+    from dynaboa_amd import losses as LS
+    from kernel_cases import _proj_t
 
     def pass_():
         rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.3 * rn(B, 24, 3, 3)).clone().requires_grad_(True)
