@@ -30,6 +30,22 @@ def test_abi_header_matches_library(emu_lib):
         assert hasattr(emu_lib, name), name
 
 
+def test_public_header_is_plain_c(tmp_path):
+    """include/dynaboa_hip.h is the contract other host languages bind (cgo / JNI / ctypes): it must compile as
+    C99 and as C++17 on its own - no torch, HIP or C++ types in any signature."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "dynaboa_hip.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(root, "include")
+    if shutil.which("gcc"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++17", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+    assert shutil.which("gcc") or shutil.which("g++")
+
+
 def test_arena_pack_unpack_roundtrip(emu_lib, ckpt_rand):
     from dynaboa_amd.hmr_layout import HmrLayout
     L = HmrLayout(emu_lib, 1)
