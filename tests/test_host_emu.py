@@ -46,6 +46,31 @@ def test_public_header_is_plain_c(tmp_path):
     assert shutil.which("gcc") or shutil.which("g++")
 
 
+def test_plain_c_consumer_links_and_agrees_with_the_python_binding(emu_lib, tmp_path):
+    """tests/c_abi/consumer.c - plan + stepper through nothing but include/dynaboa_hip.h - compiled by gcc, linked against the library
+    under test, run: the sizes it reads are the ones the Python binding reads, option keys are checked by name."""
+    import shutil
+    import subprocess
+    from emu.build_emu import build
+    from dynaboa_amd.hmr import get_layout
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build()
+    exe = str(tmp_path / "consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "consumer.c"), "-L", os.path.dirname(lib), "-ldynaboa_emu",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    got = {k: int(v) for k, v in (line.split() for line in out.stdout.strip().splitlines())}
+    L = get_layout(1)
+    assert got["param_floats"] == L.n_params and got["act_floats"] == L.act_floats and got["workspace_bytes"] == L.ws_bytes
+    assert got["tensors"] == len(L.tensors)
+    assert got["record_floats"] >= 2 * 14 * 3 + 1 + 1 and got["loss_floats"] == (3 + 1) * 4       # (records are padded to a float4 multiple)
+    assert got["hvp_dual_floats"] > L.act_floats and got["stepper_workspace_bytes"] > 4 * got["workspace_bytes"]
+
+
 def test_arena_pack_unpack_roundtrip(emu_lib, ckpt_rand):
     from dynaboa_amd.hmr_layout import HmrLayout
     L = HmrLayout(emu_lib, 1)
