@@ -77,6 +77,7 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
     from .fused_level import last_forward_acts
     # the level was just evaluated at these weights: its activations are the primal pass (nothing writes to them afterwards)
     level_acts = last_forward_acts(theta, image, init_state, n_iter)
+    kp3 = kp2d.repeat(3, 1, 1)
 
     def hvp(v):
         v = v.detach().contiguous().float()
@@ -94,13 +95,14 @@ def frame_level_hvp(hmr, smpl, prior, theta, image, kp2d, w2d, wshape, wpose, n_
         state = acts[L.off_state:L.off_state + B * STATE_LD].view(B, STATE_LD)
         off = int(lib.dyb_hmr_hvp_offset_tstate(L.plan))
         tstate = dual[off:off + B * STATE_LD].view(B, STATE_LD)
-        g0 = _head_grad(lib, smpl, prior, state.contiguous(), kp2d, w2d, wshape, wpose, st)
         tn = torch.linalg.vector_norm(tstate[:, :157])
         eps = HEAD_FD_REL * torch.linalg.vector_norm(state[:, :157]) / tn.clamp_min(1e-30)
         step = torch.zeros_like(state)
         step[:, :157] = eps * tstate[:, :157]
-        gp = _head_grad(lib, smpl, prior, (state + step).contiguous(), kp2d, w2d, wshape, wpose, st)
-        gm = _head_grad(lib, smpl, prior, (state - step).contiguous(), kp2d, w2d, wshape, wpose, st)
+        # the head's gradient at the state and at the two difference points as ONE batch of 3 B samples (a third of the launches):
+        # every term of the head is a mean over the batch, so each sample's gradient comes out scaled by 1 / 3
+        g3 = _head_grad(lib, smpl, prior, torch.cat([state, state + step, state - step]).contiguous(), kp3, w2d, wshape, wpose, st) * 3.0
+        g0, gp, gm = g3[:B].contiguous(), g3[B:2 * B], g3[2 * B:]
         td = ((gp - gm) / (2 * eps)).contiguous()
         hv = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
         check(lib.dyb_hmr_jvp_backward(L.plan, theta.data_ptr(), v.data_ptr(), acts.data_ptr(), dual.data_ptr(), g0.data_ptr(),
