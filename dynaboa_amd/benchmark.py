@@ -354,10 +354,10 @@ class Adaptor(BaseAdaptor):
             self.kp2dlosses_lower.append(ns.losses(f, i, r)[0])
         log = self.fit_losses
         for tag, lv in ((("ll", K - 1),) if K > 0 else ()) + (("ul", K),):
-            l4 = ns.losses(f, lv, r)
+            l4 = ns.losses(f, lv, r).unbind(0)
             log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"] = l4[0], l4[1], l4[2]
             log[f"{tag}/unlabelloss"] = log[f"{tag}/total"] = l4[3]
-        self.kp2dlosses_upper[self.global_step] = ns.losses(f, K, r)[0]
+        self.kp2dlosses_upper[self.global_step] = log["ul/s2dloss"]
         out = (None, None, None)
         tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', 0)]
         if not o.deferred_metrics:

@@ -351,14 +351,35 @@ class NativeStepper:
     def join(self):
         check(self.lib.dyb_stepper_join(self.h, stream_of(self.theta)), "dyb_stepper_join")
 
+    # The per-frame bookkeeping of S adaptors takes views of these buffers: ~45 indexing operations per sequence and frame when each
+    # adaptor slices for itself - milliseconds of host time per step at 32 sequences, which the GPU spends idle at the frame boundary
+    # (DESIGN.md 7).  The views of ALL sequences of a frame are therefore cut in a few batched operations on first use and handed
+    # out from a one-frame cache; they are the same views of the same storage.
+    def _frame_record_views(self, slot: int):
+        T, B, S = self.slots_per_frame, self.B, self.S
+        f = slot // T
+        c = getattr(self, "_rec_cache", None)
+        if c is None or c[0] != f:
+            R = self.records[:, f * T:(f + 1) * T]                                # [S][T][record floats]
+            cols = (R[..., :B * 42].view(S, T, B, 14, 3), R[..., B * 42:B * 84].view(S, T, B, 14, 3), R[..., B * 84:B * 85], R[..., B * 85])
+            per = [[t.unbind(0) for t in col.unbind(0)] for col in cols]            # [field][replica][slot in frame]
+            c = self._rec_cache = (f, per)
+        return c[1]
+
     def record_views(self, slot: int, r: int = 0):
-        B = self.B
-        rec = self.records[r, slot]
-        return dict(pred=rec[:B * 42].view(B, 14, 3), gt=rec[B * 42:B * 84].view(B, 14, 3), mpjpe=rec[B * 84:B * 85], pve=rec[B * 85])
+        per = self._frame_record_views(slot)
+        k = slot % self.slots_per_frame
+        return dict(pred=per[0][r][k], gt=per[1][r][k], mpjpe=per[2][r][k], pve=per[3][r][k])
 
     def losses(self, frame: int, level: int, r: int = 0):
         """(s2d, shape prior, pose prior, weighted total) of level `level` (0..inner_step-1 lower, inner_step = upper)."""
-        return self.loss_log[r, frame, 4 * level:4 * level + 4]
+        if self.full:
+            return self.loss_log[r, frame, 4 * level:4 * level + 4]
+        c = getattr(self, "_loss_cache", None)
+        if c is None or c[0] != frame:
+            rows = self.loss_log[:, frame].view(self.S, -1, 4)                    # [S][levels][4]
+            c = self._loss_cache = (frame, [t.unbind(0) for t in rows.unbind(0)])
+        return c[1][r][level]
 
 
 class ReplicaGroup:
