@@ -543,32 +543,48 @@ class Adaptor(BaseAdaptor):
 
     def flush_metrics(self):
         """Resolve deferred records: one Procrustes launch over every record, one device->host transfer of scalars."""
-        if self._native is not None:
-            self._native.join()
-        if self._side is not None:
-            self._join_side()
-            self._side.synchronize()
-        rec = self._pending
-        self._pending = []
-        if not rec:
-            return dict(mpjpe=[], pampjpe=[], pve=[], records=[])
-        pred = torch.stack([r['pred'] for r in rec])
-        gt = torch.stack([r['gt'] for r in rec])
+        return flush_metrics_of([self])[0]
+
+
+def flush_metrics_of(adaptors):
+    """`Adaptor.flush_metrics` for several adaptors at once (the sequences of a ReplicaGroup): the deferred records of all of them
+    go through ONE Procrustes launch and ONE device->host transfer instead of one of each per adaptor.  -> list of the per-adaptor
+    dicts `flush_metrics` returns."""
+    for a in adaptors:
+        if a._native is not None:
+            a._native.join()
+        if a._side is not None:
+            a._join_side()
+            a._side.synchronize()
+    recs = []
+    for a in adaptors:
+        recs.append(a._pending)
+        a._pending = []
+    flat = [r for rec in recs for r in rec]
+    if flat:
+        pred = torch.stack([r['pred'] for r in flat])
+        gt = torch.stack([r['gt'] for r in flat])
         n, B = pred.shape[0], pred.shape[1]
         # Procrustes on the device: only scalars cross PCIe (one transfer for the whole run)
         pa_t = pa_mpjpe_device(pred.reshape(n * B, 14, 3), gt.reshape(n * B, 14, 3)).view(n, B)
-        allm = torch.cat([torch.stack([r['mpjpe'] for r in rec]).reshape(n, B), pa_t,
-                          torch.stack([r['pve'] for r in rec]).reshape(n, 1)], 1).cpu().numpy() * 1000
-        mp, pa, pve = allm[:, :B], allm[:, B:2 * B], allm[:, 2 * B]
+        allm = torch.cat([torch.stack([r['mpjpe'] for r in flat]).reshape(n, B), pa_t,
+                          torch.stack([r['pve'] for r in flat]).reshape(n, 1)], 1).cpu().numpy() * 1000
+    outs, i0 = [], 0
+    for rec in recs:
         out = dict(mpjpe=[], pampjpe=[], pve=[], records=[])
-        for i, r in enumerate(rec):
-            out['records'].append(dict(step=r['step'], tag=r['tag'], mpjpe=mp[i], pampjpe=pa[i], pve=float(pve[i])))
-            if r['tag'] is not None and r['tag'][0] == 'final':
-                if out['mpjpe'] and out['records'][-2]['step'] == r['step'] and out['records'][-2]['tag'][0] == 'final':
-                    out['mpjpe'][-1], out['pampjpe'][-1], out['pve'][-1] = mp[i], pa[i], float(pve[i])
-                else:
-                    out['mpjpe'].append(mp[i]); out['pampjpe'].append(pa[i]); out['pve'].append(float(pve[i]))
-        return out
+        if rec:
+            m = allm[i0:i0 + len(rec)]
+            i0 += len(rec)
+            mp, pa, pve = m[:, :B], m[:, B:2 * B], m[:, 2 * B]
+            for i, r in enumerate(rec):
+                out['records'].append(dict(step=r['step'], tag=r['tag'], mpjpe=mp[i], pampjpe=pa[i], pve=float(pve[i])))
+                if r['tag'] is not None and r['tag'][0] == 'final':
+                    if out['mpjpe'] and out['records'][-2]['step'] == r['step'] and out['records'][-2]['tag'][0] == 'final':
+                        out['mpjpe'][-1], out['pampjpe'][-1], out['pve'][-1] = mp[i], pa[i], float(pve[i])
+                    else:
+                        out['mpjpe'].append(mp[i]); out['pampjpe'].append(pa[i]); out['pve'].append(float(pve[i]))
+        outs.append(out)
+    return outs
 
 
 if __name__ == '__main__':

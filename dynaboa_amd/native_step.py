@@ -430,4 +430,5 @@ class ReplicaGroup:
         return out
 
     def flush_metrics(self):
-        return [a.flush_metrics() for a in self.adaptors]
+        from .benchmark import flush_metrics_of
+        return flush_metrics_of(self.adaptors)
