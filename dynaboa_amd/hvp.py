@@ -195,26 +195,39 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
         shape, cam = state[:, 144:154], state[:, 154:157]
         return rot, shape, cam, ad.decode_smpl_params(rot, shape)["s3d"]
 
-    def head(states):                                   # states: dict pass name -> (B, 160) tensor
+    rep3 = lambda t: t.repeat((3,) + (1,) * (t.dim() - 1))
+    consts = {}
+
+    def const(name, make):                             # the level's constants, tiled over the three evaluation points once
+        if name not in consts:
+            consts[name] = make()
+        return consts[name]
+
+    def head(states):
+        """states: dict pass name -> (3 B, 160): the pass's state and the two difference points state +- eps * tstate as ONE batch
+        (a third of the launches).  Every term is a mean over the batch, so the value is the mean of the three losses and each
+        point's gradient comes out scaled by 1 / 3."""
         rot, shape, cam, s3d = preds(states["img"])
+        kp3 = const("kp", lambda: rep3(kp2d))
         loss = None
         if use_frame:
-            loss = frame_losses(rot, shape, cam, s3d, kp2d, ad.gmm_f, o.s2dloss_weight, o.shape_prior_weight, o.pose_prior_weight)[0]
+            loss = frame_losses(rot, shape, cam, s3d, kp3, ad.gmm_f, o.s2dloss_weight, o.shape_prior_weight, o.pose_prior_weight)[0]
         # teacher / motion / labelled terms: the value+gradient kernel nodes `_level` uses (losses._AuxTerms)
         if temporal:
             if use_teacher:                             # base_adaptor.py:320-343
-                t_rot, t_shape, t_cam, t_s3d = teacher_t
+                t_rot, t_shape, t_cam, t_s3d = const("teacher", lambda: tuple(rep3(t) for t in teacher_t))
                 t = teacher_term(rot, shape, cam, s3d, t_rot, t_shape, t_cam, t_s3d)[0] * o.teacherloss_weight
                 loss = t if loss is None else loss + t
             if use_motion:                              # base_adaptor.py:379-398
                 h_rot, h_shape, h_cam, h_s3d = preds(states["hist"])
-                loss = loss + motion_term(rot, shape, cam, s3d, h_cam, h_s3d, kp2d, hist[1])[0] * o.motionloss_weight
+                loss = loss + motion_term(rot, shape, cam, s3d, h_cam, h_s3d, kp3, const("hist_kp", lambda: rep3(hist[1])))[0] * o.motionloss_weight
         if use_label:                                   # base_adaptor.py:346-376
             from .geometry import batch_rodrigues
             b = h36m_batch
             e_rot, e_shape, e_cam, e_s3d = preds(states["ex"])
-            gt_rot = batch_rodrigues(b["pose"].view(-1, 3)).view(-1, 24, 3, 3)
-            lab = labelled_term(e_rot, e_shape, e_cam, e_s3d, b["keypoints"], gt_rot, b["betas"], b["pose_3d"])[0]
+            gt_rot, e_kp, e_betas, e_p3 = const("ex", lambda: (rep3(batch_rodrigues(b["pose"].view(-1, 3)).view(-1, 24, 3, 3)),
+                                                               rep3(b["keypoints"]), rep3(b["betas"]), rep3(b["pose_3d"])))
+            lab = labelled_term(e_rot, e_shape, e_cam, e_s3d, e_kp, gt_rot, e_betas, e_p3)[0]
             loss = loss + lab * o.labelloss_weight
         return loss
 
@@ -239,13 +252,12 @@ def general_level_hvp(ad, level, hmr, theta, image, kp2d, h36m_batch, n_iter: in
             sn = torch.sqrt(sum((s[:, :157] ** 2).sum() for s in states.values()))
             tn = torch.sqrt(sum((t ** 2).sum() for t in tst.values()))
             eps = HEAD_FD_REL * sn / tn.clamp_min(1e-30)
-        g0 = head_grad(states)
-        gp = head_grad({k: states[k] + eps * tst[k] for k in states})
-        gm = head_grad({k: states[k] - eps * tst[k] for k in states})
+        g3 = head_grad({k: torch.cat([states[k], states[k] + eps * tst[k], states[k] - eps * tst[k]]) for k in states})
         with torch.no_grad():
             out = None
             for k, p in passes.items():
-                h = p.hv(theta, v, g0[k], (gp[k] - gm[k]) / (2 * eps))
+                g0, gp, gm = (3.0 * g3[k]).chunk(3)
+                h = p.hv(theta, v, g0, (gp - gm) / (2 * eps))
                 out = h if out is None else out + h
         return out
     return hvp
