@@ -383,7 +383,7 @@ int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes, dyb_stream
 int dyb_stepper_adapt_frame(void* stepper, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
                             const long long* gender, int record_slot, int loss_slot, dyb_stream_t stream, dyb_stream_t aux,
                             dyb_stream_t side);
-/* The same step for `replicas` (set_i key, 1..16, before sizing the workspace) independent sequences in lockstep: every
+/* The same step for `replicas` (set_i key, 1..64, before sizing the workspace) independent sequences in lockstep: every
  * launch of the chain covers all replicas (replica = a grid dimension; pointer arguments inside a replica's arenas are
  * rebased in the kernels), each replica with its own weights / Adam moments / workspace / records: theta, adam_m, adam_v are
  * [replicas][param floats], records [replicas][record_capacity][record_floats], loss_log [replicas][loss_capacity]
