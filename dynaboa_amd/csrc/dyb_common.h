@@ -170,6 +170,16 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
 // "tp_batch_min" > 0 (off by default: unmeasured) - a batch of at least that many images
 bool dyb_throughput_mode(int batch = 1);
 int dyb_gn_replica_share(int N);                // > 0: workgroups per image a GroupNorm launch may use (replica-aware chunking)
+// one-pass GroupNorm backward of the throughput schedule (norm_pool.hip): chunks per slab (0: shape does not qualify), the floats
+// of partial sums the k-chunk form needs, the launch, a replica-aware zero fill (arrival counters), the policy switches
+int dyb_gn_onepass_chunks(int N, int HW, int C, int cap);
+size_t dyb_gn_onepass_part_floats(int k, int C);
+int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const float* addend, const float* out, const float* y,
+                       const float* stats, const float* gamma, const float* beta, float* dm, float* dy, float* dgamma, float* dbeta,
+                       int HW, int C, int relu, int k, float* part, unsigned* ctr, hipStream_t st);
+int dyb_zero_words(unsigned* p, int n, hipStream_t st);
+int dyb_tp_gn_onepass();
+int dyb_tp_gn_cap();
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,

@@ -60,6 +60,7 @@ int dyb_scale_add(const float*, const float*, const float*, float*, size_t, hipS
 #define STATE_LD 160     // pose 144 | shape 10 | cam 3 | pad 3
 #define HID 1024
 #define MAX_ITER 3
+#define SYNC_WORDS 8
 
 enum TensorKind { K_CONV_W = 0, K_NORM_W = 1, K_NORM_B = 2, K_FC_W = 3, K_FC_B = 4, K_DEC_W = 5, K_DEC_B = 6 };
 
@@ -116,7 +117,7 @@ struct HmrPlan {
   int poolH, poolW;            // max-pool output
   int featHW;                  // spatial size of the last feature map (7*7)
   // workspace carve (bytes)
-  size_t ws_conv, ws_conv_aux, ws_gn, ws_gnb, ws_lin, ws_grad_each, ws_dy, ws_dy2, ws_reg, ws_total;
+  size_t ws_conv, ws_conv_aux, ws_gn, ws_gnb, ws_lin, ws_grad_each, ws_dy, ws_dy2, ws_reg, ws_sync, ws_total;
   // hipGraph cache: a whole forward / backward call is captured once per distinct set of pointer
   // arguments (the caching allocator reproduces addresses in a steady-state frame loop) and replayed
   // with ONE hipGraphLaunch instead of ~180 / ~330 launches: the eager loop is host-issue-bound.
@@ -259,7 +260,9 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_grad_each = align64(maxact) * 4;
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
-  P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg + P.ws_dy2;
+  // arrival counters of the one-pass GroupNorm backward: SYNC_WORDS per conv layer (4 groups + the error word), zeroed per backward
+  P.ws_sync = align64(P.convs.size() * SYNC_WORDS) * 4;
+  P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg + P.ws_dy2 + P.ws_sync;
   return pp;
 }
 
@@ -418,6 +421,7 @@ struct WsCarve {
   float* dy;
   float* reg;
   float* dy2;
+  unsigned* sync;
 };
 static WsCarve carve(const HmrPlan& P, void* ws) {
   WsCarve c;
@@ -430,7 +434,8 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   for (int i = 0; i < 3; ++i) { c.g[i] = reinterpret_cast<float*>(b); b += P.ws_grad_each; }
   c.dy = reinterpret_cast<float*>(b); b += P.ws_dy;
   c.reg = reinterpret_cast<float*>(b); b += P.ws_reg;
-  c.dy2 = reinterpret_cast<float*>(b);
+  c.dy2 = reinterpret_cast<float*>(b); b += P.ws_dy2;
+  c.sync = reinterpret_cast<unsigned*>(b);
   return c;
 }
 
@@ -658,17 +663,36 @@ static int run_wgrad(HmrPlan& P, const WgradJob& j, const float* params, const f
 // one per layer: each edge costs ~9 us of host time).  Without an auxiliary stream they run in line.
 static int layer_gn_bwd(HmrPlan& P, int ci, const float* params, const float* acts, float* grads, const float* conv_in,
                         const ConvL* in_prev, const Pending& din, int relu, const float** dm_out, const WsCarve& w,
-                        hipStream_t st, std::vector<WgradJob>* jobs, hipEvent_t done) {
+                        hipStream_t st, std::vector<WgradJob>* jobs, hipEvent_t done, bool dm_read_later = true) {
   const ConvL& c = P.convs[ci];
   const bool alias = !relu && din.nslabs == 1 && !din.addend;
   float* dm = alias ? const_cast<float*>(din.base) : w.dy + c.dy;
   float* part = w.gnb + c.gnb;
   // ReLU mask: the saved activation where it exists, else recomputed from y (bn1 / bn2)
   const bool tp = dyb_throughput_mode(P.B);
+  WgradJob j{ci, conv_in, in_prev, dm, 0, 0, nullptr};
+  // throughput schedule, one image per replica: the one-pass backward (every tensor read / written once: norm_pool.hip)
+  int kop = 0;
+  if (tp && dyb_tp_gn_onepass() > 0) {
+    kop = dyb_gn_onepass_chunks(P.B, c.Ho * c.Wo, c.K, dyb_tp_gn_cap());
+    if (kop > 1 && (dyb_tp_gn_onepass() < 2 || dyb_gn_onepass_part_floats(kop, c.K) > dyb_groupnorm_bwd_partial_floats(P.B, c.Ho * c.Wo, c.K)))
+      kop = 0;
+  }
+  if (kop > 0) {
+    float* dyl = w.dy2 + c.dy;
+    RUN(dyb_gn_bwd_onepass(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y, acts + c.stats,
+                           params + c.gam, params + c.bet, (alias || !dm_read_later) ? nullptr : dm, dyl, grads + c.gam, grads + c.bet,
+                           c.Ho * c.Wo, c.K, relu, kop, part, w.sync + (size_t)ci * SYNC_WORDS, st));
+    if (done && hipEventRecord(done, st) != hipSuccess) return DYB_ERR_LAUNCH;
+    j.dy = dyl;
+    if (jobs) jobs->push_back(j);
+    else RUN(run_wgrad(P, j, params, acts, grads, w, w.conv, st));
+    *dm_out = dm;
+    return DYB_OK;
+  }
   RUN(dyb_gn_bwd_reduce_slabs(din.base, din.nslabs, din.stride, din.addend, c.has_out ? acts + c.out : nullptr, acts + c.y,
                               acts + c.stats, params + c.gam, params + c.bet, dm, part, P.B, c.Ho * c.Wo, c.K, relu, st,
                               tp ? nullptr : done));
-  WgradJob j{ci, conv_in, in_prev, dm, 0, 0, nullptr};
   if (tp) {
     // throughput schedule: dy once per layer (also dgamma / dbeta), plain gradient convolutions afterwards
     float* dyl = w.dy2 + c.dy;
@@ -850,6 +874,8 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   // branch, Rb holds the shortcut branch's data gradient; the residual-edge gradient of a block is the
   // dm of its third GroupNorm (the ReLU-masked incoming gradient), used in place.
   float *D0 = w.g[0], *D1 = w.g[1], *Rb = w.g[2];
+  if (dyb_throughput_mode(P.B) && dyb_tp_gn_onepass() > 1 && P.B == 1)      // arrival counters of the one-pass GroupNorm backward
+    RUN(dyb_zero_words(w.sync, (int)(P.convs.size() * SYNC_WORDS), st));
   RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, D0, B, P.featHW, FEAT, st));
   Pending cur = plain(D0);
   float* free_buf = D1;          // the D buffer `cur` does not occupy (a pending `cur` lives in the slab region)
@@ -884,19 +910,19 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
       RUN(push_wgrad(b.c2, nullptr, &c1, dm2));
     } else {
       RUN(layer_dgrad(P, b.c3, params, acts, dm3, free_buf, nullptr, &p3, w, st, bs));
-      RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, jobs, nullptr));
+      RUN(layer_gn_bwd(P, b.c2, params, acts, grads, nullptr, &c1, p3, 1, &dm2, w, st, jobs, nullptr, false));
     }
     RUN(layer_dgrad(P, b.c2, params, acts, dm2, other, nullptr, &p2, w, st, bs));      // `cur` was consumed by the c3 reduce
     const float* edge = dm3;           // residual-edge gradient of this block
     if (b.cd >= 0) {
-      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, nullptr));
+      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, nullptr, false));
       // shortcut branch: GroupNorm without ReLU on the residual-edge gradient; its data gradient is materialised
-      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, jobs, ev));
+      RUN(layer_gn_bwd(P, b.cd, params, acts, grads, xin, nullptr, plain(dm3), 0, &dmd, w, st, jobs, ev, false));
       if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
       RUN(layer_dgrad(P, b.cd, params, acts, dmd, Rb, nullptr, nullptr, w, st, bs));
       edge = Rb;
     } else {
-      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, ev));
+      RUN(layer_gn_bwd(P, b.c1, params, acts, grads, xin, nullptr, p2, 1, &dm1, w, st, jobs, ev, false));
       if (aux) RUN(flush_wgrads(P, jobs_store, ev, params, acts, grads, w, aux));
     }
     k4 = false;
@@ -922,7 +948,7 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   RUN(dyb_maxpool3x3s2_bwd(gpool, reinterpret_cast<const uint32_t*>(acts + P.a_poolidx), spare, B, stem.Ho, stem.Wo, stem.K, st));
   const float* dm0;
   RUN(layer_gn_bwd(P, 0, params, acts, grads, acts + P.a_x4, nullptr, plain(spare), 1, &dm0, w, st, jobs,
-                   aux ? E.dy[0] : nullptr));
+                   aux ? E.dy[0] : nullptr, false));
   if (aux) RUN(flush_wgrads(P, jobs_store, E.dy[0], params, acts, grads, w, aux));
   if (aux) {
     if (hipEventRecord(E.join, aux) != hipSuccess) return DYB_ERR_LAUNCH;

@@ -1116,7 +1116,8 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // +13.5 % at batch 16 in BENCH_r02, and the schedule the bf16 form of igemm_tp_kernel needs), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
-  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ;
+  std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
+      tp_gn_cap;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1132,6 +1133,8 @@ struct DybSwitches {
     tp_batch_min = env("DYB_TP_BATCH_MIN", 16);
     tp_gn_wgs = env("DYB_TP_GN_WGS", 1024);
     tp_occ = env("DYB_TP_OCC", 0);
+    tp_gn_onepass = env("DYB_TP_GN_ONEPASS", 2);
+    tp_gn_cap = env("DYB_TP_GN_CAP", 0);
   }
 };
 static DybSwitches& switches() {
@@ -1156,6 +1159,8 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_batch_min")) return &s.tp_batch_min;
   if (!strcmp(name, "tp_gn_wgs")) return &s.tp_gn_wgs;
   if (!strcmp(name, "tp_occ")) return &s.tp_occ;
+  if (!strcmp(name, "tp_gn_onepass")) return &s.tp_gn_onepass;
+  if (!strcmp(name, "tp_gn_cap")) return &s.tp_gn_cap;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1725,6 +1730,11 @@ int dyb_gn_replica_share(int N) {
   int w = switches().tp_gn_wgs.load(std::memory_order_relaxed) / (reps * (N > 0 ? N : 1));
   return w < 1 ? 1 : w;
 }
+// throughput schedule, GroupNorm backward: "tp_gn_onepass" 2 (default) = the one-pass kernel for every layer that qualifies (slabs
+// of several row chunks meet on a counter), 1 = only layers whose (image, group) slab is one workgroup, 0 = the two-launch
+// reduce + apply; "tp_gn_cap" = float4 per workgroup (0: 8192; tests force several chunks on small shapes)
+int dyb_tp_gn_onepass() { return switches().tp_gn_onepass.load(std::memory_order_relaxed); }
+int dyb_tp_gn_cap() { return switches().tp_gn_cap.load(std::memory_order_relaxed); }
 bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
   if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;

@@ -611,6 +611,279 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+// ---- one-pass backward (throughput schedule, one image per sequence replica) ------------------------------------------------
+// The two-launch backward streams every tensor of a layer twice: the reduce reads the incoming gradient, y and the ReLU mask
+// source and writes the masked gradient dm; the apply reads dm and y again and writes dy - 6 to 7 tensor passes per layer, the
+// second-largest kernel family of a frame step at 32 sequences (profiles/r03_final_kernel_stats_S32.csv).  Here a workgroup of
+// 1024 work-items keeps its share of an (image, group) slab IN REGISTERS between the two phases (8 x 16 bytes of masked gradient
+// and of xhat per work-item), so the layer costs one read of each input and one write of each output: 3 passes for the layers
+// inside a bottleneck (gradient, y -> dy), 5 for a block output (gradient, y, activation -> dm, dy).
+//   grid (k, G, replicas): workgroup (c, g, r) owns rows [c * rows, (c + 1) * rows) of replica r's slab of group g;
+//   k = 1  (slab <= 8192 float4: every 14x14 and 7x7 layer, 28x28 up to 256 channels, 56x56 x 64): sums, coefficients, dy,
+//          dgamma / dbeta - everything in the one workgroup;
+//   k > 1  (up to 7: the stem and the 56x56 / 28x28 block outputs): the k workgroups of a slab - CONSECUTIVE linear ids, so
+//          they are dispatched together - leave their per-channel and per-group sums in `part`, arrive on the slab's counter and
+//          poll it (one lane, s_sleep between polls) until all k have; every workgroup then adds the k group sums in chunk
+//          order (identical coefficients everywhere), chunk 0 also folds dgamma / dbeta.  A workgroup only ever waits for
+//          workgroups with nearby ids of its own launch: in-order dispatch makes that wait finite whatever else shares the
+//          chip.  A poll that lasts longer than ~0.2 s raises the error word and goes on (results of that launch are then
+//          wrong, the queue is not blocked).
+// Deterministic (fixed summation orders); agrees with the two-launch form to fp32 rounding (different orders).
+#define OP_T 1024
+#define OP_IT 8
+struct GnOnepass {
+  const float* din;        // incoming gradient (first split-K slab)
+  const float* addend;     // + residual-edge gradient, or NULL
+  const float* out;        // saved activation (ReLU mask) or NULL: the mask is recomputed from y
+  const float* y;
+  const float* stats;      // [G][2] mean, rstd
+  const float* gamma;
+  const float* beta;
+  float* dm;               // masked gradient out, or NULL
+  float* dy;
+  float* dgamma;
+  float* dbeta;
+  float* part;             // k > 1: [k][2][C] per-channel sums, then [k][G][2] group sums
+  unsigned* ctr;           // k > 1: [G] arrival counters (zero before the launch) + [1] error word
+  size_t slab_stride;
+  int nslabs, HW, C, rows, relu;
+};
+__global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, a.din); DYB_RB(R, a.addend); DYB_RB(R, a.out); DYB_RB(R, a.y); DYB_RB(R, a.stats); DYB_RB(R, a.gamma); DYB_RB(R, a.beta);
+  DYB_RB(R, a.dm); DYB_RB(R, a.dy); DYB_RB(R, a.dgamma); DYB_RB(R, a.dbeta); DYB_RB(R, a.part); DYB_RB(R, a.ctr);
+  __shared__ float sm[16][64][8];
+  __shared__ float s_grp[2][2];
+  __shared__ float s_c[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x, k = gridDim.x, g = blockIdx.y;
+  const int C = a.C, cqg = C >> 4;                        // float4 columns of a group: 4 .. 128, a power of two (host-checked)
+  const int row0 = chunk * a.rows;
+  const int row1 = row0 + a.rows < a.HW ? row0 + a.rows : a.HW;
+  const int q = tid & (cqg - 1);                           // this work-item's column inside the group (OP_T % cqg == 0)
+  const int c0 = (g * cqg + q) * 4;                        // its first channel
+  const int rstep = OP_T / cqg;                            // rows between its consecutive items
+  const int rfirst = row0 + tid / cqg;
+  const float mean = a.stats[g * 2], rstd = a.stats[g * 2 + 1];
+  const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c0);
+  const bool mask_y = a.relu && a.out == nullptr;
+  const float4 be = mask_y ? *reinterpret_cast<const float4*>(a.beta + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 d[OP_IT], xh[OP_IT];
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  // phase 1, four items at a time: every load of the four (gradient, y, mask source, addend) is in flight before the first use
+#pragma unroll
+  for (int h = 0; h < OP_IT; h += 4) {
+    size_t off[4];
+    bool ok[4];
+    float4 dv[4], yv[4], ov[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rfirst + (h + j) * rstep;
+      ok[j] = row < row1;
+      off[j] = (size_t)(ok[j] ? row : row0) * C + c0;      // (a missing item re-reads the chunk's first row and is dropped)
+      dv[j] = *reinterpret_cast<const float4*>(a.din + off[j]);
+      yv[j] = *reinterpret_cast<const float4*>(a.y + off[j]);
+      ov[j] = (a.relu && a.out) ? *reinterpret_cast<const float4*>(a.out + off[j]) : zero4;
+    }
+    if (a.addend) {
+      float4 p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const float4*>(a.addend + off[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dv[j].x += p[j].x; dv[j].y += p[j].y; dv[j].z += p[j].z; dv[j].w += p[j].w; }
+    }
+    for (int z = 1; z < a.nslabs; ++z) {                   // un-folded split-K slabs of the data gradient that produced din
+      float4 p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const float4*>(a.din + (size_t)z * a.slab_stride + off[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dv[j].x += p[j].x; dv[j].y += p[j].y; dv[j].z += p[j].z; dv[j].w += p[j].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 x;
+      x.x = (yv[j].x - mean) * rstd; x.y = (yv[j].y - mean) * rstd; x.z = (yv[j].z - mean) * rstd; x.w = (yv[j].w - mean) * rstd;
+      float4 o = ov[j];
+      if (mask_y) {                                          // exactly the consumer's expression (igemm_conv.hip gnf_apply)
+        o.x = fmaf(x.x, ga.x, be.x); o.y = fmaf(x.y, ga.y, be.y); o.z = fmaf(x.z, ga.z, be.z); o.w = fmaf(x.w, ga.w, be.w);
+      }
+      float4 v = dv[j];
+      if (a.relu) {
+        v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+      }
+      if (!ok[j]) { v = zero4; x = zero4; }
+      d[h + j] = v;
+      xh[h + j] = x;
+      sa[0] += v.x; sa[1] += v.y; sa[2] += v.z; sa[3] += v.w;
+      sb[0] += v.x * x.x; sb[1] += v.y * x.y; sb[2] += v.z * x.z; sb[3] += v.w * x.w;
+    }
+  }
+  // per-channel sums of the chunk: lanes of a wave that share a column first (cqg < 64), then the 16 waves through LDS
+  for (int m = 32; m >= cqg; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sa[i] += __shfl_xor(sa[i], m); sb[i] += __shfl_xor(sb[i], m); }
+  }
+  const int W = cqg < 64 ? cqg : 64;                       // distinct columns per wave
+  if (lane < W) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sm[wave][lane][i] = sa[i]; sm[wave][lane][4 + i] = sb[i]; }
+  }
+  __syncthreads();
+  float A[4] = {0.f, 0.f, 0.f, 0.f}, Bv[4] = {0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  if (tid < cqg) {
+    // column tid lives in lane (tid % 64) of the waves w with (w * 64) % cqg == tid - tid % 64
+    const int l = tid & 63, wbase = tid >> 6, wstep = cqg > 64 ? cqg >> 6 : 1;
+    for (int w = wbase; w < 16; w += wstep) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { A[i] += sm[w][l][i]; Bv[i] += sm[w][l][4 + i]; }
+    }
+    s1 = (ga.x * A[0] + ga.y * A[1]) + (ga.z * A[2] + ga.w * A[3]);      // (tid < cqg: this work-item's own column is column tid)
+    s2 = (ga.x * Bv[0] + ga.y * Bv[1]) + (ga.z * Bv[2] + ga.w * Bv[3]);
+    const int cc = (g * cqg + tid) * 4;
+    if (k == 1) {
+      *reinterpret_cast<float4*>(a.dbeta + cc) = make_float4(A[0], A[1], A[2], A[3]);
+      *reinterpret_cast<float4*>(a.dgamma + cc) = make_float4(Bv[0], Bv[1], Bv[2], Bv[3]);
+    } else {
+      float* p = a.part + (size_t)chunk * 2 * C + cc;
+      *reinterpret_cast<float4*>(p) = make_float4(A[0], A[1], A[2], A[3]);
+      *reinterpret_cast<float4*>(p + C) = make_float4(Bv[0], Bv[1], Bv[2], Bv[3]);
+    }
+  }
+  // group sums of gamma * A, gamma * B: whole-wave butterflies (work-items without a column hold zeros), waves 0 and 1 carry the columns
+  for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+  if (lane == 0 && wave < 2) { s_grp[wave][0] = s1; s_grp[wave][1] = s2; }
+  __syncthreads();
+  const float inv_m = 1.0f / ((float)(C / G) * (float)a.HW);
+  if (k == 1) {
+    if (tid == 0) {
+      const float s1 = cqg > 64 ? s_grp[0][0] + s_grp[1][0] : s_grp[0][0];
+      const float s2 = cqg > 64 ? s_grp[0][1] + s_grp[1][1] : s_grp[0][1];
+      s_c[0] = s1 * inv_m;
+      s_c[1] = s2 * inv_m;
+    }
+  } else {
+    float* gpart = a.part + (size_t)k * 2 * C;             // [k][G][2]
+    if (tid == 0) {
+      gpart[(chunk * G + g) * 2 + 0] = cqg > 64 ? s_grp[0][0] + s_grp[1][0] : s_grp[0][0];
+      gpart[(chunk * G + g) * 2 + 1] = cqg > 64 ? s_grp[0][1] + s_grp[1][1] : s_grp[0][1];
+    }
+    // publish (every writer's stores reach device scope), arrive, wait for the slab's other chunks
+    if (tid < cqg || tid == 0) __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(a.ctr + g, 1u);
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
+          atomicAdd(a.ctr + G, 1u);
+          break;
+        }
+      }
+      __threadfence();
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = 0; c < k; ++c) { s1 += gpart[(c * G + g) * 2]; s2 += gpart[(c * G + g) * 2 + 1]; }
+      s_c[0] = s1 * inv_m;
+      s_c[1] = s2 * inv_m;
+    }
+  }
+  __syncthreads();
+  const float c1 = s_c[0], c2 = s_c[1];
+  // phase 2: dy (and dm) from the registers
+#pragma unroll
+  for (int j = 0; j < OP_IT; ++j) {
+    const int row = rfirst + j * rstep;
+    if (row < row1) {
+      const size_t off = (size_t)row * C + c0;
+      float4 r;
+      r.x = rstd * (ga.x * d[j].x - c1 - xh[j].x * c2);
+      r.y = rstd * (ga.y * d[j].y - c1 - xh[j].y * c2);
+      r.z = rstd * (ga.z * d[j].z - c1 - xh[j].z * c2);
+      r.w = rstd * (ga.w * d[j].w - c1 - xh[j].w * c2);
+      *reinterpret_cast<float4*>(a.dy + off) = r;
+      if (a.dm) *reinterpret_cast<float4*>(a.dm + off) = d[j];
+    }
+  }
+  if (k > 1 && chunk == 0 && tid < cqg) {
+    // dgamma / dbeta of this group's channels: the k chunks' per-channel sums in chunk order
+    __threadfence();
+    const int cc = (g * cqg + tid) * 4;
+    float4 sA = zero4, sB = zero4;
+    for (int c = 0; c < k; ++c) {
+      const float* p = a.part + (size_t)c * 2 * C + cc;
+      const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + C);
+      sA.x += u.x; sA.y += u.y; sA.z += u.z; sA.w += u.w;
+      sB.x += v.x; sB.y += v.y; sB.z += v.z; sB.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.dbeta + cc) = sA;
+    *reinterpret_cast<float4*>(a.dgamma + cc) = sB;
+  }
+}
+// zero fill of a small per-replica region (the arrival counters): replica-aware, unlike a memset node
+__global__ void zero_words_kernel(unsigned* p, int n, DybRep R) {
+  DYB_REP_PROLOGUE(R);
+  DYB_RB(R, p);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+int dyb_zero_words(unsigned* p, int n, hipStream_t st) {
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1, 1, R.n), dim3(256), 0, st, p, n, R);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// chunks per (image, group) slab of the one-pass backward, 0 = the shape does not qualify (`cap` float4 per workgroup: OP_T *
+// OP_IT, or less - the tests force several chunks on small shapes that way)
+int dyb_gn_onepass_chunks(int N, int HW, int C, int cap) {
+  if (N != 1 || C % 16 != 0 || C < 64 || C > 2048 || !dyb_is_pow2(C)) return 0;
+  if (cap <= 0 || cap > OP_T * OP_IT) cap = OP_T * OP_IT;
+  const int cqg = C / 16;
+  int k = 1;
+  while (k <= 8 && dyb_cdiv(HW, k) * cqg > cap) ++k;
+  if (k > 8) return 0;
+  return dyb_cdiv(HW, dyb_cdiv(HW, k));
+}
+// floats of `part` the k-chunk form needs (k > 1)
+size_t dyb_gn_onepass_part_floats(int k, int C) { return k > 1 ? (size_t)k * 2 * C + (size_t)k * G * 2 : 0; }
+int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const float* addend, const float* out, const float* y,
+                       const float* stats, const float* gamma, const float* beta, float* dm, float* dy, float* dgamma, float* dbeta,
+                       int HW, int C, int relu, int k, float* part, unsigned* ctr, hipStream_t st) {
+  DYB_REQUIRE(din && y && stats && gamma && dy && dgamma && dbeta && nslabs >= 1 && k >= 1, DYB_ERR_ARG);
+  DYB_REQUIRE(!relu || out || beta, DYB_ERR_ARG);
+  DYB_REQUIRE(k == 1 || (part && ctr), DYB_ERR_ARG);
+  const int rows = dyb_cdiv(HW, k);
+  DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= OP_T * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
+  GnOnepass a{din, addend, out, y, stats, gamma, beta, dm == din ? nullptr : dm, dy, dgamma, dbeta, part, ctr, slab_stride, nslabs, HW, C,
+              rows, relu};
+  const DybRep& R = dyb_rep_current();
+  hipLaunchKernelGGL(gn_bwd_onepass_kernel, dim3(k, G, R.n), dim3(OP_T), 0, st, a, R);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// Stand-alone form (tests, direct callers): one image, ws >= dyb_groupnorm_bwd_onepass_workspace_bytes; cap = float4 per
+// workgroup (0: the kernel's 8192).  The arrival counters inside ws are zeroed here, on `st`.
+extern "C" size_t dyb_groupnorm_bwd_onepass_workspace_bytes(int HW, int C) {
+  return ((size_t)8 * 2 * C + 8 * G * 2 + 64) * sizeof(float);
+}
+extern "C" int dyb_groupnorm_bwd_onepass(const float* dout_slabs, int nslabs, size_t slab_stride, const float* addend, const float* out,
+                                         const float* y, const float* stats, const float* gamma, const float* beta, float* dm, float* dy,
+                                         float* dgamma, float* dbeta, int HW, int C, int relu, int cap, void* ws, size_t ws_bytes,
+                                         hipStream_t st) {
+  const int k = dyb_gn_onepass_chunks(1, HW, C, cap);
+  DYB_REQUIRE(k > 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(ws && ws_bytes >= dyb_groupnorm_bwd_onepass_workspace_bytes(HW, C), DYB_ERR_WORKSPACE);
+  float* part = reinterpret_cast<float*>(ws);
+  unsigned* ctr = reinterpret_cast<unsigned*>(part + (size_t)8 * 2 * C + 8 * G * 2);
+  if (k > 1) {
+    int rc = dyb_zero_words(ctr, G + 1, st);
+    if (rc != DYB_OK) return rc;
+  }
+  return dyb_gn_bwd_onepass(dout_slabs, nslabs, slab_stride, addend, out, y, stats, gamma, beta, dm, dy, dgamma, dbeta, HW, C, relu, k, part,
+                            ctr, st);
+}
+
 // ---- reduce-only form for consumers that form dy in their operand loaders (igemm_conv.hip) ----------
 void dyb_gn_bwd_layout(int N, int HW, int C, int* nch, int* ncolb) {
   *nch = gn_chunks_bwd(HW, N, C);

@@ -3,7 +3,8 @@
 // yield at __syncthreads() / cross-lane operations, which gives exactly the barrier semantics the
 // kernels rely on.  The workgroups of a grid are spread over a few OS threads (DYB_EMU_THREADS, default = the CPU
 // count, max 16): every piece of executor state, the built-in index variables and the kernels' __shared__ arrays are
-// thread_local, and no kernel here communicates between workgroups.  x86-64 SysV only.
+// thread_local.  Workgroups are claimed in id order, so the few kernels whose workgroups meet on a counter (groups of <= 8
+// consecutive ids; the pool has at least 8 threads) make progress as they do on the device.  x86-64 SysV only.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
@@ -18,6 +19,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+void emu_os_yield() { std::this_thread::yield(); }
 
 namespace emu {
 thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
@@ -300,7 +303,7 @@ static int pool_size() {
   static int n = [] {
     const char* e = getenv("DYB_EMU_THREADS");
     long v = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-    if (v < 1) v = 1;
+    if (v < 8) v = 8;                  // kernels that meet on a counter need every workgroup of a meeting claimed (<= 8 of consecutive ids)
     if (v > 16) v = 16;
     return (int)v;
   }();

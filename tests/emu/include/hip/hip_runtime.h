@@ -96,6 +96,18 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
   return v;
 }
 static inline void __threadfence_system() {}
+// Inter-workgroup hand-offs (the one-pass GroupNorm backward: a few workgroups of consecutive ids meet on a counter).  The
+// emulator claims workgroups in id order on a pool of OS threads (emu_runtime.cpp: at least 8), so a workgroup that polls for
+// peers with nearby ids makes progress as on the device; s_sleep yields the OS thread.
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+// (__hip_atomic_load is a clang builtin in host mode as well)
+void emu_os_yield();
+static inline void __builtin_amdgcn_s_sleep(int) { emu_os_yield(); }
+static inline long long wall_clock64() { return 0; }
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

@@ -500,6 +500,56 @@ def case_hmr_engine(be, golden, ckpt, check_grads=True):
     return e
 
 
+def case_hmr_engine_schedules(be, ckpt, options, seed=22):
+    """One image through the engine (forward + backward) under the default latency schedule and again with `options`
+    (dyb_set_option name -> value; restored afterwards) - e.g. the throughput schedule with the one-pass GroupNorm backward, which
+    only exists at one image per sequence: every parameter gradient of the second run against the first (itself pinned to the
+    reference module's golden g3 at batch 2 by case_hmr_engine)."""
+    from dynaboa_amd import assets
+    from dynaboa_amd.hmr_layout import HmrLayout
+    import ctypes
+    B = 1
+    L = HmrLayout(be.lib, B)
+    params = be.dev(L.pack(ckpt).numpy())
+    img = assets.make_frame(0, batch_size=B, seed=seed)["image"].numpy()
+    init = np.repeat(HmrLayout.init_state(ckpt).numpy(), B, 0)
+    rng = _rng(seed)
+    d_rot = (rng.standard_normal((B, 24, 3, 3)) * 1e-2).astype(np.float32)
+    d_state = np.zeros((B, 160), np.float32)
+    d_state[:, 144:157] = (rng.standard_normal((B, 13)) * 1e-2).astype(np.float32)
+
+    def run():
+        acts = be.empty((L.act_floats,))
+        ws = be.empty((L.ws_bytes // 4,))
+        check(be.lib.dyb_hmr_forward(L.plan, be.ptr(params), be.ptr(be.dev(img)), be.ptr(be.dev(init)), 3, be.ptr(acts),
+                                     be.ptr(ws), L.ws_bytes, be.stream), "hmr forward")
+        grads = be.zeros((L.n_params,))
+        check(be.lib.dyb_hmr_backward(L.plan, be.ptr(params), be.ptr(acts), be.ptr(be.dev(d_rot)), be.ptr(be.dev(d_state)), 3,
+                                      be.ptr(grads), be.ptr(ws), L.ws_bytes, be.stream, be.aux_stream()), "hmr backward")
+        return L.unpack(torch.from_numpy(be.host(grads)))
+    ref = run()
+    saved = {}
+    for k, v in options.items():
+        cur = ctypes.c_int()
+        be.lib.dyb_get_option(k.encode(), ctypes.byref(cur))
+        saved[k] = cur.value
+        assert be.lib.dyb_set_option(k.encode(), v) == 0, k
+    try:
+        got = run()
+    finally:
+        for k, v in saved.items():
+            be.lib.dyb_set_option(k.encode(), v)
+    from conftest import cosine
+    worst, wcos = 0.0, 1.0
+    for n in ref:
+        a, b = got[n].double(), ref[n].double()
+        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
+        wcos = min(wcos, cosine(a.flatten()[:4096].numpy(), b.flatten()[:4096].numpy()))
+    # (the two schedules sum in different orders; activations within rounding of zero may flip their ReLU mask - see case_hmr_engine)
+    assert worst < 5e-3 and wcos > 0.9999, (worst, wcos)
+    return dict(worst_rel=worst, worst_cos=wcos)
+
+
 def case_groupnorm_fold(be, N, HW, C, nslabs, with_addend, seed=11):
     """dyb_groupnorm_bwd_fold == dyb_groupnorm_bwd on the pre-folded gradient."""
     rng = _rng(seed)
@@ -532,6 +582,49 @@ def case_groupnorm_fold(be, N, HW, C, nslabs, with_addend, seed=11):
     for name, a, b in zip(("dy", "dres", "dgamma", "dbeta"), res["fold"], res["ref"]):
         e[name] = rel_err(a, b)
     assert max(e.values()) < 1e-5, e
+    return e
+
+
+def case_groupnorm_onepass(be, HW, C, relu, mask_from_y, nslabs, with_addend, cap=0, seed=13):
+    """dyb_groupnorm_bwd_onepass (one image; the throughput schedule's GroupNorm backward) against torch autograd of
+    relu?(group_norm(y)): dy, dgamma, dbeta and the masked gradient dm.  mask_from_y: the activation was never saved (layers
+    inside a bottleneck), the ReLU mask is recomputed from y; cap: float4 per workgroup (small values force several row chunks
+    per (image, group) slab, whose workgroups meet on a counter)."""
+    rng = _rng(seed)
+    y = (rng.standard_normal((1, HW, C)) * 1.4 + 0.2).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    slabs = rng.standard_normal((nslabs, 1, HW, C)).astype(np.float32)
+    addend = rng.standard_normal((1, HW, C)).astype(np.float32) if with_addend else None
+    dout = slabs.sum(0) + (addend if with_addend else 0)
+    yt = torch.from_numpy(y).permute(0, 2, 1).reshape(1, C, HW, 1).contiguous().requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    o = F.group_norm(yt, 4, gt, bt, 1e-5)
+    pre = o
+    if relu:
+        o = F.relu(o)
+    gy, gg, gb = torch.autograd.grad(o, [yt, gt, bt], torch.from_numpy(dout).permute(0, 2, 1).reshape(1, C, HW, 1))
+    dy_ref = gy.reshape(1, C, HW).permute(0, 2, 1).numpy()
+    act = o.detach().reshape(1, C, HW).permute(0, 2, 1).numpy()
+    dm_ref = dout * (pre.detach().reshape(1, C, HW).permute(0, 2, 1).numpy() > 0) if relu else dout
+    # statistics exactly as the forward saves them
+    wsb = be.lib.dyb_groupnorm_workspace_bytes(1, HW, C)
+    ws = be.empty((max(wsb, 16) // 4,))
+    Y, OUT, ST = be.dev(y), be.empty((1, HW, C)), be.empty((1, 4, 2))
+    G_, B_ = be.dev(gamma), be.dev(beta)
+    check(be.lib.dyb_groupnorm_fwd(None, 1, be.ptr(Y), be.ptr(G_), be.ptr(B_), None, be.ptr(OUT), be.ptr(ST), 1, HW, C, relu,
+                                   be.ptr(ws), wsb, be.stream), "gn fwd")
+    assert rel_err(be.host(OUT), act) < 5e-4
+    wsb2 = be.lib.dyb_groupnorm_bwd_onepass_workspace_bytes(HW, C)
+    ws2 = be.empty((wsb2 // 4,))
+    DM, DY, DG, DB = be.empty((1, HW, C)), be.empty((1, HW, C)), be.empty((C,)), be.empty((C,))
+    check(be.lib.dyb_groupnorm_bwd_onepass(be.ptr(be.dev(slabs)), nslabs, HW * C, be.ptr(be.dev(addend)) if with_addend else None,
+                                           None if (mask_from_y or not relu) else be.ptr(OUT), be.ptr(Y), be.ptr(ST), be.ptr(G_), be.ptr(B_),
+                                           be.ptr(DM), be.ptr(DY), be.ptr(DG), be.ptr(DB), HW, C, relu, cap, be.ptr(ws2), wsb2, be.stream),
+          "gn bwd onepass")
+    e = dict(dy=rel_err(be.host(DY), dy_ref), dm=rel_err(be.host(DM), dm_ref), dgamma=rel_err(be.host(DG), gg.numpy()),
+             dbeta=rel_err(be.host(DB), gb.numpy()))
+    assert max(e.values()) < 5e-4, e
     return e
 
 

@@ -112,6 +112,19 @@ def test_groupnorm(be, cfg):
     K.case_groupnorm(be, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [
+    # HW, C, relu, mask_from_y, nslabs, with_addend, cap
+    (49, 64, 1, False, 1, False, 0),        # 7x7, one chunk, mask from the saved activation
+    (49, 2048, 1, True, 1, False, 0),       # widest layer (128 float4 columns per group: two waves carry the columns), mask from y
+    (36, 128, 0, False, 1, False, 0),       # no ReLU (the shortcut branch's GroupNorm)
+    (50, 64, 1, True, 3, True, 0),          # split-K slabs + residual-edge addend folded on the way in
+    (60, 64, 1, False, 2, True, 64),        # 4 row chunks per slab meet on the counter (cap 64 float4 per workgroup)
+    (45, 256, 1, True, 1, False, 128),      # 6 chunks, ragged last chunk
+])
+def test_groupnorm_onepass(be, cfg):
+    K.case_groupnorm_onepass(be, *cfg, seed=sum(cfg[:2]))
+
+
 def test_groupnorm_fold(be):
     K.case_groupnorm_fold(be, 1, 49, 64, 5, True)
     K.case_groupnorm_fold(be, 2, 20, 512, 2, False)
@@ -260,16 +273,29 @@ def test_optim(be):
 
 
 @pytest.mark.slow
-def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand):
+@pytest.mark.parametrize("onepass", [2, 0], ids=["gn_onepass", "gn_two_launch"])
+def test_hmr_engine_throughput_schedule_vs_reference_module(be, ckpt_rand, onepass):
     """The throughput schedule (materialised dy, plain gradient convolutions; used by launches covering >= 8 sequence
-    replicas) forced on for a plain call: the whole engine against the reference module's golden g3."""
+    replicas) forced on for a plain call: the whole engine against the reference module's golden g3 - with the one-pass
+    GroupNorm backward (default; the stem's and layer1's slabs are 7 row chunks meeting on a counter) and with the
+    two-launch reduce + apply."""
     be.lib.dyb_set_option(b"rep_split", 1)
     be.lib.dyb_set_option(b"tp_min", 1)
+    be.lib.dyb_set_option(b"tp_gn_onepass", onepass)
     try:
         K.case_hmr_engine(be, golden, ckpt_rand)
     finally:
         be.lib.dyb_set_option(b"rep_split", 0)
         be.lib.dyb_set_option(b"tp_min", 8)
+        be.lib.dyb_set_option(b"tp_gn_onepass", 2)
+
+
+@pytest.mark.slow
+def test_hmr_engine_one_image_throughput_schedule_with_onepass_groupnorm_backward(be, ckpt_rand):
+    """One image per launch replica is where the one-pass GroupNorm backward runs (the benchmarked configuration): the engine's
+    gradients under the throughput schedule against its own latency schedule; the stem and layer1 slabs are cut into 7 row
+    chunks whose workgroups meet on a counter."""
+    print(K.case_hmr_engine_schedules(be, ckpt_rand, {"rep_split": 1, "tp_min": 1, "tp_gn_onepass": 2}))
 
 
 @pytest.mark.slow

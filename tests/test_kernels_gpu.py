@@ -93,6 +93,21 @@ def test_groupnorm(be, cfg):
     K.case_groupnorm(be, *cfg)
 
 
+# every GroupNorm of the backbone at one image: (HW, C, relu, mask_from_y, nslabs, with_addend, cap) - block outputs mask from
+# the saved activation, layers inside a bottleneck from y, the shortcut branch has no ReLU; slabs / addend as the backward
+# chain hands them over; cap 0 = 8192 float4 per workgroup (stem / 56x56x256: 7 chunks, 28x28x512: 4, 56x56x128: 4, ...)
+GN_ONEPASS = [(12544, 64, 1, False, 1, False, 0), (3136, 64, 1, True, 4, False, 0), (3136, 256, 1, False, 2, True, 0),
+              (3136, 256, 0, False, 1, False, 0), (3136, 128, 1, True, 1, False, 0), (784, 128, 1, True, 2, False, 0),
+              (784, 512, 1, False, 1, True, 0), (784, 256, 1, True, 1, False, 0), (196, 256, 1, True, 4, False, 0),
+              (196, 1024, 1, False, 4, True, 0), (196, 512, 1, True, 1, False, 0), (49, 512, 1, True, 8, False, 0),
+              (49, 2048, 1, False, 8, True, 0), (49, 2048, 0, False, 1, False, 0), (196, 1024, 1, False, 1, False, 1024)]
+
+
+@pytest.mark.parametrize("cfg", GN_ONEPASS)
+def test_groupnorm_onepass(be, cfg):
+    print(K.case_groupnorm_onepass(be, *cfg, seed=sum(cfg[:2])))
+
+
 @pytest.mark.parametrize("shape", RESNET_SHAPES)
 def test_conv_gn_bwd_fused_all_resnet_shapes(be, shape):
     H, W, C, Kc, R, st, pad = shape
@@ -234,6 +249,14 @@ def test_conv_linearity_full_size(be):
                                          be.stream), "conv")
         outs.append(be.host(y))
     assert np.abs(outs[2] - (2.5 * outs[0] + outs[1])).max() < 1e-4 * np.abs(outs[2]).max()
+
+
+@pytest.mark.parametrize("onepass", [2, 1, 0])
+def test_hmr_engine_one_image_throughput_schedule_vs_latency_schedule(be, ckpt_rand, onepass):
+    """One image per launch replica (the benchmarked configuration): the engine's gradients under the throughput schedule - one-pass
+    GroupNorm backward for every layer (2), for one-workgroup slabs only (1), two-launch reduce + apply (0) - against its own
+    latency schedule (pinned to the reference module by test_hmr_engine_vs_reference_module)."""
+    print(K.case_hmr_engine_schedules(be, ckpt_rand, {"rep_split": 1, "tp_min": 1, "tp_gn_onepass": onepass}))
 
 
 @pytest.mark.parametrize("k4_batch", [1, 0])
