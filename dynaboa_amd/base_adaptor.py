@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import assets as A
 from . import constants
 from .hmr import hmr
-from .fused_level import level_forward
+from .fused_level import clear_last_forward, level_forward
 from .losses import (AUX_MAX_BATCH, MaxMixturePrior, frame_losses, labelled_term, motion_term, pose_prior, projection_normed,
                      teacher_term)
 from .maml import MAML
@@ -315,6 +315,7 @@ class BaseAdaptor:
                 learner, self.smpl_neutral, self.gmm_f, image, gt_keypoints_2d, o.s2dloss_weight, o.shape_prior_weight,
                 o.pose_prior_weight)
         else:
+            clear_last_forward()                 # (a remembered fused forward must not be mistaken for this level's: ADVICE r3)
             rot, shape, cam, feats = learner(image, need_feature=True)
             smpl_out = self.decode_smpl_params(rot, shape)
             s3d = smpl_out["s3d"]

@@ -387,6 +387,14 @@ class Adaptor(BaseAdaptor):
         self.save_hist(image, gt_keypoints_2d)
         if self._native_ok():
             return self._adapt_native(batch)
+        try:
+            return self._adapt_autograd(batch, image, gt_keypoints_2d)
+        finally:
+            from .fused_level import clear_last_forward
+            clear_last_forward()                 # the remembered level forwards (and their activation arenas) end with the frame
+
+    def _adapt_autograd(self, batch, image, gt_keypoints_2d):
+        o = self.options
         if not o.use_boa:
             loss, _ = self.lower_level_adaptation(image, gt_keypoints_2d, None, self.model)
             self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()

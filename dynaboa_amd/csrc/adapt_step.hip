@@ -909,13 +909,18 @@ static int stage_inputs(Stepper& S, const void* const* src, int ld, int k0, int 
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
-// The launch scope of a set of physical replicas: every per-replica arena of the stepper, map = the set.
-static DybRep make_scope(const Stepper& S, const int* idx, int n) {
+// The launch scope of a set of physical replicas: every per-replica arena of the stepper, map = the set.  DYB_ERR_UNSUPPORTED when
+// the stepper's arenas do not fit the scope's DYB_MAX_ARENAS slots: with the full term set and replicas the separate records /
+// loss_log / gate_log / feat5_out pointers are one too many - pass them as sub-buffers of ONE per-replica block through
+// "logs_base" / "logs_bytes" (what the Python driver does); an arena silently left out would alias every replica onto replica 0's.
+static int make_scope(const Stepper& S, const int* idx, int n, DybRep* out) {
   DybRep R{};
   dyb_rep_identity(R);
   dyb_rep_set_map(R, idx, n);
+  bool overflow = false;
   auto arena = [&](const void* lo, size_t bytes) {
-    if (!lo || !bytes || R.narenas >= DYB_MAX_ARENAS) return;
+    if (!lo || !bytes) return;
+    if (R.narenas >= DYB_MAX_ARENAS) { overflow = true; return; }
     R.lo[R.narenas] = reinterpret_cast<const char*>(lo);
     R.span[R.narenas] = bytes;
     R.stride[R.narenas] = bytes;
@@ -926,6 +931,7 @@ static DybRep make_scope(const Stepper& S, const int* idx, int n) {
   arena(S.theta, S.n_params * sizeof(float));
   arena(S.adam_m, S.n_params * sizeof(float));
   arena(S.adam_v, S.n_params * sizeof(float));
+  if (S.full) arena(S.teacher, S.n_params * sizeof(float));
   if (S.logs_base && S.logs_bytes) {
     arena(S.logs_base, S.logs_bytes);              // records, loss_log, gate_log, feat5_out: sub-buffers of one per-replica block
   } else {
@@ -936,8 +942,9 @@ static DybRep make_scope(const Stepper& S, const int* idx, int n) {
       arena(S.feat5_out, (size_t)S.B * 2048 * sizeof(float));
     }
   }
-  if (S.full) arena(S.teacher, S.n_params * sizeof(float));
-  return R;
+  DYB_REQUIRE(!overflow, DYB_ERR_UNSUPPORTED);
+  *out = R;
+  return DYB_OK;
 }
 // the replicas the next frame step covers (ascending physical indices; n = 0: all).  Sequences of different lengths: a replica
 // whose stream has ended simply leaves the set - its weights, Adam state and records stay as they are.
@@ -1076,7 +1083,8 @@ extern "C" int dyb_stepper_adapt_frames_full(void* stepper, const void* const* i
     if (i == 0) { have_hist = h; have_ex = e; have_gt = gt; }
     DYB_REQUIRE(h == have_hist && e == have_ex && gt == have_gt, DYB_ERR_UNSUPPORTED);     // lockstep: the same terms for every replica
   }
-  const DybRep R = make_scope(S, act, na);
+  DybRep R{};
+  RUN(make_scope(S, act, na, &R));
   DybRepScope scope(R);
   RUN(stage_inputs(S, inputs, n, IN_IMAGE, 5, st));
   if (have_hist) RUN(stage_inputs(S, inputs + (size_t)IN_HIST_IMAGE * n, n, IN_HIST_IMAGE, 2, st));
@@ -1117,7 +1125,11 @@ extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs
                             (const long long*)inputs[4], record_slot, loss_slot, st, aux, side);
   int act[DYB_MAX_REPLICAS];
   const int na = active_set(S, act);
-  const DybRep R = make_scope(S, act, na);
+  // replicas + side stream: the owed final inference of frame f would read staging buffers the next call has already refilled,
+  // under the next frame's launch scope - replica groups run their tail in line
+  DYB_REQUIRE(!(S.use_side && side && side != st), DYB_ERR_UNSUPPORTED);
+  DybRep R{};
+  RUN(make_scope(S, act, na, &R));
   DybRepScope scope(R);
   for (int i = 0; i < na; ++i) DYB_REQUIRE(inputs[0 * n + act[i]] && inputs[1 * n + act[i]], DYB_ERR_ARG);
   // previous frame's tail on the side stream still reads the staged inputs

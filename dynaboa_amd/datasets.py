@@ -97,6 +97,7 @@ def preprocess_frame(img_u8: torch.Tensor, center, scale, res: int = C.IMG_RES, 
     check(lib.dyb_crop_resize_normalize(img_u8.data_ptr(), H, W, int(ul[0]), int(ul[1]), int(br[0]), int(br[1]), out.data_ptr(), res,
                                         m[0], m[1], m[2], s[0], s[1], s[2], ws.data_ptr(), ws.numel(), stream_of(img_u8)),
           "dyb_crop_resize_normalize")
+    torch.autograd.graph.increment_version(out)     # written by a raw kernel: caches keyed on (storage, version) must see the new frame
     return out
 
 

@@ -22,23 +22,32 @@ from ._abi import check
 from .hmr import (STATE_LD, _feature_views, aux_stream_of, get_bwd_stage, get_layout, get_workspace, stream_of)
 
 _STAGE: Dict[tuple, dict] = {}
-# the activation arena of the newest level forward per plan, with what identifies its inputs (weights / image storage and versions):
-# the exact Hessian-vector product of that level (dynaboa_amd/hvp.py) starts from it instead of repeating the forward
+# The activation arena of the newest level forward per plan, for the exact Hessian-vector product of that level (dynaboa_amd/hvp.py),
+# which starts from it instead of repeating the forward.  Identity of "the same forward" is NOT inferred from addresses alone: an
+# entry keeps its three input tensors alive (so no later tensor can occupy their storage while the entry exists), compares the
+# storages and autograd version counters (the wrappers around the library's in-place kernels - Adam, EMA, preprocess - bump them
+# by hand), is handed out ONCE (the consumer pops it) and is dropped at the end of the frame and whenever a level runs unfused.
 _LAST_FORWARD: Dict[tuple, tuple] = {}
 
 
 def _fwd_key(theta, image, init_state, n_iter):
-    return (theta.data_ptr(), theta._version, image.data_ptr(), image._version, init_state.data_ptr(), init_state._version, int(n_iter))
+    return (theta.data_ptr(), theta._version, tuple(theta.shape), image.data_ptr(), image._version, tuple(image.shape),
+            init_state.data_ptr(), init_state._version, int(n_iter))
 
 
 def last_forward_acts(theta, image, init_state, n_iter):
     """The activation arena `level_forward` filled for exactly these (weights, image, initial state) if it was the newest one, else
-    None.  Call while the three tensors are alive (storage addresses are compared)."""
+    None; the entry is consumed either way."""
     B, _, H, W = image.shape
-    hit = _LAST_FORWARD.get((B, H, W, str(theta.device)))
+    hit = _LAST_FORWARD.pop((B, H, W, str(theta.device)), None)
     if hit is None or hit[0] != _fwd_key(theta, image, init_state, n_iter):
         return None
     return hit[1]
+
+
+def clear_last_forward():
+    """Drop every remembered level forward (end of a frame; a level that ran without the fused node)."""
+    _LAST_FORWARD.clear()
 
 
 def _stage(B: int, device: torch.device) -> dict:
@@ -101,7 +110,7 @@ class _LevelFunction(torch.autograd.Function):
                                    drot_l.data_ptr(), dshape_l.data_ptr(), 10, dcam_l.data_ptr(), 3, djoints_l.data_ptr(), B,
                                    lws.data_ptr(), B * 16, st), "dyb_frame_losses")
         ctx.L, ctx.n_iter, ctx.smpl, ctx.B = L, n_iter, smpl, B
-        _LAST_FORWARD[(B, H, W, str(dev))] = (_fwd_key(theta, image, init_state, n_iter), acts)
+        _LAST_FORWARD[(B, H, W, str(dev))] = (_fwd_key(theta, image, init_state, n_iter), acts, theta, image, init_state)
         ctx.save_for_backward(theta, acts, buf)
         ctx.sizes = sizes
         comps = losses[:3].clone()

@@ -46,6 +46,13 @@ class _FastWeightStep(torch.autograd.Function):
         return d_out, None, None
 
 
+def _note_grad(p):
+    """post-accumulate-grad hook of a parameter whose last second-order accumulation may be deferred: remember WHICH tensor
+    autograd left in .grad and at which version, so that Adam.step can tell whether anybody edited or replaced it since."""
+    g = p.grad
+    p._so_grad_seen = None if g is None else (id(g), g._version)
+
+
 class _SecondOrderStep(torch.autograd.Function):
     """out = p - lr * g(p).  Backward: v -> v - lr * H v, with H v supplied by `hvp` (finite differences of
     the first-order gradient at p +- e v; see the module docstring)."""
@@ -123,6 +130,8 @@ class MAML(nn.Module):
         # the first adapt() of a clone feeds the base parameter directly: its accumulation can ride in Adam's launch
         defer = self.module.theta if (self.defer_accumulate and self._first) else None
         self._first = False
+        if defer is not None and not hasattr(defer, "_so_grad_hook"):
+            defer._so_grad_hook = defer.register_post_accumulate_grad_hook(_note_grad)
         if hvp_factory is not None:
             exact = hvp_factory(self._theta.detach())
             self._theta = _SecondOrderStep.apply(self._theta, g, self.lr, lambda v: exact(v.detach()), defer)

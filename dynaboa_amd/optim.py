@@ -63,21 +63,25 @@ class Adam:
             if pend is not None:
                 # second order: the gradient is still g - alpha * h (MAML deferred its last accumulation, maml.py) - one launch
                 h, alpha = pend[0], pend[1]
-                # the pair belongs to the gradient MAML left in .grad.  An in-place edit of .grad since (gradient clipping, a second
-                # backward accumulating into it) would be combined with a stale H v: .grad arrives here untouched (version 0) in the
-                # supported flow - say so loudly otherwise (a .grad REPLACED by a new tensor cannot be told apart; use
-                # dynaboa_amd.optim.materialize_grad(p) before editing gradients, or MAML(defer_accumulate=False))
-                if p.grad._version != 0:
+                # the pair belongs to the gradient autograd left in .grad at the end of that backward (maml.py notes the tensor and
+                # its version in a post-accumulate hook - the parameter may legitimately receive several accumulations in one
+                # backward).  An in-place edit since (gradient clipping, a second backward) or a replaced .grad would be combined
+                # with a stale H v: say so loudly (use dynaboa_amd.optim.materialize_grad(p) before editing gradients, or
+                # MAML(defer_accumulate=False))
+                seen = getattr(p, "_so_grad_seen", None)
+                if seen is not None and seen != (id(p.grad), p.grad._version):
                     import warnings
-                    warnings.warn("second-order gradient: .grad was modified in place after backward() while its last accumulation "
+                    warnings.warn("second-order gradient: .grad was modified or replaced after backward() while its last accumulation "
                                   "(v - lr * H v) was still deferred to Adam.step", RuntimeWarning, stacklevel=2)
                 p._so_pending = None
                 check(lib.dyb_adam_step_accum(p.data_ptr(), g.data_ptr(), h.data_ptr(), float(alpha), st["exp_avg"].data_ptr(),
                                               st["exp_avg_sq"].data_ptr(), b1, b2, step_size, bc2_sqrt, eps, p.numel(), stream_of(p)),
                       "dyb_adam_step_accum")
+                torch.autograd.graph.increment_version(p)
                 continue
             check(lib.dyb_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                     b1, b2, step_size, bc2_sqrt, eps, p.numel(), stream_of(p)), "dyb_adam_step")
+            torch.autograd.graph.increment_version(p)      # (the library's kernels write p in place behind autograd's back)
 
 
 def ema_update(teacher_params, model_params, alpha: float):
@@ -85,3 +89,4 @@ def ema_update(teacher_params, model_params, alpha: float):
     lib = _lib.load()
     for pt, p in zip(teacher_params, model_params):
         check(lib.dyb_ema_update(pt.data_ptr(), p.data_ptr(), float(alpha), pt.numel(), stream_of(pt)), "dyb_ema_update")
+        torch.autograd.graph.increment_version(pt)

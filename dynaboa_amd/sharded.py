@@ -54,6 +54,9 @@ def run_sharded(options, sequences: Sequence[SequenceSpec], make_adaptor: Callab
     # longest first inside a rank: a wave's sequences then have similar lengths (fewer idle replica slots at its tail)
     order = sorted(owned, key=lambda i: (-sequences[i].nframes, i))
     S = max(1, int(seqs_per_gpu))
+    if S > 1 and B > 1 and any(sequences[i].nframes % B for i in owned):
+        # a replica group stages B samples per sequence and step: a last, partial batch would be read past its end
+        raise ValueError("seqs_per_gpu > 1 needs sequence lengths that are multiples of batch_size (or batch_size 1)")
     for w0 in range(0, len(order), S):
         wave = [sequences[i] for i in order[w0:w0 + S]]
         steps = max(-(-s.nframes // B) for s in wave)
@@ -80,7 +83,9 @@ def run_sharded(options, sequences: Sequence[SequenceSpec], make_adaptor: Callab
             mp = np.concatenate([np.ravel(np.asarray(x, np.float64)) for x in res["mpjpe"]]) if len(res["mpjpe"]) else np.zeros(0)
             pa = np.concatenate([np.ravel(np.asarray(x, np.float64)) for x in res["pampjpe"]]) if len(res["pampjpe"]) else np.zeros(0)
             pve_b = np.ravel(np.asarray(res["pve"], np.float64))                      # one value per batch (mean over it)
-            n = min(s.nframes, mp.shape[0])
+            if mp.shape[0] != s.nframes:             # a missing frame record must not be papered over
+                raise RuntimeError(f"sequence {s.name}: {mp.shape[0]} frame records for {s.nframes} frames")
+            n = s.nframes
             pve = np.repeat(pve_b, B)[:n] if pve_b.size else np.zeros(n)
             gi = np.arange(s.first, s.first + n, dtype=np.float64)
             rows.append(np.stack([gi, mp[:n], pa[:n], pve], 1))

@@ -426,7 +426,12 @@ int dyb_stepper_adapt_frame_full(void* stepper, const void* const* inputs, int r
  * r the physical replica (entries of inactive replicas ignored; the history pair present for all active replicas or none;
  * exemplars NULL with the per-replica callback set_p "retrieve_rep_fn": int fn(void* user, int level, int replica, const void**
  * ex5)).  teacher / gate_log / feat5_out are [replicas][...] like theta; gate_host 16 floats per replica.  extra_steps: `replicas`
- * ints.  dyb_stepper_set_active: the replicas following frame steps cover (ascending physical indices; n = 0: all) - sequences of
+ * ints.  A launch scope holds at most 8 per-replica arenas (workspace, theta, adam_m, adam_v, teacher + the logs): with replicas
+ * the four log buffers (records, loss_log, gate_log, feat5_out) must be sub-buffers of ONE per-replica block registered with
+ * set_p "logs_base" / set_i "logs_bytes" (replica r's block at logs_base + r * logs_bytes); with separate log pointers the call
+ * returns DYB_ERR_UNSUPPORTED rather than alias replicas.  dyb_stepper_adapt_frames (replicas > 1) takes no side stream
+ * (DYB_ERR_UNSUPPORTED: the owed final inference would read restaged inputs).  dyb_stepper_set_active: the replicas following
+ * frame steps cover (ascending physical indices; n = 0: all) - sequences of
  * different lengths: a replica whose stream has ended leaves the set, its weights / Adam state / records stay as they are. */
 int dyb_stepper_adapt_frames_full(void* stepper, const void* const* inputs, int record_slot, int loss_slot, int* extra_steps,
                                   dyb_stream_t stream, dyb_stream_t aux);
