@@ -262,6 +262,20 @@ class Runner:
         else:
             self.grp.step([self.frames[r][s] for r in range(self.S)], s)
 
+    def step_with_upload(self, s, pinned):
+        """The same step with the frame's inputs handed over as pinned HOST buffers (what the reference's loop does every frame,
+        dynaboa_benchmark.py:86 `.to(device)`): upload on the issuing stream, then the step."""
+        dev = self.device
+        up = [{k: v.to(dev, non_blocking=True) for k, v in pinned[r][s].items()} for r in range(self.S)]
+        if self.grp is None:
+            ad = self.ad
+            ad.global_step = s
+            ad.fit_losses = {}
+            ad.model.eval()
+            ad.adaptation(up[0])
+        else:
+            self.grp.step(up, s)
+
     def run_range(self, lo, hi, evs=None):
         """G > 1: every group walks steps [lo, hi) from its own host thread on its own stream; returns when all have issued,
         with the caller's current stream made to wait for them.  evs: group 0 records an event after each of its steps."""
@@ -424,7 +438,7 @@ def main():
                          "1 = the single-sequence latency configuration")
     ap.add_argument("--groups", type=int, default=1,
                     help="split the --seqs sequences into this many lockstep groups, each issued by its own host thread on its own stream")
-    ap.add_argument("--replicas", type=str, default="1,4,16",
+    ap.add_argument("--replicas", type=str, default="1,2,4,5,8,16,48,64",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--probe", type=str, default="", help="mode,H,C,K,R: phase clocks of the throughput conv kernel for that layer (diagnostic)")
@@ -464,7 +478,8 @@ def main():
     total = args.warmup + args.steps
     n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
-    nfr = total + n_roof + n_pct
+    n_h2d = 0 if (args.no_sub_records or not simple or args.groups > 1) else 6      # extra steps of the PCIe-inclusive pass (outside the clock)
+    nfr = total + n_roof + n_pct + n_h2d
     rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, groups=args.groups, full_losses=args.full_losses,
                 second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule,
                 hvp=args.hvp)
@@ -530,7 +545,9 @@ def main():
                "ms_per_step": dt * 1e3 / args.steps, "host_issue_ms_per_step": t_issue * 1e3 / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
+               "config": {"workload": "configs[1]: full bilevel adapt, synthetic 224x224 frames, bs=%d per sequence, %d inner + 1 outer, %s, %d seqs/GPU"
+                                      % (args.batch, args.inner_step, order, seqs),
+                          "workload_detail": "configs[1]: single MI355X full bilevel adapt on synthetic 224x224 frames, batch=%d, "
                                       "inner_step=%d + 1 outer, %s, %s; %s; a step = one frame of every sequence; schedule=%s: every "
                                       "output of the reference's %d-forward schedule is produced (metrics after each inner step when "
                                       "faithful), %d HMR forwards + %d backwards executed per frame%s; native frame stepper: %s; "
@@ -594,6 +611,27 @@ def main():
                                     "p99": float(np.percentile(ft, 99)), "max": float(ft.max()),
                                     "how": "HIP event after every step (one frame of each of the %d sequences) on the issuing stream; "
                                            "intervals between consecutive events = time from a sequence's frame to its next" % seqs}
+        if n_h2d:
+            # PCIe-inclusive rate (never `value`): the same steps with every frame's inputs uploaded from pinned host memory inside the clock
+            base = total + n_roof + n_pct
+            pinned = [{s_: {k: v.cpu().pin_memory() for k, v in rn.frames[r][s_].items()} for s_ in range(base, base + n_h2d)} for r in range(seqs)]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(main_stream):
+                rn.step_with_upload(base, pinned)                  # (first touch of the pinned buffers)
+                torch.cuda.synchronize()
+                t0h = time.perf_counter()
+                for s_ in range(base + 1, base + n_h2d):
+                    rn.step_with_upload(s_, pinned)
+                rn.flush()
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - t0h
+            nb = sum(v.numel() * v.element_size() for v in pinned[0][base].values())
+            out["pcie_inclusive"] = {"value": (n_h2d - 1) * args.batch * seqs / dth, "unit": "adapted frames/s", "steps": n_h2d - 1,
+                                     "ms_per_step": dth * 1e3 / (n_h2d - 1), "h2d_bytes_per_frame": nb,
+                                     "note": "the headline loop with each frame's inputs (image, 2-D keypoints, ground-truth pose / shape / gender) "
+                                             "uploaded from pinned host memory on the issuing stream inside the clock, as the reference moves its "
+                                             "batch every frame (dynaboa_benchmark.py:86); `value` above has the inputs resident in HBM"}
+            del pinned
         if world == 1 and not args.no_sub_records and simple and args.batch == 1:
             del rn, run, res
             torch.cuda.empty_cache()
@@ -664,6 +702,27 @@ def main():
                 device, "so_full_exact", 4, 1, 1, 1, "the reference's default term set in second-order mode with exact Hessian-vector "
                 "products for every level (--hvp_terms all, the default: multi-pass form; parity: tests/test_adaptation_gpu.py "
                 "test_second_order_full_loss_set_matches_reference_second_order)", full_losses=1, second_order=1, hvp="exact", hvp_terms="all")
+    # N > 1: what the real 3DPW test stream can supply - 24 files / ~37 person tracks (utils/data_preprocess/pw3d.py:71-77) shared by
+    # N ranks is ceil(37 / N) sequences per GPU, not 32; the same timed loop at that size (all ranks, barrier + max as above)
+    if dist is not None and simple and args.batch == 1 and not args.no_sub_records:
+        s_real = -(-37 // world)
+        try:
+            del rn
+            torch.cuda.empty_cache()
+            rn2 = Runner(device, s_real, args.batch, args.inner_step, 4 + 12, rank=rank, frame_base=500)
+            r2 = timed_stream(rn2, 4, 12, torch.cuda.Stream(device=device), dist)
+            t = torch.tensor([r2["dt"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                out["pw3d_operating_point"] = {"value": 12 * s_real * world / float(t.item()), "unit": "adapted frames/s", "sequences_per_gpu": s_real,
+                                               "ms_per_step": float(t.item()) * 1e3 / 12, "steps": 12, "warmup": 4,
+                                               "note": "the timed loop with ceil(37 / n_gpus) sequences per GPU: 3DPW test has ~37 person tracks, so this - not "
+                                                       "32 per GPU - is what a sharded run of the real stream can keep in flight"}
+            del rn2
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                out["pw3d_operating_point"] = dict(value=None, error=f"{type(e).__name__}: {e}")
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
         print(json.dumps(out))

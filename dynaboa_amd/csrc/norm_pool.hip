@@ -624,13 +624,24 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
 //   k > 1  (up to 7: the stem and the 56x56 / 28x28 block outputs): the k workgroups of a slab - CONSECUTIVE linear ids, so
 //          they are dispatched together - leave their per-channel and per-group sums in `part`, arrive on the slab's counter and
 //          poll it (one lane, s_sleep between polls) until all k have; every workgroup then adds the k group sums in chunk
-//          order (identical coefficients everywhere), chunk 0 also folds dgamma / dbeta.  A workgroup only ever waits for
+//          order (identical coefficients everywhere), chunk 0 also folds dgamma / dbeta.  The exchanged words travel as
+//          device-scope write-through stores / cache-bypassing loads: no cache-wide fence.  A workgroup only ever waits for
 //          workgroups with nearby ids of its own launch: in-order dispatch makes that wait finite whatever else shares the
 //          chip.  A poll that lasts longer than ~0.2 s raises the error word and goes on (results of that launch are then
 //          wrong, the queue is not blocked).
 // Deterministic (fixed summation orders); agrees with the two-launch form to fp32 rounding (different orders).
 #define OP_T 1024
 #define OP_IT 8
+// device-scope (write-through, cache-bypassing) accesses for the few words the workgroups of a slab exchange: global_store /
+// global_load ... sc1.  With them the hand-off needs NO cache-wide fence - a release fence at device scope writes back, an acquire
+// fence invalidates, the WHOLE L2 of the XCD, and ~900 workgroups doing both per launch made the first version of this kernel run
+// at a third of its traffic's rate and slowed the convolutions on the other queue (profiles/r04_s1_*).
+__device__ __forceinline__ void op_store_dev(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float op_load_dev(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 struct GnOnepass {
   const float* din;        // incoming gradient (first split-K slab)
   const float* addend;     // + residual-edge gradient, or NULL
@@ -748,8 +759,8 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
       *reinterpret_cast<float4*>(a.dgamma + cc) = make_float4(Bv[0], Bv[1], Bv[2], Bv[3]);
     } else {
       float* p = a.part + (size_t)chunk * 2 * C + cc;
-      *reinterpret_cast<float4*>(p) = make_float4(A[0], A[1], A[2], A[3]);
-      *reinterpret_cast<float4*>(p + C) = make_float4(Bv[0], Bv[1], Bv[2], Bv[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { op_store_dev(p + i, A[i]); op_store_dev(p + C + i, Bv[i]); }
     }
   }
   // group sums of gamma * A, gamma * B: whole-wave butterflies (work-items without a column hold zeros), waves 0 and 1 carry the columns
@@ -759,35 +770,32 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
   const float inv_m = 1.0f / ((float)(C / G) * (float)a.HW);
   if (k == 1) {
     if (tid == 0) {
-      const float s1 = cqg > 64 ? s_grp[0][0] + s_grp[1][0] : s_grp[0][0];
-      const float s2 = cqg > 64 ? s_grp[0][1] + s_grp[1][1] : s_grp[0][1];
-      s_c[0] = s1 * inv_m;
-      s_c[1] = s2 * inv_m;
+      s_c[0] = (s_grp[0][0] + s_grp[1][0]) * inv_m;          // (wave 1 holds zeros unless cqg = 128)
+      s_c[1] = (s_grp[0][1] + s_grp[1][1]) * inv_m;
     }
   } else {
     float* gpart = a.part + (size_t)k * 2 * C;             // [k][G][2]
     if (tid == 0) {
-      gpart[(chunk * G + g) * 2 + 0] = cqg > 64 ? s_grp[0][0] + s_grp[1][0] : s_grp[0][0];
-      gpart[(chunk * G + g) * 2 + 1] = cqg > 64 ? s_grp[0][1] + s_grp[1][1] : s_grp[0][1];
+      op_store_dev(gpart + (chunk * G + g) * 2 + 0, s_grp[0][0] + s_grp[1][0]);      // (wave 1 holds zeros unless cqg = 128)
+      op_store_dev(gpart + (chunk * G + g) * 2 + 1, s_grp[0][1] + s_grp[1][1]);
     }
-    // publish (every writer's stores reach device scope), arrive, wait for the slab's other chunks
-    if (tid < cqg || tid == 0) __threadfence();
+    // publish = the write-through stores above, drained (s_waitcnt vmcnt(0)) before this workgroup arrives on the slab's counter
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (tid == 0) {
       atomicAdd(a.ctr + g, 1u);
       const long long t0 = wall_clock64();
       while (__hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
           atomicAdd(a.ctr + G, 1u);
           break;
         }
       }
-      __threadfence();
-      float s1 = 0.f, s2 = 0.f;
-      for (int c = 0; c < k; ++c) { s1 += gpart[(c * G + g) * 2]; s2 += gpart[(c * G + g) * 2 + 1]; }
-      s_c[0] = s1 * inv_m;
-      s_c[1] = s2 * inv_m;
+      float t1 = 0.f, t2 = 0.f;
+      for (int c = 0; c < k; ++c) { t1 += op_load_dev(gpart + (c * G + g) * 2); t2 += op_load_dev(gpart + (c * G + g) * 2 + 1); }
+      s_c[0] = t1 * inv_m;
+      s_c[1] = t2 * inv_m;
     }
   }
   __syncthreads();
@@ -808,18 +816,16 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
     }
   }
   if (k > 1 && chunk == 0 && tid < cqg) {
-    // dgamma / dbeta of this group's channels: the k chunks' per-channel sums in chunk order
-    __threadfence();
+    // dgamma / dbeta of this group's channels: the k chunks' per-channel sums in chunk order (every chunk has arrived)
     const int cc = (g * cqg + tid) * 4;
-    float4 sA = zero4, sB = zero4;
+    float uA[4] = {0.f, 0.f, 0.f, 0.f}, uB[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < k; ++c) {
       const float* p = a.part + (size_t)c * 2 * C + cc;
-      const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + C);
-      sA.x += u.x; sA.y += u.y; sA.z += u.z; sA.w += u.w;
-      sB.x += v.x; sB.y += v.y; sB.z += v.z; sB.w += v.w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { uA[i] += op_load_dev(p + i); uB[i] += op_load_dev(p + C + i); }
     }
-    *reinterpret_cast<float4*>(a.dbeta + cc) = sA;
-    *reinterpret_cast<float4*>(a.dgamma + cc) = sB;
+    *reinterpret_cast<float4*>(a.dbeta + cc) = make_float4(uA[0], uA[1], uA[2], uA[3]);
+    *reinterpret_cast<float4*>(a.dgamma + cc) = make_float4(uB[0], uB[1], uB[2], uB[3]);
   }
 }
 // zero fill of a small per-replica region (the arrival counters): replica-aware, unlike a memset node

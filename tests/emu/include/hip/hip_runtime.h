@@ -108,6 +108,12 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 void emu_os_yield();
 static inline void __builtin_amdgcn_s_sleep(int) { emu_os_yield(); }
 static inline long long wall_clock64() { return 0; }
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+static inline float __uint_as_float(unsigned u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

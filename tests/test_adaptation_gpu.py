@@ -100,6 +100,41 @@ def assert_final_state_matches_golden(ad, g, theta0, opts, slices=True):
         np.testing.assert_allclose(tn, g["teacher_delta_norms"], rtol=5e-2)
 
 
+def assert_first_frame_outer_gradient(ad, g, cos_min=0.9999, norm_tol=1e-3):
+    """VERDICT r3 / SURVEY 8c: after the FIRST Adam step m = (1 - beta1) * g, so the outer gradient of frame 0 is exp_avg / (1 - beta1):
+    per-tensor norms against the reference's `g1_norms` (median within norm_tol; every tensor within 10 x - the stem / layer1
+    GroupNorm affines collect the ReLU-flip noise of the whole network) and the sampled slices `g1_<name>` at cosine >= cos_min."""
+    hmr = ad.model.module
+    st = ad.optimizer.state[hmr.theta]
+    assert int(st["step"]) == 1
+    g1 = hmr._layout1.unpack(st["exp_avg"] / (1 - ad.options.beta1))
+    names = [str(x) for x in g["names"]]
+    gn = np.array([float(g1[k].double().norm()) for k in names])
+    err = np.abs(gn - g["g1_norms"]) / g["g1_norms"]
+    sl = {k[3:]: cosine(g1[k[3:]].flatten()[:256].double().cpu().numpy(), g[k]) for k in g.files if k.startswith("g1_") and k != "g1_norms"}
+    print("first-frame outer gradient: norm error median %.2e max %.2e; worst slice cosine %.6f" % (np.median(err), err.max(), min(sl.values())))
+    assert np.median(err) < norm_tol and err.max() < 10 * norm_tol, (float(np.median(err)), [(names[i], float(err[i])) for i in np.argsort(-err)[:5]])
+    bad = {k: v for k, v in sl.items() if v < cos_min}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("native", [1, 0], ids=["native_stepper", "autograd_path"])
+def test_first_frame_first_order_outer_gradient_matches_reference(native):
+    """Frame 0 of golden g5_fo_inner3_frameonly (the reference's Adaptor.adaptation, dynaboa_benchmark.py:126-157, first_order=True):
+    the outer gradient itself - not only the Adam state after 4 frames - at cosine 0.9999 / norms 1e-3."""
+    from dynaboa_amd import assets
+    g = golden("g5_fo_inner3_frameonly.npz")
+    opts, ident = STREAMS["fo_inner3_frameonly"]
+    ad, _ = make_adaptor(dict(opts, native_step=native), ident)
+    ad.reset_records(1)
+    ad.global_step = 0
+    ad.fit_losses = {}
+    ad.model.eval()
+    ad.adaptation({k: v.to(ad.device) for k, v in assets.make_frame(0, 1, seed=22).items()})
+    assert (ad._native is not None) == bool(native)
+    assert_first_frame_outer_gradient(ad, g)
+
+
 def test_deferred_metrics_equal_immediate():
     from dynaboa_amd import assets
     opts, ident = STREAMS["fo_inner1_frameonly_identity"]

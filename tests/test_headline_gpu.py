@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from conftest import golden, rel_err
-from test_adaptation_gpu import assert_final_state_matches_golden
+from test_adaptation_gpu import assert_final_state_matches_golden, assert_first_frame_outer_gradient
 
 pytestmark = pytest.mark.gpu
 
@@ -135,6 +135,7 @@ def test_headline_32_sequences_one_frame(headline_switches):
         assert rel_err(v.cpu().numpy(), g[f"pred0_{k}"]) < 1e-3, k
     fl = grp.flush_metrics()
     assert abs(float(np.mean(fl[0]["mpjpe"][0])) - g["mpjpe"][0]) < 1e-3 * g["mpjpe"][0]
+    assert_first_frame_outer_gradient(ads[0], g)          # the throughput schedule's outer gradient against the reference's, tensor by tensor
     for r in range(S):
         a = ads[r]
         st = a.optimizer.state[a.model.module.theta]

@@ -100,7 +100,7 @@ GN_ONEPASS = [(12544, 64, 1, False, 1, False, 0), (3136, 64, 1, True, 4, False, 
               (3136, 256, 0, False, 1, False, 0), (3136, 128, 1, True, 1, False, 0), (784, 128, 1, True, 2, False, 0),
               (784, 512, 1, False, 1, True, 0), (784, 256, 1, True, 1, False, 0), (196, 256, 1, True, 4, False, 0),
               (196, 1024, 1, False, 4, True, 0), (196, 512, 1, True, 1, False, 0), (49, 512, 1, True, 8, False, 0),
-              (49, 2048, 1, False, 8, True, 0), (49, 2048, 0, False, 1, False, 0), (196, 1024, 1, False, 1, False, 1024)]
+              (49, 2048, 1, False, 8, True, 0), (49, 2048, 0, False, 1, False, 0), (196, 1024, 1, False, 1, False, 2048)]
 
 
 @pytest.mark.parametrize("cfg", GN_ONEPASS)
