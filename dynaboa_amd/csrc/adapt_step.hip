@@ -263,6 +263,15 @@ struct Stepper {
   float *gt_rot = nullptr, *gt_verts[3] = {}, *gt_joints = nullptr, *gt_saved = nullptr, *gt17[2] = {};
   DybEvents* ev = nullptr;
   hipEvent_t e_theta = nullptr, e_side = nullptr, e_gt = nullptr;
+  // weight updates by arena ranges beside the next forward ("upd_overlap", replica groups): the fast-weight steps and Adam are
+  // streaming passes over [replicas] x 108 MB that nothing overlapped - now the range a forward needs first (stem .. layer2, 5 % of
+  // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
+  // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
+  int upd_overlap = 1;
+  hipEvent_t e_upd = nullptr;
+  DybFwdGates gates{};
+  bool gates_pending = false;
+  size_t grp_bounds[2] = {0, 0};
   bool side_pending = false;
   // the final inference of a frame (side stream) is issued by the NEXT call, behind that frame's first level: the host cannot
   // run far ahead of the GPU (launches block when the queue is full), so issuing ~130 side-stream launches right after Adam
@@ -384,9 +393,13 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   S->lbs_saved = dyb_lbs_saved_floats(B);
   S->lbs_wsb = dyb_lbs_bwd_workspace_bytes(B);
   S->ev = dyb_hmr_events_create(plan);
+  dyb_hmr_param_groups(plan, S->grp_bounds);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->e_upd, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->gates.ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->gates.ev[1], hipEventDisableTiming) != hipSuccess) {
     delete S;
     return DYB_ERR_LAUNCH;
   }
@@ -400,6 +413,9 @@ extern "C" void dyb_stepper_destroy(void* stepper) {
   if (S->e_theta) (void)hipEventDestroy(S->e_theta);
   if (S->e_side) (void)hipEventDestroy(S->e_side);
   if (S->e_gt) (void)hipEventDestroy(S->e_gt);
+  if (S->e_upd) (void)hipEventDestroy(S->e_upd);
+  if (S->gates.ev[0]) (void)hipEventDestroy(S->gates.ev[0]);
+  if (S->gates.ev[1]) (void)hipEventDestroy(S->gates.ev[1]);
   delete S;
 }
 
@@ -412,6 +428,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "inner_step") S->inner_step = (int)v;
   else if (k == "eval_lower") S->eval_lower = (int)v;
   else if (k == "use_side") S->use_side = (int)v;
+  else if (k == "upd_overlap") S->upd_overlap = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -594,7 +611,11 @@ static int check_ready(const Stepper& S) {
 
 // HMR forward at `theta` -> rotmat / shape / cam in the pass's arena -> SMPL (neutral) vertices + 49 joints
 static int pass_forward(Stepper& S, Pass& P, const float* theta, const float* image, hipStream_t st) {
-  RUN(dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st));
+  // (a ranged weight update may still be running on the auxiliary stream: this forward - the first reader of the new weights -
+  // waits for each range where it first reads it)
+  const DybFwdGates* gates = S.gates_pending ? &S.gates : nullptr;
+  S.gates_pending = false;
+  RUN(dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st, gates));
   const float* rot = P.acts + S.off_rot;
   const float* state = P.acts + S.off_state;
   return dyb_lbs_fwd(S.smpl_f[0], S.smpl_i[0], state + 144, STATE_LD, rot, P.verts, P.joints, P.saved, S.B, st);
@@ -658,19 +679,51 @@ static int issue_side_work(Stepper& S, hipStream_t side) {
   return DYB_OK;
 }
 // Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
-static int adam_scope(Stepper& S, hipStream_t st) {
+// One weight update over the whole arena - the fast-weight step out = p - fastlr * grads (adam = false) or Adam in place on theta -
+// as one launch on `st`, or (upd_overlap, replica groups with an auxiliary stream) by arena ranges: [0, layer3) on `st`, [layer3,
+// layer4) and [layer4, end) on `aux` behind everything `st` has issued, each followed by its gate event; the next pass_forward waits
+// for them where it first reads those weights.
+static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipStream_t st, hipStream_t aux) {
   const DybRep& R = dyb_rep_current();
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
-  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
-  for (int i = 0; i < R.n; ++i) {
-    const int r = dyb_rep_phys(R, i);
-    const double t = (double)(++S.adam_t_rep[r]);
-    ss[r] = (float)(S.lr / (1.0 - pow(S.beta1, t)));
-    bc[r] = (float)sqrt(1.0 - pow(S.beta2, t));
-    if (S.adam_t_rep[r] > S.adam_t) S.adam_t = S.adam_t_rep[r];
+  if (adam) {
+    for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
+    for (int i = 0; i < R.n; ++i) {
+      const int r = dyb_rep_phys(R, i);
+      const double t = (double)(++S.adam_t_rep[r]);
+      ss[r] = (float)(S.lr / (1.0 - pow(S.beta1, t)));
+      bc[r] = (float)sqrt(1.0 - pow(S.beta2, t));
+      if (S.adam_t_rep[r] > S.adam_t) S.adam_t = S.adam_t_rep[r];
+    }
   }
-  return dyb_adam_step_rep(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, S.n_params, st);
+  auto range = [&](size_t lo, size_t hi, hipStream_t s) -> int {
+    if (adam)
+      return dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps,
+                               hi - lo, s);
+    return dyb_fastweight_update(p + lo, S.grads + lo, out + lo, (float)S.fastlr, hi - lo, s);
+  };
+  const bool ranged = S.upd_overlap && S.nrep > 1 && aux && aux != st && S.grp_bounds[0] > 0 && S.grp_bounds[1] > S.grp_bounds[0] &&
+                      S.grp_bounds[1] < S.n_params;
+  if (!ranged) return range(0, S.n_params, st);
+  RUN(range(0, S.grp_bounds[0], st));
+  HIPOK(hipEventRecord(S.e_upd, st));                 // the gradients' main-stream writers (and the first range) are behind this point
+  HIPOK(hipStreamWaitEvent(aux, S.e_upd, 0));
+  RUN(range(S.grp_bounds[0], S.grp_bounds[1], aux));
+  HIPOK(hipEventRecord(S.gates.ev[0], aux));
+  RUN(range(S.grp_bounds[1], S.n_params, aux));
+  HIPOK(hipEventRecord(S.gates.ev[1], aux));
+  S.gates_pending = true;
+  return DYB_OK;
 }
+// make `st` wait for a ranged update nobody has consumed yet (a consumer other than a forward follows)
+static int settle_update(Stepper& S, hipStream_t st) {
+  if (!S.gates_pending) return DYB_OK;
+  HIPOK(hipStreamWaitEvent(st, S.gates.ev[0], 0));
+  HIPOK(hipStreamWaitEvent(st, S.gates.ev[1], 0));
+  S.gates_pending = false;
+  return DYB_OK;
+}
+static int adam_scope(Stepper& S, hipStream_t st) { return weight_update(S, true, nullptr, nullptr, st, nullptr); }
 static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, const float* gt_pose, const float* gt_betas,
                             const long long* gender, int record_slot, int loss_slot, hipStream_t st, hipStream_t aux,
                             hipStream_t side) {
@@ -730,7 +783,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     }
     if (i < K) {
       HostTimer t(S.h_update);
-      RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, n, st));
+      RUN(weight_update(S, false, cur, S.theta_fast, st, aux));
       cur = S.theta_fast;
     }
   }
@@ -740,7 +793,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     HIPOK(hipStreamWaitEvent(st, S.e_side, 0));
     S.side_pending = false;
   }
-  RUN(adam_scope(S, st));
+  RUN(weight_update(S, true, nullptr, nullptr, st, side ? nullptr : aux));
   // final inference() with the updated weights (dynaboa_benchmark.py:156): in line, or - with a side stream - owed to the
   // next call / dyb_stepper_join (the caller keeps this frame's inputs alive until then)
   if (side) {
@@ -750,6 +803,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     return DYB_OK;
   }
   RUN(pass_forward(S, S.fin, S.theta, image, st));
+  RUN(settle_update(S, st));                         // (consumed by the forward above; a no-op unless that changes)
   if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
   return DYB_OK;
 }

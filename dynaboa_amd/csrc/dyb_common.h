@@ -180,6 +180,7 @@ int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const f
 int dyb_zero_words(unsigned* p, int n, hipStream_t st);
 int dyb_tp_gn_onepass();
 int dyb_tp_gn_cap();
+int dyb_tp_gn_threads();
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,
@@ -198,7 +199,15 @@ struct DybEvents {
 };
 DybEvents* dyb_hmr_events_create(const void* plan);
 void dyb_hmr_events_destroy(DybEvents* e);
+// Weight-ready gates of a forward: the parameter arena is laid out in forward order, so a caller that updates the weights by arena
+// ranges on another stream (the frame stepper: fast-weight steps / Adam beside the next forward's first layers) hands over one event
+// per range - ev[0]: layer3's weights onward, ev[1]: layer4 + regressor - and the forward waits for each right before its first
+// reader.  dyb_hmr_param_groups: the float offsets where those two ranges begin.
+struct DybFwdGates {
+  hipEvent_t ev[2];
+};
+void dyb_hmr_param_groups(const void* plan, size_t bounds[2]);
 int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, const float* init_state, int n_iter, float* acts,
-                          void* ws, size_t ws_bytes, hipStream_t st);
+                          void* ws, size_t ws_bytes, hipStream_t st, const DybFwdGates* gates = nullptr);
 int dyb_hmr_backward_ev(void* plan, const float* params, const float* acts, const float* d_rotmat, const float* d_state,
                         int n_iter, float* grads, void* ws, size_t ws_bytes, hipStream_t st, hipStream_t aux, const DybEvents* ev);

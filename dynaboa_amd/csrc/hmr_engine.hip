@@ -535,7 +535,7 @@ static int run_cached(HmrPlan& P, std::unordered_map<GKey, GEntry, GKeyHash>& ca
 // image: [B][3][H][W] fp32 (NCHW, as the reference's dataloader produces it); init_state:
 // [B][160] = init_pose | init_shape | init_cam | 0.  Results land in the activation arena.
 static int forward_body(const HmrPlan& P, const float* params, const float* init_state, int n_iter, float* acts,
-                        const WsCarve& w, hipStream_t st, const DropCfg& drop = kNoDrop);
+                        const WsCarve& w, hipStream_t st, const DropCfg& drop = kNoDrop, const DybFwdGates* gates = nullptr);
 
 extern "C" int dyb_hmr_forward(void* plan, const float* params, const float* image, const float* init_state,
                                int n_iter, float* acts, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -553,7 +553,7 @@ extern "C" int dyb_hmr_forward(void* plan, const float* params, const float* ima
 }
 
 static int forward_body(const HmrPlan& P, const float* params, const float* init_state, int n_iter, float* acts,
-                        const WsCarve& w, hipStream_t st, const DropCfg& drop) {
+                        const WsCarve& w, hipStream_t st, const DropCfg& drop, const DybFwdGates* gates) {
   DybBf16Scope bf(P.bf16 != 0);
   const int B = P.B;
   const ConvL& stem = P.convs[0];
@@ -564,8 +564,13 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   RUN(dyb_maxpool3x3s2_fwd(acts + stem.out, acts + P.a_pool, reinterpret_cast<uint32_t*>(acts + P.a_poolidx), B, stem.Ho,
                            stem.Wo, stem.K, st));
   const float* x = acts + P.a_pool;
-  for (const BlockL& b : P.blocks) {
+  for (int bi = 0; bi < (int)P.blocks.size(); ++bi) {
+    const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
+    if (gates) {                   // weights updated by arena ranges on another stream: wait right before a range's first reader
+      if (bi == P.layer_last_block[1] + 1 && gates->ev[0] && hipStreamWaitEvent(st, gates->ev[0], 0) != hipSuccess) return DYB_ERR_LAUNCH;
+      if (bi == P.layer_last_block[2] + 1 && gates->ev[1] && hipStreamWaitEvent(st, gates->ev[1], 0) != hipSuccess) return DYB_ERR_LAUNCH;
+    }
     // 3 launches per conv become 2 (or 1: the small 1x1 layers write their statistics themselves): bn1 / bn2 (+ReLU)
     // are applied by conv2 / conv3 while loading
     RUN(conv_stats(P, c1, params, acts, x, nullptr, nullptr, 0, w.gn[0], &nA, w, st));
@@ -776,15 +781,20 @@ int dyb_hmr_backward_ev(void* plan, const float* params, const float* acts, cons
   return backward_body(*Pp, params, acts, d_rotmat, d_state, n_iter, grads, w, st, aux, ev ? *ev : none);
 }
 // forward without the graph cache (same reason)
+void dyb_hmr_param_groups(const void* plan, size_t bounds[2]) {
+  const HmrPlan* P = reinterpret_cast<const HmrPlan*>(plan);
+  bounds[0] = P->convs[P->blocks[P->layer_last_block[1] + 1].c1].w;       // first tensor of layer3
+  bounds[1] = P->convs[P->blocks[P->layer_last_block[2] + 1].c1].w;       // first tensor of layer4 (the regressor follows)
+}
 int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, const float* init_state, int n_iter, float* acts,
-                          void* ws, size_t ws_bytes, hipStream_t st) {
+                          void* ws, size_t ws_bytes, hipStream_t st, const DybFwdGates* gates) {
   HmrPlan* Pp = reinterpret_cast<HmrPlan*>(plan);
   DYB_REQUIRE(Pp && params && image && init_state && acts && ws, DYB_ERR_ARG);
   DYB_REQUIRE(n_iter >= 1 && n_iter <= MAX_ITER, DYB_ERR_UNSUPPORTED);
   DYB_REQUIRE(ws_bytes >= Pp->ws_total && Pp->featHW == 49, DYB_ERR_WORKSPACE);
   WsCarve w = carve(*Pp, ws);
   RUN(dyb_nchw3_to_nhwc4(image, acts + Pp->a_x4, Pp->B, Pp->H, Pp->W, st));
-  return forward_body(*Pp, params, init_state, n_iter, acts, w, st);
+  return forward_body(*Pp, params, init_state, n_iter, acts, w, st, kNoDrop, gates);
 }
 
 // train-mode variants: nn.Dropout(0.5) after fc1 / fc2 of every regressor iteration (reference model/hmr.py:84,86,165,169).

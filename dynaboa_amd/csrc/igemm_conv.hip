@@ -1117,7 +1117,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap;
+      tp_gn_cap, tp_gn_threads;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1135,6 +1135,7 @@ struct DybSwitches {
     tp_occ = env("DYB_TP_OCC", 0);
     tp_gn_onepass = env("DYB_TP_GN_ONEPASS", 2);
     tp_gn_cap = env("DYB_TP_GN_CAP", 0);
+    tp_gn_threads = env("DYB_TP_GN_THREADS", 256);
   }
 };
 static DybSwitches& switches() {
@@ -1161,6 +1162,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_occ")) return &s.tp_occ;
   if (!strcmp(name, "tp_gn_onepass")) return &s.tp_gn_onepass;
   if (!strcmp(name, "tp_gn_cap")) return &s.tp_gn_cap;
+  if (!strcmp(name, "tp_gn_threads")) return &s.tp_gn_threads;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1732,9 +1734,11 @@ int dyb_gn_replica_share(int N) {
 }
 // throughput schedule, GroupNorm backward: "tp_gn_onepass" 2 (default) = the one-pass kernel for every layer that qualifies (slabs
 // of several row chunks meet on a counter), 1 = only layers whose (image, group) slab is one workgroup, 0 = the two-launch
-// reduce + apply; "tp_gn_cap" = float4 per workgroup (0: 8192; tests force several chunks on small shapes)
+// reduce + apply; "tp_gn_cap" = float4 per workgroup (0: 8 x "tp_gn_threads", the workgroup size 256 / 512 / 1024; tests force
+// several chunks on small shapes)
 int dyb_tp_gn_onepass() { return switches().tp_gn_onepass.load(std::memory_order_relaxed); }
 int dyb_tp_gn_cap() { return switches().tp_gn_cap.load(std::memory_order_relaxed); }
+int dyb_tp_gn_threads() { return switches().tp_gn_threads.load(std::memory_order_relaxed); }
 bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
   if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;

@@ -614,14 +614,14 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
 // ---- one-pass backward (throughput schedule, one image per sequence replica) ------------------------------------------------
 // The two-launch backward streams every tensor of a layer twice: the reduce reads the incoming gradient, y and the ReLU mask
 // source and writes the masked gradient dm; the apply reads dm and y again and writes dy - 6 to 7 tensor passes per layer, the
-// second-largest kernel family of a frame step at 32 sequences (profiles/r03_final_kernel_stats_S32.csv).  Here a workgroup of
-// 1024 work-items keeps its share of an (image, group) slab IN REGISTERS between the two phases (8 x 16 bytes of masked gradient
+// second-largest kernel family of a frame step at 32 sequences (profiles/r03_final_kernel_stats_S32.csv).  Here a workgroup (256
+// work-items by default) keeps its share of an (image, group) slab IN REGISTERS between the two phases (8 x 16 bytes of masked gradient
 // and of xhat per work-item), so the layer costs one read of each input and one write of each output: 3 passes for the layers
 // inside a bottleneck (gradient, y -> dy), 5 for a block output (gradient, y, activation -> dm, dy).
 //   grid (k, G, replicas): workgroup (c, g, r) owns rows [c * rows, (c + 1) * rows) of replica r's slab of group g;
-//   k = 1  (slab <= 8192 float4: every 14x14 and 7x7 layer, 28x28 up to 256 channels, 56x56 x 64): sums, coefficients, dy,
+//   k = 1  (slab <= 2048 float4: the 7x7 x 512 layers): sums, coefficients, dy,
 //          dgamma / dbeta - everything in the one workgroup;
-//   k > 1  (up to 7: the stem and the 56x56 / 28x28 block outputs): the k workgroups of a slab - CONSECUTIVE linear ids, so
+//   k > 1  (2 .. 25: everything else; the stem and the 56x56 block outputs are the 25): the k workgroups of a slab - CONSECUTIVE linear ids, so
 //          they are dispatched together - leave their per-channel and per-group sums in `part`, arrive on the slab's counter and
 //          poll it (one lane, s_sleep between polls) until all k have; every workgroup then adds the k group sums in chunk
 //          order (identical coefficients everywhere), chunk 0 also folds dgamma / dbeta.  The exchanged words travel as
@@ -630,8 +630,8 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
 //          chip.  A poll that lasts longer than ~0.2 s raises the error word and goes on (results of that launch are then
 //          wrong, the queue is not blocked).
 // Deterministic (fixed summation orders); agrees with the two-launch form to fp32 rounding (different orders).
-#define OP_T 1024
 #define OP_IT 8
+#define OP_KMAX 32
 // device-scope (write-through, cache-bypassing) accesses for the few words the workgroups of a slab exchange: global_store /
 // global_load ... sc1.  With them the hand-off needs NO cache-wide fence - a release fence at device scope writes back, an acquire
 // fence invalidates, the WHOLE L2 of the XCD, and ~900 workgroups doing both per launch made the first version of this kernel run
@@ -659,11 +659,13 @@ struct GnOnepass {
   size_t slab_stride;
   int nslabs, HW, C, rows, relu;
 };
+template <int OP_T>
 __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRep R) {
   DYB_REP_PROLOGUE(R);
   DYB_RB(R, a.din); DYB_RB(R, a.addend); DYB_RB(R, a.out); DYB_RB(R, a.y); DYB_RB(R, a.stats); DYB_RB(R, a.gamma); DYB_RB(R, a.beta);
   DYB_RB(R, a.dm); DYB_RB(R, a.dy); DYB_RB(R, a.dgamma); DYB_RB(R, a.dbeta); DYB_RB(R, a.part); DYB_RB(R, a.ctr);
-  __shared__ float sm[16][64][8];
+  constexpr int NW = OP_T / 64;
+  __shared__ float sm[NW][64][8];
   __shared__ float s_grp[2][2];
   __shared__ float s_c[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
   if (tid < cqg) {
     // column tid lives in lane (tid % 64) of the waves w with (w * 64) % cqg == tid - tid % 64
     const int l = tid & 63, wbase = tid >> 6, wstep = cqg > 64 ? cqg >> 6 : 1;
-    for (int w = wbase; w < 16; w += wstep) {
+    for (int w = wbase; w < NW; w += wstep) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { A[i] += sm[w][l][i]; Bv[i] += sm[w][l][4 + i]; }
     }
@@ -840,15 +842,24 @@ int dyb_zero_words(unsigned* p, int n, hipStream_t st) {
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
-// chunks per (image, group) slab of the one-pass backward, 0 = the shape does not qualify (`cap` float4 per workgroup: OP_T *
-// OP_IT, or less - the tests force several chunks on small shapes that way)
+// chunks per (image, group) slab of the one-pass backward, 0 = the shape does not qualify.  `cap` = float4 per workgroup: a
+// workgroup of T work-items holds T * OP_IT; 0 = the policy's workgroup size ("tp_gn_threads": 256 - four workgroups per CU in
+// different phases; 512 and 1024 measured slower) - the tests force several chunks on small shapes with small caps
+static int onepass_threads(int cap) {
+  if (cap <= 0) {
+    const int t = dyb_tp_gn_threads();
+    return t >= 1024 ? 1024 : t >= 512 ? 512 : 256;
+  }
+  return cap > 512 * OP_IT ? 1024 : cap > 256 * OP_IT ? 512 : 256;
+}
 int dyb_gn_onepass_chunks(int N, int HW, int C, int cap) {
   if (N != 1 || C % 16 != 0 || C < 64 || C > 2048 || !dyb_is_pow2(C)) return 0;
-  if (cap <= 0 || cap > OP_T * OP_IT) cap = OP_T * OP_IT;
+  const int T = onepass_threads(cap);
+  if (cap <= 0 || cap > T * OP_IT) cap = T * OP_IT;
   const int cqg = C / 16;
   int k = 1;
-  while (k <= 8 && dyb_cdiv(HW, k) * cqg > cap) ++k;
-  if (k > 8) return 0;
+  while (k <= OP_KMAX && dyb_cdiv(HW, k) * cqg > cap) ++k;
+  if (k > OP_KMAX) return 0;
   return dyb_cdiv(HW, dyb_cdiv(HW, k));
 }
 // floats of `part` the k-chunk form needs (k > 1)
@@ -856,22 +867,25 @@ size_t dyb_gn_onepass_part_floats(int k, int C) { return k > 1 ? (size_t)k * 2 *
 int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const float* addend, const float* out, const float* y,
                        const float* stats, const float* gamma, const float* beta, float* dm, float* dy, float* dgamma, float* dbeta,
                        int HW, int C, int relu, int k, float* part, unsigned* ctr, hipStream_t st) {
-  DYB_REQUIRE(din && y && stats && gamma && dy && dgamma && dbeta && nslabs >= 1 && k >= 1, DYB_ERR_ARG);
+  DYB_REQUIRE(din && y && stats && gamma && dy && dgamma && dbeta && nslabs >= 1 && k >= 1 && k <= OP_KMAX, DYB_ERR_ARG);
   DYB_REQUIRE(!relu || out || beta, DYB_ERR_ARG);
   DYB_REQUIRE(k == 1 || (part && ctr), DYB_ERR_ARG);
   const int rows = dyb_cdiv(HW, k);
-  DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= OP_T * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= 1024 * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
   GnOnepass a{din, addend, out, y, stats, gamma, beta, dm == din ? nullptr : dm, dy, dgamma, dbeta, part, ctr, slab_stride, nslabs, HW, C,
               rows, relu};
   const DybRep& R = dyb_rep_current();
-  hipLaunchKernelGGL(gn_bwd_onepass_kernel, dim3(k, G, R.n), dim3(OP_T), 0, st, a, R);
+  const int items = rows * (C / 16);
+  if (items <= 256 * OP_IT) hipLaunchKernelGGL(gn_bwd_onepass_kernel<256>, dim3(k, G, R.n), dim3(256), 0, st, a, R);
+  else if (items <= 512 * OP_IT) hipLaunchKernelGGL(gn_bwd_onepass_kernel<512>, dim3(k, G, R.n), dim3(512), 0, st, a, R);
+  else hipLaunchKernelGGL(gn_bwd_onepass_kernel<1024>, dim3(k, G, R.n), dim3(1024), 0, st, a, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 // Stand-alone form (tests, direct callers): one image, ws >= dyb_groupnorm_bwd_onepass_workspace_bytes; cap = float4 per
 // workgroup (0: the kernel's 8192).  The arrival counters inside ws are zeroed here, on `st`.
 extern "C" size_t dyb_groupnorm_bwd_onepass_workspace_bytes(int HW, int C) {
-  return ((size_t)8 * 2 * C + 8 * G * 2 + 64) * sizeof(float);
+  return ((size_t)OP_KMAX * 2 * C + OP_KMAX * G * 2 + 64) * sizeof(float);
 }
 extern "C" int dyb_groupnorm_bwd_onepass(const float* dout_slabs, int nslabs, size_t slab_stride, const float* addend, const float* out,
                                          const float* y, const float* stats, const float* gamma, const float* beta, float* dm, float* dy,
@@ -881,7 +895,7 @@ extern "C" int dyb_groupnorm_bwd_onepass(const float* dout_slabs, int nslabs, si
   DYB_REQUIRE(k > 0, DYB_ERR_UNSUPPORTED);
   DYB_REQUIRE(ws && ws_bytes >= dyb_groupnorm_bwd_onepass_workspace_bytes(HW, C), DYB_ERR_WORKSPACE);
   float* part = reinterpret_cast<float*>(ws);
-  unsigned* ctr = reinterpret_cast<unsigned*>(part + (size_t)8 * 2 * C + 8 * G * 2);
+  unsigned* ctr = reinterpret_cast<unsigned*>(part + (size_t)OP_KMAX * 2 * C + OP_KMAX * G * 2);
   if (k > 1) {
     int rc = dyb_zero_words(ctr, G + 1, st);
     if (rc != DYB_OK) return rc;

@@ -63,10 +63,10 @@ int dyb_groupnorm_bwd_fold(const float* dout_slabs, int nslabs, size_t slab_stri
 /* One-pass GroupNorm backward of ONE image (the throughput schedule's form: one image per sequence replica; replaces
  * nn.GroupNorm's autograd, reference model/hmr.py:14-18): every input is read once and every output written once - a workgroup
  * keeps its rows of an (image, group) slab in registers between the sums and the apply; slabs beyond `cap` float4 per workgroup
- * (0: 8192) are cut into up to 8 row chunks whose workgroups meet on a counter inside `ws`.  Incoming gradient = sum_z
+ * (0: the policy's, 2048) are cut into up to 32 row chunks whose workgroups meet on a counter inside `ws`.  Incoming gradient = sum_z
  * dout_slabs[z*slab_stride + .] (+ addend); out = the saved activation (ReLU mask) or NULL: the mask is recomputed from y
  * (beta required); dm (may be NULL) receives the masked gradient.  DYB_ERR_UNSUPPORTED when the shape does not qualify
- * (C a power of two in 64..2048, a slab of at most 8 chunks). */
+ * (C a power of two in 64..2048, a slab of at most 32 chunks). */
 size_t dyb_groupnorm_bwd_onepass_workspace_bytes(int HW, int C);
 int dyb_groupnorm_bwd_onepass(const float* dout_slabs, int nslabs, size_t slab_stride, const float* addend, const float* out,
                               const float* y, const float* stats, const float* gamma, const float* beta, float* dm, float* dy,

@@ -3,8 +3,8 @@
 // yield at __syncthreads() / cross-lane operations, which gives exactly the barrier semantics the
 // kernels rely on.  The workgroups of a grid are spread over a few OS threads (DYB_EMU_THREADS, default = the CPU
 // count, max 16): every piece of executor state, the built-in index variables and the kernels' __shared__ arrays are
-// thread_local.  Workgroups are claimed in id order, so the few kernels whose workgroups meet on a counter (groups of <= 8
-// consecutive ids; the pool has at least 8 threads) make progress as they do on the device.  x86-64 SysV only.
+// thread_local.  Workgroups are claimed in id order, so the few kernels whose workgroups meet on a counter (groups of <= 32
+// consecutive ids; the pool has 32 threads) make progress as they do on the device.  x86-64 SysV only.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
@@ -303,8 +303,8 @@ static int pool_size() {
   static int n = [] {
     const char* e = getenv("DYB_EMU_THREADS");
     long v = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-    if (v < 8) v = 8;                  // kernels that meet on a counter need every workgroup of a meeting claimed (<= 8 of consecutive ids)
     if (v > 16) v = 16;
+    if (v < 32) v = 32;                // kernels that meet on a counter need every workgroup of a meeting claimed (<= 32 of consecutive ids)
     return (int)v;
   }();
   return n;

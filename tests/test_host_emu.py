@@ -301,6 +301,56 @@ def test_native_stepper_side_stream_schedule_under_adversarial_stream_order(emu_
         np.testing.assert_array_equal(outs[0][4], other[4])
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~6 min under the emulator; set DYB_EMU_FULL=1")
+def test_replica_group_ranged_weight_updates_under_adversarial_stream_order(emu_lib, monkeypatch):
+    """Replica groups update the weights by arena ranges: [stem .. layer2] on the chain's stream, [layer3] and [layer4 + regressor] on
+    the auxiliary stream beside the next forward's first layers, which waits for each range right before its first reader
+    (adapt_step.hip weight_update / DybFwdGates).  One frame step of S = 2 sequences (a fast-weight step, Adam, the final inference)
+    in the emulator's lazy stream mode, drained chain-first and auxiliary-stream-first: weights / Adam state / metrics of the in-line
+    run bit for bit."""
+    from types import SimpleNamespace
+    from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    raw = _lib.load()
+    S = 2
+    frames = [assets.make_frame(100 * r, 1, seed=22) for r in range(S)]
+    orig = NS.NativeStepper.adapt_frames
+    outs = []
+    for order in (None, 0, 1):
+        used = []
+
+        def wrapped(self, batches, side_stream=None, order=order, used=used):
+            self._aux = SimpleNamespace(cuda_stream=1)          # any non-null handle is a second stream to the emulator
+            if order is None:
+                return orig(self, batches, side_stream)
+            raw.emu_lazy(1)
+            try:
+                return orig(self, batches, side_stream)
+            finally:
+                used.append(raw.emu_flush(order))
+                raw.emu_lazy(0)
+        monkeypatch.setattr(NS.NativeStepper, "adapt_frames", wrapped)
+        ads = []
+        for r in range(S):
+            o = DB.frame_only_options(inner_step=1)
+            o.deferred_metrics = 1
+            ads.append(DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cpu"))
+        grp = NS.ReplicaGroup(ads, 1)
+        grp.step(frames, 0)
+        fl = grp.flush_metrics()
+        if order is not None:
+            assert used == [2], used
+        row = []
+        for r in range(S):
+            st = ads[r].optimizer.state[ads[r].model.module.theta]
+            row += [ads[r].model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                    torch.from_numpy(np.ravel(np.array(fl[r]["mpjpe"], np.float64)))]
+        outs.append(row)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
     assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None
