@@ -16,6 +16,7 @@
 // outer gradient = gradient of the upper-level loss AT the last fast weights (learn2learn clone() + adapt() with
 // first_order=True: SURVEY Appendix B).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -394,6 +395,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   S->lbs_wsb = dyb_lbs_bwd_workspace_bytes(B);
   S->ev = dyb_hmr_events_create(plan);
   dyb_hmr_param_groups(plan, S->grp_bounds);
+  if (const char* e = getenv("DYB_UPD_OVERLAP")) S->upd_overlap = atoi(e);       // (A/B runs; set_i "upd_overlap" afterwards wins)
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
