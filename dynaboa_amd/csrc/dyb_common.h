@@ -181,6 +181,7 @@ int dyb_zero_words(unsigned* p, int n, hipStream_t st);
 int dyb_tp_gn_onepass();
 int dyb_tp_gn_cap();
 int dyb_tp_gn_threads();
+int dyb_tp_gn_poll();
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,

@@ -65,6 +65,9 @@ struct IgemmArgs {
                          // COMPACT (class-local index) into slabs of slab_rows rows; a scatter fold places them (run_igemm_tp)
   int slab_rows;         // rows of one split-K slab (M unless compact)
   unsigned long long* probe;   // throughput form: per-wave phase clocks (dyb_conv_probe_set), normally NULL
+  float* gn_part;        // throughput forward, one image, nsplit == 1: the GroupNorm statistics of the OUTPUT leave with the tile - one
+                         // [G][2] (sum, sum of squares) record per wave tile, [(lx * WM + wm) * ntiles_n * WN + ly * WN + wn] - instead of
+                         // a statistics launch re-reading y (igemm_tp.inc epilogue)
 };
 
 // ---- tile loaders: each returns the 16 bytes this thread contributes to the K-step tile ----
@@ -274,6 +277,7 @@ struct GnFwdFuse {
 // replica rebasing of the argument blocks (dyb_common.h: sequence replicas in the grid)
 __device__ __forceinline__ void rebase(IgemmArgs& g, const DybRep& R, int rep) {
   g.A = dyb_rb(g.A, R, rep); g.B = dyb_rb(g.B, R, rep); g.out = dyb_rb(g.out, R, rep); g.addend = dyb_rb(g.addend, R, rep);
+  g.gn_part = dyb_rb(g.gn_part, R, rep);
 }
 __device__ __forceinline__ void rebase(GnBwdFuse& f, const DybRep& R, int rep) {
   f.y = dyb_rb(f.y, R, rep); f.stats = dyb_rb(f.stats, R, rep); f.gpart = dyb_rb(f.gpart, R, rep); f.gamma = dyb_rb(f.gamma, R, rep);
@@ -1117,7 +1121,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1136,6 +1140,8 @@ struct DybSwitches {
     tp_gn_onepass = env("DYB_TP_GN_ONEPASS", 2);
     tp_gn_cap = env("DYB_TP_GN_CAP", 0);
     tp_gn_threads = env("DYB_TP_GN_THREADS", 256);
+    tp_gn_fuse_stats = env("DYB_TP_GN_FUSE_STATS", 1);
+    tp_gn_poll = env("DYB_TP_GN_POLL", 1);
   }
 };
 static DybSwitches& switches() {
@@ -1163,6 +1169,8 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_gn_onepass")) return &s.tp_gn_onepass;
   if (!strcmp(name, "tp_gn_cap")) return &s.tp_gn_cap;
   if (!strcmp(name, "tp_gn_threads")) return &s.tp_gn_threads;
+  if (!strcmp(name, "tp_gn_fuse_stats")) return &s.tp_gn_fuse_stats;
+  if (!strcmp(name, "tp_gn_poll")) return &s.tp_gn_poll;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1383,8 +1391,10 @@ static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
   if (mode == MODE_DGRAD) return d.K % TPK == 0 && d.R * d.S <= 32;
   return true;
 }
+// stats_part / stats_nrec (forward only): where the GroupNorm statistics of the output may leave with the tiles ("tp_gn_fuse_stats":
+// one image, nsplit == 1, at most min(Ho*Wo, 256) records - what a layer's partial slot holds); *stats_nrec = records written, 0 = none
 static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, const float* addend, void* ws, size_t ws_bytes,
-                        int* raw_slabs_out, hipStream_t st, const GnFwdFuse* nfuse) {
+                        int* raw_slabs_out, hipStream_t st, const GnFwdFuse* nfuse, float* stats_part = nullptr, int* stats_nrec = nullptr) {
   const DybRep& R = dyb_rep_current();
   // tile form: 128x128, or one 64-slab along the short side.  A stride-2 data gradient enumerates its rows by phase class
   // ((h+pad)&1, (w+pad)&1) - tiles never mix classes, each class loops over its own taps - so the row count that matters is
@@ -1436,6 +1446,17 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.out = (split || g.compact) ? reinterpret_cast<float*>(ws) : out;          // (compact: always through the scatter fold)
   g.addend = (split || g.compact) ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
+  g.gn_part = nullptr;
+  if (stats_nrec) *stats_nrec = 0;
+  if (mode == MODE_FWD && stats_part && stats_nrec && !split && d.N == 1 && d.K >= 64 && d.K <= 2048 &&
+      switches().tp_gn_fuse_stats.load(std::memory_order_relaxed)) {
+    const int nrec = (int)(grid.x * grid.y) * (TM / 64) * (TN / 64);
+    const int HWo = g.Ho * g.Wo;
+    if (nrec <= (HWo < 256 ? HWo : 256)) {
+      g.gn_part = stats_part;
+      *stats_nrec = nrec;
+    }
+  }
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);
   // 1: round 2's phase-separated loop (also what the phase probe and
@@ -1520,13 +1541,14 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
 static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B, float* out, const float* addend,
                      void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st, const GnBwdFuse* fuse = nullptr,
-                     const GnFwdFuse* nfuse = nullptr) {
+                     const GnFwdFuse* nfuse = nullptr, float* stats_part = nullptr, int* stats_nrec = nullptr) {
   DYB_REQUIRE(A && B && out, DYB_ERR_ARG);
   IgemmArgs g{};
   int rc = fill_args(g, d, mode);
   if (rc != DYB_OK) return rc;
   g.A = A; g.B = B;
-  if (tp_eligible(mode, d, fuse)) return run_igemm_tp(mode, d, g, out, addend, ws, ws_bytes, raw_slabs_out, st, nfuse);
+  if (stats_nrec) *stats_nrec = 0;
+  if (tp_eligible(mode, d, fuse)) return run_igemm_tp(mode, d, g, out, addend, ws, ws_bytes, raw_slabs_out, st, nfuse, stats_part, stats_nrec);
   g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode, raw_slabs_out != nullptr && mode != MODE_FWD);
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits
@@ -1739,6 +1761,7 @@ int dyb_gn_replica_share(int N) {
 int dyb_tp_gn_onepass() { return switches().tp_gn_onepass.load(std::memory_order_relaxed); }
 int dyb_tp_gn_cap() { return switches().tp_gn_cap.load(std::memory_order_relaxed); }
 int dyb_tp_gn_threads() { return switches().tp_gn_threads.load(std::memory_order_relaxed); }
+int dyb_tp_gn_poll() { return switches().tp_gn_poll.load(std::memory_order_relaxed); }
 bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
   if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;
@@ -1850,9 +1873,13 @@ extern "C" int dyb_conv2d_nhwc_fwd_gnstats(const float* x, const float* part_pre
     nf.nchunks = nch_prev;
   }
   if (dyb_conv_k4_ok(d)) return dyb_conv_fwd_k4(d, x, w, y, partials, part_prev ? &nf : nullptr, nchunks, st);
-  int nslabs = 1;
-  int rc = run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, &nslabs, st, nullptr, part_prev ? &nf : nullptr);
+  int nslabs = 1, nrec = 0;
+  int rc = run_igemm(MODE_FWD, d, x, w, y, nullptr, ws, ws_bytes, &nslabs, st, nullptr, part_prev ? &nf : nullptr, partials, &nrec);
   if (rc != DYB_OK) return rc;
+  if (nrec > 0) {                        // throughput kernel, no split: the statistics left with the tiles (igemm_tp.inc epilogue)
+    *nchunks = nrec;
+    return DYB_OK;
+  }
   *nchunks = dyb_gn_fwd_chunks(N, Ho * Wo);
   return dyb_groupnorm_stats(reinterpret_cast<const float*>(ws), nslabs, y, partials, N, Ho * Wo, K, st);
 }

@@ -658,6 +658,8 @@ struct GnOnepass {
   unsigned* ctr;           // k > 1: [G] arrival counters (zero before the launch) + [1] error word
   size_t slab_stride;
   int nslabs, HW, C, rows, relu;
+  int poll_sleep;          // s_sleep(8) repetitions between two polls of the slab's counter
+  int lab_nowait;          // LAB ONLY (dyb_debug_gn_onepass_replicas): skip the wait - wrong results, timing of the streaming part
 };
 template <int OP_T>
 __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRep R) {
@@ -787,8 +789,8 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
     if (tid == 0) {
       atomicAdd(a.ctr + g, 1u);
       const long long t0 = wall_clock64();
-      while (__hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
-        __builtin_amdgcn_s_sleep(4);
+      while (!a.lab_nowait && __hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
+        for (int i = 0; i < a.poll_sleep; ++i) __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
           atomicAdd(a.ctr + G, 1u);
           break;
@@ -873,7 +875,7 @@ int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const f
   const int rows = dyb_cdiv(HW, k);
   DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= 1024 * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
   GnOnepass a{din, addend, out, y, stats, gamma, beta, dm == din ? nullptr : dm, dy, dgamma, dbeta, part, ctr, slab_stride, nslabs, HW, C,
-              rows, relu};
+              rows, relu, dyb_tp_gn_poll() > 0 ? dyb_tp_gn_poll() : 1, dyb_tp_gn_poll() < 0 ? 1 : 0};
   const DybRep& R = dyb_rep_current();
   const int items = rows * (C / 16);
   if (items <= 256 * OP_IT) hipLaunchKernelGGL(gn_bwd_onepass_kernel<256>, dim3(k, G, R.n), dim3(256), 0, st, a, R);
@@ -902,6 +904,34 @@ extern "C" int dyb_groupnorm_bwd_onepass(const float* dout_slabs, int nslabs, si
   }
   return dyb_gn_bwd_onepass(dout_slabs, nslabs, slab_stride, addend, out, y, stats, gamma, beta, dm, dy, dgamma, dbeta, HW, C, relu, k, part,
                             ctr, st);
+}
+
+// Diagnostic (tools/gn_lab.py): the one-pass backward for `nrep` sequence replicas in ONE launch, the way the stepper issues it.
+// blob: [nrep] x { din | y | out | dm | dy (HW*C floats each) | stats (8) | dgamma (C) | dbeta (C) | ws } with `blob_floats` floats per
+// replica (>= 5*HW*C + 8 + 2*C + workspace floats); gamma / beta shared.  mode bits: 1 = mask from the saved activation, 2 = write dm.
+extern "C" int dyb_debug_gn_onepass_replicas(float* blob, size_t blob_floats, int nrep, const float* gamma, const float* beta, int HW, int C,
+                                             int relu, int mode, hipStream_t st) {
+  DYB_REQUIRE(blob && gamma && beta && nrep >= 1 && nrep <= DYB_MAX_REPLICAS, DYB_ERR_ARG);
+  const size_t n = (size_t)HW * C;
+  const size_t need = 5 * n + 8 + 2 * (size_t)C + dyb_groupnorm_bwd_onepass_workspace_bytes(HW, C) / sizeof(float);
+  DYB_REQUIRE(blob_floats >= need, DYB_ERR_WORKSPACE);
+  DybRep Rp{};
+  Rp.n = nrep;
+  dyb_rep_identity(Rp);
+  Rp.lo[0] = reinterpret_cast<const char*>(blob); Rp.span[0] = blob_floats * sizeof(float); Rp.stride[0] = blob_floats * sizeof(float);
+  Rp.narenas = 1;
+  DybRepScope scope(Rp);
+  float *din = blob, *y = blob + n, *out = blob + 2 * n, *dm = blob + 3 * n, *dy = blob + 4 * n, *stats = blob + 5 * n;
+  float *dgamma = stats + 8, *dbeta = dgamma + C, *ws = dbeta + C;
+  const int k = dyb_gn_onepass_chunks(1, HW, C, 0);
+  DYB_REQUIRE(k > 0, DYB_ERR_UNSUPPORTED);
+  unsigned* ctr = reinterpret_cast<unsigned*>(ws + (size_t)OP_KMAX * 2 * C + OP_KMAX * G * 2);
+  if (k > 1) {
+    int rc = dyb_zero_words(ctr, G + 1, st);
+    if (rc != DYB_OK) return rc;
+  }
+  return dyb_gn_bwd_onepass(din, 1, 0, nullptr, (relu && (mode & 1)) ? out : nullptr, y, stats, gamma, beta, (mode & 2) ? dm : nullptr, dy, dgamma,
+                            dbeta, HW, C, relu, k, ws, ctr, st);
 }
 
 // ---- reduce-only form for consumers that form dy in their operand loaders (igemm_conv.hip) ----------

@@ -313,6 +313,10 @@ int dyb_cosine_sim(const float* a, const float* b, size_t n, float eps, float* o
  * tools/tp_lab.py to time a layer's kernels alone. */
 int dyb_debug_conv_replicas(int mode, const float* x, const float* w, const float* dy, float* out, int nrep, int N, int H, int W, int C,
                             int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, dyb_stream_t stream);
+/* diagnostic (tools/gn_lab.py): dyb_groupnorm_bwd_onepass for nrep replicas in one launch; blob = [nrep] x { din | y | out | dm | dy |
+ * stats(8) | dgamma | dbeta | workspace }, blob_floats per replica; mode bit 0: mask from the saved activation, bit 1: write dm */
+int dyb_debug_gn_onepass_replicas(float* blob, size_t blob_floats, int nrep, const float* gamma, const float* beta, int HW, int C, int relu,
+                                  int mode, dyb_stream_t stream);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 

@@ -165,6 +165,36 @@ def test_layer_gnstats(be, cfg):
     assert r["nA"] > 0 and r["nB"] > 0
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, Ka, Ra, sa, Kb, Rb, sb       (one image: the statistics of both layers' outputs leave with the conv tiles)
+    (1, 12, 12, 64, 64, 3, 1, 128, 1, 1),      # groups of 16 columns: a wave tile holds all four; then groups of 32
+    (1, 9, 9, 64, 256, 1, 1, 512, 1, 1),       # groups of 64 / 128 columns (one group per wave tile, several tiles per group), ragged 81 rows
+    (1, 16, 16, 128, 128, 3, 2, 64, 3, 1),     # stride 2, then the 256x64 tile form
+    (1, 7, 7, 256, 512, 1, 1, 256, 3, 1),      # 49 rows: the 64x256 form
+])
+def test_layer_gnstats_from_the_throughput_kernels_epilogue(be, cfg):
+    """One image, no K split (tp_grid 1): igemm_tp_kernel's forward epilogue leaves one (sum, sum of squares) record per wave tile and
+    no statistics launch follows; the next layer's loader and the apply kernel fold those records (test body as test_layer_gnstats)."""
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    be.lib.dyb_set_option(b"tp_grid", 1)
+    try:
+        r = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+        N, H, W, C, Ka, Ra, sa, Kb, Rb, sb = cfg
+        Ha = (H + 2 * (Ra // 2) - Ra) // sa + 1
+        tm = 256 if Ka <= 64 else (64 if Ha * Ha <= 64 else 128)
+        tn = 64 if Ka <= 64 else (256 if Ha * Ha <= 64 else 128)
+        assert r["nA"] == -(-Ha * Ha // tm) * (tm // 64) * -(-Ka // tn) * (tn // 64), r     # the records are the wave tiles, not row chunks
+        be.lib.dyb_set_option(b"tp_gn_fuse_stats", 0)
+        r0 = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+        assert r0["nA"] != r["nA"] or Ha * Ha <= 64
+    finally:
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)
+        be.lib.dyb_set_option(b"tp_grid", 512)
+        be.lib.dyb_set_option(b"tp_gn_fuse_stats", 1)
+
+
 def _random_conv_cfgs(n, seed):
     rng = np.random.default_rng(seed)
     out = []

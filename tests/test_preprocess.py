@@ -70,6 +70,27 @@ def test_resize_restatement_known_answers():
     assert np.abs(dn - box)[3:-3, 3:-3].max() < 2e-2
 
 
+def test_resize_restatement_against_scipy_ndimage():
+    """The restatement's interpolation half against an INDEPENDENT implementation: scipy.ndimage.map_coordinates(order=1,
+    mode='mirror') sampled at the coordinates skimage 0.17.2's warp() visits for resize - in = (out + 0.5) * in/out - 0.5 - applied to
+    the output of the same scipy.ndimage.gaussian_filter call skimage.transform.resize itself makes for anti-aliasing.  (scikit-image
+    is absent from this image, so this pins the arithmetic to scipy's code - the library skimage delegates the filter to - rather
+    than to the oracle's own loops; the golden g7 is regenerated with the real package wherever it is importable.)"""
+    from scipy import ndimage as ndi
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(5)
+    for (h, w), (oh, ow) in (((300, 260), (224, 224)), ((97, 131), (224, 224)), ((640, 512), (224, 224)), ((224, 224), (224, 224))):
+        img = rng.random((h, w, 3)) * 255.0
+        got = O.skimage_resize(img, (oh, ow))
+        fac = np.array([h / oh, w / ow, 1.0])
+        blur = ndi.gaussian_filter(img, np.maximum(0, (fac - 1) / 2), cval=0, mode="mirror")
+        rr = fac[0] * (np.arange(oh) + 0.5) - 0.5
+        cc = fac[1] * (np.arange(ow) + 0.5) - 0.5
+        R, Cc = np.meshgrid(rr, cc, indexing="ij")
+        ref = np.stack([ndi.map_coordinates(blur[..., ch], [R, Cc], order=1, mode="mirror") for ch in range(3)], -1)
+        assert np.abs(got - ref).max() < 1e-9 * 255, ((h, w), float(np.abs(got - ref).max()))
+
+
 # ---------------------------------------------------------------------------- the HIP kernels vs golden / oracle
 def _check_crop_kernel(device):
     from dynaboa_amd import datasets as D
