@@ -413,6 +413,25 @@ def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_pe
         return dict(value=None, error=f"{type(e).__name__}: {e}", config=note)
 
 
+def calibrate_gate_threshold(device, frames=3):
+    """A cos_sim_threshold at which the dynamic-BOA loop (dynaboa_benchmark.py:161-192) takes 2-3 extra upper-level steps per frame on
+    THIS synthetic stream, as it does on real video (the default 3.1e-4 never opens it here): a few frames with the gate forced open
+    (threshold -1: every frame takes all optim_steps), then the median over frames of the geometric mean of 1 - cos(feature 12) at the
+    checks after extra steps 2 and 3."""
+    rn = Runner(device, 1, 1, 1, frames, frame_base=700_000, full_losses=1, cos_sim_threshold=-1.0)
+    st = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(st):
+        for s_ in range(frames):
+            rn.step(s_)
+        rn.flush()
+    torch.cuda.synchronize()
+    nat = rn.ad._native
+    gl = nat.gate_log[0, :frames, :, 12].detach().cpu().numpy().astype(np.float64)       # [frame][check] cos of feature 12
+    d = np.maximum(1.0 - gl, 1e-12)
+    thr = float(np.median(np.sqrt(d[:, 2] * d[:, 3])))
+    return thr, d.tolist()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -697,6 +716,21 @@ def main():
                 "exemplars + dynamic-BOA gate decided per sequence) for 32 sequences in lockstep on this GPU: teacher forward, history-frame "
                 "pass and exemplar pass are replica-batched launches; a sequence whose gate has closed leaves the launch set of the "
                 "remaining extra steps", roofline_peak=PEAK_FP32_MFMA_TFLOPS, seqs=32, full_losses=1)
+            torch.cuda.empty_cache()
+            # the same two configurations with the dynamic loop actually ENTERED: threshold calibrated on this stream
+            try:
+                thr, dtab = calibrate_gate_threshold(device)
+                note = ("the reference's default flags with cos_sim_threshold = %.3e (calibrated on this synthetic stream so that the dynamic-BOA "
+                        "loop takes 2-3 extra upper-level steps per frame, as on real video; with the default 3.1e-4 it never opens here)" % thr)
+                out["full_default_losses_dynamic"] = sub_record(device, "full_default_losses_dynamic", 16, 4, 1, 1, note, full_losses=1,
+                                                                cos_sim_threshold=thr)
+                torch.cuda.empty_cache()
+                out["full_default_losses_dynamic_S32"] = sub_record(device, "full_default_losses_dynamic_S32", 8, 2, 1, 1, note + "; 32 sequences in "
+                                                                    "lockstep, the gate decided per sequence", roofline_peak=None, seqs=32, full_losses=1,
+                                                                    cos_sim_threshold=thr)
+                out["full_default_losses_dynamic"]["one_minus_cos12_by_check"] = dtab
+            except Exception as e:      # noqa: BLE001
+                out["full_default_losses_dynamic"] = dict(value=None, error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
             out["second_order_full_losses_exact_hvp"] = sub_record(
                 device, "so_full_exact", 4, 1, 1, 1, "the reference's default term set in second-order mode with exact Hessian-vector "

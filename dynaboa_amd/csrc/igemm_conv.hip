@@ -1139,9 +1139,9 @@ struct DybSwitches {
     tp_occ = env("DYB_TP_OCC", 0);
     tp_gn_onepass = env("DYB_TP_GN_ONEPASS", 2);
     tp_gn_cap = env("DYB_TP_GN_CAP", 0);
-    tp_gn_threads = env("DYB_TP_GN_THREADS", 256);
+    tp_gn_threads = env("DYB_TP_GN_THREADS", 1024);
     tp_gn_fuse_stats = env("DYB_TP_GN_FUSE_STATS", 1);
-    tp_gn_poll = env("DYB_TP_GN_POLL", 1);
+    tp_gn_poll = env("DYB_TP_GN_POLL", 8);
   }
 };
 static DybSwitches& switches() {

@@ -845,8 +845,10 @@ int dyb_zero_words(unsigned* p, int n, hipStream_t st) {
   return DYB_OK;
 }
 // chunks per (image, group) slab of the one-pass backward, 0 = the shape does not qualify.  `cap` = float4 per workgroup: a
-// workgroup of T work-items holds T * OP_IT; 0 = the policy's workgroup size ("tp_gn_threads": 256 - four workgroups per CU in
-// different phases; 512 and 1024 measured slower) - the tests force several chunks on small shapes with small caps
+// workgroup of T work-items holds T * OP_IT; 0 = the policy's workgroup size ("tp_gn_threads", 1024: alone on the chip it is 1.3 -
+// 1.5x faster than 256 on every layer shape - 3.0 - 4.9 TB/s, the wait costing 3 - 5 % - and needs no poll spacing; beside the
+// weight-gradient queue the two measure the same, profiles/r04_gn_lab.txt) - the tests force several chunks on small shapes with
+// small caps
 static int onepass_threads(int cap) {
   if (cap <= 0) {
     const int t = dyb_tp_gn_threads();
