@@ -128,7 +128,10 @@ def conv_roofline(run, lo, hi, main_stream):
         buf = ctypes.create_string_buffer(int(need))
         lib.dyb_conv_timing_table(buf, need)
         table = buf.value.decode()
+    union_ms = float(lib.dyb_conv_timing_union_ms()) if hasattr(lib, "dyb_conv_timing_union_ms") else None
     return dict(table=table, achieved=flop.value / (ms.value * 1e-3) / 1e12, conv_ms_per_frame=ms.value / nfr,
+                union_ms_per_frame=(union_ms / nfr if union_ms else None),
+                achieved_while_running=(flop.value / (union_ms * 1e-3) / 1e12 if union_ms else None),
                 launches_per_frame=n.value / nfr, avg_launch_us=ms.value * 1e3 / n.value,
                 gflop_per_frame=flop.value / nfr / 1e9, algorithmic_bytes_per_launch=nbytes.value / n.value,
                 sample_frames=nfr)
@@ -607,6 +610,13 @@ def main():
                                          "weight-gradient streams; a launch covers all sequences of the step), timed on its own dispatch "
                                          "inside the path",
                                "sample_steps": r["sample_frames"], "sample_frames": fr,
+                               "achieved_while_convs_run": r.get("achieved_while_running"),
+                               "frac_while_convs_run": (r["achieved_while_running"] / PEAK_FP32_MFMA_TFLOPS) if r.get("achieved_while_running") else None,
+                               "conv_busy_ms_per_step": r.get("union_ms_per_frame"),
+                               "while_convs_run_note": "data- and weight-gradient launches run on two queues and share the chip, so their durations (the "
+                                                       "denominator of `achieved`) add up to more than the time the chip spends on convolutions; "
+                                                       "achieved_while_convs_run divides the same algorithmic flops by the UNION of the launches' "
+                                                       "[start, stop] intervals (same HIP events)",
                                "avg_launch_us": r["avg_launch_us"], "launches_per_step": r["launches_per_frame"],
                                "conv_ms_per_step": r["conv_ms_per_frame"], "algorithmic_gflop_per_frame": r["gflop_per_frame"] / seqs,
                                "whole_frame_tflops_on_min_schedule": MIN_SCHEDULE_GFLOP * value / world / 1e3,

@@ -28,6 +28,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -1243,6 +1244,7 @@ struct IgemmTiming {
   double flop = 0.0, bytes = 0.0;
 };
 static std::string g_timing_table;             // per-shape table of the last closed scope (dyb_conv_timing_table)
+static double g_timing_union_ms = 0.0;         // of the last closed scope: time during which at least one timed launch was running
 static IgemmTiming* g_timing = nullptr;
 static std::mutex g_timing_mu;
 
@@ -1277,6 +1279,29 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
     Row& row = rows[key];
     row.ms += one; row.flop += r.flop; row.n += 1;
   }
+  // union of the launches' [start, stop] intervals (launches on the two queues overlap: their durations add up to more than the time
+  // the chip spent on convolutions)
+  {
+    std::vector<std::pair<float, float>> iv;
+    for (size_t i = 0; i + 1 < t->used; i += 2) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, t->ev[0], t->ev[i]) != hipSuccess || hipEventElapsedTime(&b, t->ev[0], t->ev[i + 1]) != hipSuccess) continue;
+      iv.emplace_back(a, b);
+    }
+    std::sort(iv.begin(), iv.end());
+    double u = 0.0;
+    float lo = 0.f, hi = -1.f;
+    for (const auto& p : iv) {
+      if (hi < 0.f || p.first > hi) {
+        if (hi >= 0.f) u += hi - lo;
+        lo = p.first; hi = p.second;
+      } else if (p.second > hi) {
+        hi = p.second;
+      }
+    }
+    if (hi >= 0.f) u += hi - lo;
+    g_timing_union_ms = u;
+  }
   g_timing_table = "kind,N,H,W,C,K,R,stride,pad,nsplit,nrep,launches,ms_total,gflop_total\n";
   for (const auto& kv : rows) {
     char tail[96];
@@ -1289,6 +1314,11 @@ extern "C" int dyb_conv_timing_end(double* ms_total, long long* launches, double
   return DYB_OK;
 }
 
+// of the scope closed last: milliseconds during which at least one timed conv launch was executing (union of the launches' intervals)
+extern "C" double dyb_conv_timing_union_ms() {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  return g_timing_union_ms;
+}
 // Per-shape table of the scope closed last (CSV, header line first): kind f/d/w (t/u/v: throughput form) = tiled forward / data gradient / weight
 // gradient, F/D = the single-launch 1x1 kernels; returns the bytes needed including the terminator.
 extern "C" size_t dyb_conv_timing_table(char* buf, size_t cap) {

@@ -10,7 +10,9 @@
  *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the library never
  *     allocates, frees or retains caller memory; scratch is passed in (`ws`, size from the
  *     matching *_workspace_bytes);
- *   - everything is enqueued on `stream` in order; no call synchronises the host;
+ *   - everything is enqueued on `stream` in order; no call synchronises the host - with ONE exception, stated where it occurs:
+ *     dyb_stepper_adapt_frame_full / _frames_full with the dynamic-BOA gate on poll device-written pinned memory once per gate
+ *     check (the reference's `.item()`, dynaboa_benchmark.py:165) to decide which sequences take a further step;
  *   - return value: 0 = ok, -1 bad argument, -2 launch failure, -3 unsupported shape,
  *     -4 workspace too small;
  *   - one host thread per GPU process; re-entrant across different streams + workspaces.
@@ -123,6 +125,7 @@ int dyb_conv_timing_end(double* ms_total, long long* launches, double* flop, dou
  * weight gradient kernel, F/D = the single-launch 1x1 kernels).  Copies at most cap-1 bytes + terminator into buf; returns
  * the size needed.  tools/conv_table.py prints it. */
 size_t dyb_conv_timing_table(char* buf, size_t cap);
+double dyb_conv_timing_union_ms(void); /* of the scope closed last: time during which at least one timed launch was executing */
 /* Diagnostic: while set (buf != NULL), launches of the throughput-form conv kernel whose mode (0 forward, 1 data gradient,
  * 2 weight gradient) and layer (H, C, K, R) match write per-wave phase clocks into buf ([workgroup][4 waves][8] 64-bit words,
  * cap_wgs workgroups of room; layout in igemm_conv.hip).  bench.py --probe / tools/tp_probe.py read it.  buf = NULL clears. */
