@@ -389,6 +389,7 @@ def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_pe
     """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each; with
     roofline_peak (TFLOP/s) also the conv family's in-path achieved rate against that peak (2 extra steps).  seqs > 1: that many
     sequences in lockstep (a ReplicaGroup), value = aggregate frames/s."""
+    t_sub = time.perf_counter()
     try:
         extra = 2 if roofline_peak else 0
         rn = Runner(device, seqs, batch, inner_step, warmup + steps + extra, frame_base=500_000, **kw)
@@ -411,16 +412,17 @@ def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_pe
                 out["roofline"] = dict(bound="mfma", achieved=c["achieved"], peak=roofline_peak, unit="TFLOP/s",
                                        frac=c["achieved"] / roofline_peak, avg_launch_us=c["avg_launch_us"],
                                        conv_ms_per_step=c["conv_ms_per_frame"])
+        print("[bench] side run %s: %.1f s" % (name, time.perf_counter() - t_sub), file=sys.stderr)
         return out
     except Exception as e:      # noqa: BLE001
         return dict(value=None, error=f"{type(e).__name__}: {e}", config=note)
 
 
-def calibrate_gate_threshold(device, frames=3):
+def calibrate_gate_threshold(device, frames=5):
     """A cos_sim_threshold at which the dynamic-BOA loop (dynaboa_benchmark.py:161-192) takes 2-3 extra upper-level steps per frame on
     THIS synthetic stream, as it does on real video (the default 3.1e-4 never opens it here): a few frames with the gate forced open
-    (threshold -1: every frame takes all optim_steps), then the median over frames of the geometric mean of 1 - cos(feature 12) at the
-    checks after extra steps 2 and 3."""
+    (threshold -1: every frame takes all optim_steps), then the median over frames of 1 - cos(feature 12) at the check after the third
+    extra step (frames whose feature still moves more than that continue)."""
     rn = Runner(device, 1, 1, 1, frames, frame_base=700_000, full_losses=1, cos_sim_threshold=-1.0)
     st = torch.cuda.Stream(device=device)
     with torch.cuda.stream(st):
@@ -431,7 +433,7 @@ def calibrate_gate_threshold(device, frames=3):
     nat = rn.ad._native
     gl = nat.gate_log[0, :frames, :, 12].detach().cpu().numpy().astype(np.float64)       # [frame][check] cos of feature 12
     d = np.maximum(1.0 - gl, 1e-12)
-    thr = float(np.median(np.sqrt(d[:, 2] * d[:, 3])))
+    thr = float(np.median(d[:, 3]))
     return thr, d.tolist()
 
 
@@ -462,7 +464,7 @@ def main():
                     help="split the --seqs sequences into this many lockstep groups, each issued by its own host thread on its own stream")
     ap.add_argument("--replicas", type=str, default="1,2,4,5,8,16,48,64",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
-    ap.add_argument("--percentile_frames", type=int, default=200, help="frames of the per-frame-time pass when --steps < 200")
+    ap.add_argument("--percentile_frames", type=int, default=80, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--probe", type=str, default="", help="mode,H,C,K,R: phase clocks of the throughput conv kernel for that layer (diagnostic)")
     ap.add_argument("--probe_out", type=str, default="")
     ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")

@@ -269,6 +269,7 @@ struct Stepper {
   // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
   // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
   int upd_overlap = 1;
+  int upd_blocks = 1024;           // workgroups (all replicas together) of the ranged passes on the auxiliary stream, beside the forward's convolutions
   hipEvent_t e_upd = nullptr;
   DybFwdGates gates{};
   bool gates_pending = false;
@@ -396,6 +397,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   S->ev = dyb_hmr_events_create(plan);
   dyb_hmr_param_groups(plan, S->grp_bounds);
   if (const char* e = getenv("DYB_UPD_OVERLAP")) S->upd_overlap = atoi(e);       // (A/B runs; set_i "upd_overlap" afterwards wins)
+  if (const char* e = getenv("DYB_UPD_BLOCKS")) S->upd_blocks = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
@@ -431,6 +433,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "eval_lower") S->eval_lower = (int)v;
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "upd_overlap") S->upd_overlap = (int)v;
+  else if (k == "upd_blocks") S->upd_blocks = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -710,10 +713,13 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   RUN(range(0, S.grp_bounds[0], st));
   HIPOK(hipEventRecord(S.e_upd, st));                 // the gradients' main-stream writers (and the first range) are behind this point
   HIPOK(hipStreamWaitEvent(aux, S.e_upd, 0));
-  RUN(range(S.grp_bounds[0], S.grp_bounds[1], aux));
-  HIPOK(hipEventRecord(S.gates.ev[0], aux));
-  RUN(range(S.grp_bounds[1], S.n_params, aux));
-  HIPOK(hipEventRecord(S.gates.ev[1], aux));
+  {
+    DybStreamCapScope cap(S.upd_blocks / R.n > 0 ? S.upd_blocks / R.n : 1);      // upd_blocks = workgroups over ALL replicas of the launch
+    RUN(range(S.grp_bounds[0], S.grp_bounds[1], aux));
+    HIPOK(hipEventRecord(S.gates.ev[0], aux));
+    RUN(range(S.grp_bounds[1], S.n_params, aux));
+    HIPOK(hipEventRecord(S.gates.ev[1], aux));
+  }
   S.gates_pending = true;
   return DYB_OK;
 }

@@ -138,6 +138,13 @@ struct DybBf16Scope {
   ~DybBf16Scope();
 };
 
+// workgroup cap of the flat-arena streaming launches of the calling host thread (optim.hip)
+struct DybStreamCapScope {
+  int saved;
+  explicit DybStreamCapScope(int cap);
+  ~DybStreamCapScope();
+};
+
 // ---- cross-file internals (not part of the C ABI) ----------------------------------------
 struct ConvDesc {
   int N, H, W, C, K, R, S, stride, pad;

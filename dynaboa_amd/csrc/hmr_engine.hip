@@ -258,8 +258,8 @@ static HmrPlan* build_plan(int B, int H, int W) {
   P.ws_gnb = gnboff * 4;
   P.ws_lin = align64(wl / 4) * 4;
   P.ws_grad_each = align64(maxact) * 4;
-  // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208]
-  P.ws_reg = align64((size_t)B * (4 * STATE_LD + 6 * HID + FC1_IN_PAD)) * 4;
+  // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208], two [B][1024] for sum_t d_h1[t]
+  P.ws_reg = align64((size_t)B * (4 * STATE_LD + 8 * HID + FC1_IN_PAD)) * 4;
   // arrival counters of the one-pass GroupNorm backward: SYNC_WORDS per conv layer (4 groups + the error word), zeroed per backward
   P.ws_sync = align64(P.convs.size() * SYNC_WORDS) * 4;
   P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg + P.ws_dy2 + P.ws_sync;
@@ -592,10 +592,15 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   float* dsts[MAX_ITER];
   for (int t = 0; t < n_iter; ++t) dsts[t] = acts + P.a_xc[t];
   RUN(dyb_avgpool_fwd_tail(x, dsts, n_iter, FC1_IN_PAD, B, P.featHW, FEAT, init_state, STATE_LD, STATE_LD, FEAT, st));
+  // fc1 over xc = [pooled feature (2048) | state (157)]: the feature is the same in every iteration, so its 93 % of the weight
+  // matrix is streamed ONCE per forward (pre = b + W[:, :2048] feat) and each iteration adds the state columns' product
+  // (model/hmr.py:160-163; at 32 sequences fc1 is 289 MB per pass)
+  float* fc1_pre = reinterpret_cast<float*>(w.lin);
+  RUN(dyb_linear_fwd(acts + P.a_xc[0], FC1_IN_PAD, params + P.fc1_w, FC1_IN_PAD, params + P.fc1_b, nullptr, 0, fc1_pre, HID, B, FEAT, HID, st));
   for (int t = 0; t < n_iter; ++t) {
     const float* xc = acts + P.a_xc[t];
-    RUN(dyb_linear_fwd(xc, FC1_IN_PAD, params + P.fc1_w, FC1_IN_PAD, params + P.fc1_b, nullptr, 0, acts + P.a_h1[t], HID, B,
-                       FC1_IN_PAD, HID, st));
+    RUN(dyb_linear_fwd(xc + FEAT, FC1_IN_PAD, params + P.fc1_w + FEAT, FC1_IN_PAD, nullptr, fc1_pre, HID, acts + P.a_h1[t], HID, B,
+                       FC1_IN_PAD - FEAT, HID, st));
     // train mode: xc = drop1(fc1(xc)); xc = drop2(fc2(xc)) (model/hmr.py:163-169); eval: Dropout is the identity
     const float* h1 = acts + P.a_h1[t];
     if (drop.on) {
@@ -866,8 +871,21 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
     RUN(dyb_linear_bwd_dx(d_h2[t], HID, params + P.fc2_w, HID, B, HID, HID, d_h1[t], HID, 0, HID, nullptr, 0, nullptr, 0,
                           w.lin, P.ws_lin, st));
     if (drop.on) RUN(dropout_launch(d_h1[t], d_h1[t], B * HID, drop, 2u * t, st));            // through drop1
-    RUN(dyb_linear_bwd_dx(d_h1[t], HID, params + P.fc1_w, FC1_IN_PAD, B, FC1_IN_PAD, HID, d_xf, FC1_IN_PAD,
-                          t < n_iter - 1 ? 1 : 0, FEAT, d_st[t], STATE_LD, d_st[t + 1], STATE_LD, w.lin, P.ws_lin, st));
+    // through fc1: the state columns per iteration (d_st[t] = W[:, 2048:]^T d_h1[t] + d_st[t + 1]); the feature columns once, below
+    RUN(dyb_linear_bwd_dx(d_h1[t], HID, params + P.fc1_w + FEAT, FC1_IN_PAD, B, FC1_IN_PAD - FEAT, HID, d_st[t], STATE_LD, 0, 0, d_st[t],
+                          STATE_LD, d_st[t + 1], STATE_LD, w.lin, P.ws_lin, st));
+  }
+  {
+    // d_xf = W[:, :2048]^T (sum_t d_h1[t]): one pass over the feature columns instead of one per iteration
+    float* sbuf[2] = {d_xf + (size_t)B * FC1_IN_PAD, d_xf + (size_t)B * (FC1_IN_PAD + HID)};     // two [B][1024] behind d_xf in the regressor scratch
+    const float* dsum = d_h1[0];
+    for (int t = 1; t < n_iter; ++t) {                       // (ping-pong: the add kernel's operands may not alias its result)
+      float* o = sbuf[t & 1];
+      RUN(dyb_scale_add(nullptr, dsum, d_h1[t], o, (size_t)B * HID, st));
+      dsum = o;
+    }
+    RUN(dyb_linear_bwd_dx(dsum, HID, params + P.fc1_w, FC1_IN_PAD, B, FEAT, HID, d_xf, FC1_IN_PAD, 0, FEAT, nullptr, 0, nullptr, 0, w.lin,
+                          P.ws_lin, st));
   }
   {
     const float *dys[MAX_ITER], *xs[MAX_ITER];

@@ -1122,7 +1122,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1143,6 +1143,7 @@ struct DybSwitches {
     tp_gn_threads = env("DYB_TP_GN_THREADS", 1024);
     tp_gn_fuse_stats = env("DYB_TP_GN_FUSE_STATS", 1);
     tp_gn_poll = env("DYB_TP_GN_POLL", 8);
+    tp_fwd_nosplit2 = env("DYB_TP_FWD_NOSPLIT2", 1);
   }
 };
 static DybSwitches& switches() {
@@ -1172,6 +1173,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_gn_threads")) return &s.tp_gn_threads;
   if (!strcmp(name, "tp_gn_fuse_stats")) return &s.tp_gn_fuse_stats;
   if (!strcmp(name, "tp_gn_poll")) return &s.tp_gn_poll;
+  if (!strcmp(name, "tp_fwd_nosplit2")) return &s.tp_fwd_nosplit2;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1466,6 +1468,17 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   const int maxs = g.ktiles / 4 > 0 ? g.ktiles / 4 : 1;                 // every split keeps >= 4 K-steps
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
+  // forward, one image: an unsplit launch leaves the output's GroupNorm statistics with its tiles (no statistics launch, no slabs to
+  // write and fold) - worth more than the second workgroup per CU a split of two would buy ("tp_fwd_nosplit2")
+  bool stats_fusable = false;
+  int stats_records = 0;
+  if (mode == MODE_FWD && stats_part && stats_nrec && d.N == 1 && d.K >= 64 && d.K <= 2048 &&
+      switches().tp_gn_fuse_stats.load(std::memory_order_relaxed)) {
+    stats_records = mtiles * dyb_cdiv(g.Ncols, TN) * (TM / 64) * (TN / 64);
+    const int HWo = g.Ho * g.Wo;
+    stats_fusable = stats_records <= (HWo < 256 ? HWo : 256);
+  }
+  if (stats_fusable && s == 2 && switches().tp_fwd_nosplit2.load(std::memory_order_relaxed)) s = 1;
   const size_t per = (size_t)g.slab_rows * g.Ncols, ws_floats = ws ? ws_bytes / sizeof(float) : 0;
   while (s > 1 && (size_t)s * per > ws_floats) --s;
   g.nsplit = s;
@@ -1478,14 +1491,9 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.gn_part = nullptr;
   if (stats_nrec) *stats_nrec = 0;
-  if (mode == MODE_FWD && stats_part && stats_nrec && !split && d.N == 1 && d.K >= 64 && d.K <= 2048 &&
-      switches().tp_gn_fuse_stats.load(std::memory_order_relaxed)) {
-    const int nrec = (int)(grid.x * grid.y) * (TM / 64) * (TN / 64);
-    const int HWo = g.Ho * g.Wo;
-    if (nrec <= (HWo < 256 ? HWo : 256)) {
-      g.gn_part = stats_part;
-      *stats_nrec = nrec;
-    }
+  if (stats_fusable && !split) {
+    g.gn_part = stats_part;
+    *stats_nrec = stats_records;
   }
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     // bias (+ residual) fetched up front by every lane (same address: one broadcast line), not by lane 0 after the
     // reduction - there it would be two more dependent round trips at the end of a 5 us kernel
     {
-      const float bo = bias[o];
+      const float bo = bias ? bias[o] : 0.f;
 #pragma unroll
       for (int t = 0; t < LIN_BT; ++t) {
         const int bb = b0 + t < B ? b0 + t : B - 1;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 
 extern "C" int dyb_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* res,
                               int ldres, float* y, int ldy, int B, int I, int O, hipStream_t st) {
-  DYB_REQUIRE(x && w && bias && y && B > 0 && O > 0, DYB_ERR_ARG);
+  DYB_REQUIRE(x && w && y && B > 0 && O > 0, DYB_ERR_ARG);          // (bias may be NULL: a partial product added to `res`)
   DYB_REQUIRE(I % 4 == 0 && ldw % 4 == 0 && ldx % 4 == 0, DYB_ERR_UNSUPPORTED);
   const DybRep& R = dyb_rep_current();
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(dyb_cdiv(O, 4), 1, R.n), dim3(256), 0, st, x, ldx, w, ldw, bias, res, ldres, y, ldy,

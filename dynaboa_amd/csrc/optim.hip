@@ -11,9 +11,15 @@
 //   cosine       : F.cosine_similarity(a.flatten(), b.flatten(), dim=0, eps)   base_adaptor.py:211-219
 #include "dyb_common.h"
 
+// workgroups of a streaming launch: 2048, or the calling thread's cap (DybStreamCapScope: a pass that runs BESIDE convolutions on
+// another queue takes fewer - it only has to finish before its consumer, and 2048 light workgroups would fill every workgroup
+// slot of the chip in front of the convolutions' own)
+static thread_local int t_stream_cap = 2048;
+DybStreamCapScope::DybStreamCapScope(int cap) : saved(t_stream_cap) { t_stream_cap = cap > 0 ? cap : 2048; }
+DybStreamCapScope::~DybStreamCapScope() { t_stream_cap = saved; }
 static int stream_blocks(size_t n4) {
   size_t b = (n4 + 255) / 256;
-  if (b > 2048) b = 2048;
+  if (b > (size_t)t_stream_cap) b = (size_t)t_stream_cap;
   if (b < 1) b = 1;
   return (int)b;
 }

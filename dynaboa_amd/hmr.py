@@ -180,6 +180,10 @@ def hmr_apply(theta, image, init_state, n_iter=3, need_feature=False, drop=None)
     return out[0], out[1], out[2]
 
 
+_INIT_CACHE: dict = {}      # (seed, mean-parameter hashes) -> (packed arena, init_pose, init_shape, init_cam), one entry
+_PACK_CACHE: dict = {}      # the last complete checkpoint packed: keep (its tensors), sig (addresses + versions), packed
+
+
 class HMR(nn.Module):
     """SMPL iterative regressor with ResNet-50(GroupNorm) backbone; parameters live in one arena."""
     dropout_p = 0.5        # nn.Dropout() default, reference model/hmr.py:84,86
@@ -192,12 +196,21 @@ class HMR(nn.Module):
         else:
             mp = smpl_mean_params
         self._layout1 = get_layout(1)
-        sd = assets.make_synthetic_checkpoint(seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,))),
-                                              {k: np.asarray(v, np.float32) for k, v in mp.items()}, prefix="")["model"]
-        self.theta = nn.Parameter(self._layout1.pack(sd))
-        self.register_buffer("init_pose", sd["init_pose"].clone())
-        self.register_buffer("init_shape", sd["init_shape"].clone())
-        self.register_buffer("init_cam", sd["init_cam"].clone())
+        mpf = {k: np.asarray(v, np.float32) for k, v in mp.items()}
+        # a seeded initialisation is a pure function of (seed, mean parameters): drivers that build many models (sequence
+        # replicas, the bench's side runs) get it from a one-entry cache instead of 0.15 s of torch.randn + packing each
+        key = None if seed is None else (int(seed),) + tuple(hash(mpf[k].tobytes()) for k in ("pose", "shape", "cam"))
+        hit = _INIT_CACHE.get(key) if key is not None else None
+        if hit is None:
+            sd = assets.make_synthetic_checkpoint(seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,))), mpf, prefix="")["model"]
+            hit = (self._layout1.pack(sd), sd["init_pose"].clone(), sd["init_shape"].clone(), sd["init_cam"].clone())
+            if key is not None:
+                _INIT_CACHE.clear()
+                _INIT_CACHE[key] = hit
+        self.theta = nn.Parameter(hit[0].clone())
+        self.register_buffer("init_pose", hit[1].clone())
+        self.register_buffer("init_shape", hit[2].clone())
+        self.register_buffer("init_cam", hit[3].clone())
 
     # ---- reference-named checkpoint I/O --------------------------------------------------------
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False, **kw):
@@ -215,12 +228,22 @@ class HMR(nn.Module):
         unexpected = [k for k in state_dict if k not in want]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for HMR: missing {missing[:5]} unexpected {unexpected[:5]}")
-        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        cur = self.state_dict()
-        for k in missing:
-            sd[k] = cur[k].cpu()
+        # the same checkpoint dict loaded again (every sequence replica / side run loads the bundle's): its packed arena is kept,
+        # keyed on the tensors' storage addresses and versions (the tensors are kept alive by the cache entry)
+        sig = tuple((k, state_dict[k].data_ptr(), state_dict[k]._version) for k in want) if not missing else None
+        if sig is not None and _PACK_CACHE.get("sig") == sig:          # (the cache keeps those tensors alive: their addresses cannot be reused)
+            packed, sd = _PACK_CACHE["packed"], {b: state_dict[b].detach().cpu() for b in ("init_pose", "init_shape", "init_cam")}
+        else:
+            sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+            if missing:
+                cur = self.state_dict()
+                for k in missing:
+                    sd[k] = cur[k].cpu()
+            packed = self._layout1.pack(sd)
+            if sig is not None:
+                _PACK_CACHE.update(keep=[state_dict[k] for k in want], sig=sig, packed=packed)
         with torch.no_grad():
-            self.theta.copy_(self._layout1.pack(sd).to(self.theta.device))
+            self.theta.copy_(packed.to(self.theta.device))
             for b in ("init_pose", "init_shape", "init_cam"):
                 getattr(self, b).copy_(sd[b].reshape(getattr(self, b).shape).to(self.theta.device))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
