@@ -269,7 +269,10 @@ class Runner:
         """The same step with the frame's inputs handed over as pinned HOST buffers (what the reference's loop does every frame,
         dynaboa_benchmark.py:86 `.to(device)`): upload on the issuing stream, then the step."""
         dev = self.device
-        up = [{k: v.to(dev, non_blocking=True) for k, v in pinned[r][s].items()} for r in range(self.S)]
+        # one upload per input kind for all sequences of the step (a stacked pinned buffer), not one per sequence and kind
+        keys = list(pinned[0][s].keys())
+        stacked = {k: pinned["stack"][s][k].to(dev, non_blocking=True) for k in keys}
+        up = [{k: stacked[k][r] for k in keys} for r in range(self.S)]
         if self.grp is None:
             ad = self.ad
             ad.global_step = s
@@ -434,7 +437,26 @@ def calibrate_gate_threshold(device, frames=5):
     gl = nat.gate_log[0, :frames, :, 12].detach().cpu().numpy().astype(np.float64)       # [frame][check] cos of feature 12
     d = np.maximum(1.0 - gl, 1e-12)
     thr = float(np.median(d[:, 3]))
-    return thr, d.tolist()
+    # the forced run adapts harder than a gated one, so refine on gated probes: bisect the threshold (log scale) until a 6-frame probe
+    # takes 2-3 extra steps per frame on average
+    lo, hi, tried = thr / 4.0, thr * 1.5, []
+    for _ in range(5):
+        rn = Runner(device, 1, 1, 1, 6, frame_base=710_000, full_losses=1, cos_sim_threshold=thr)
+        with torch.cuda.stream(st):
+            for s_ in range(6):
+                rn.step(s_)
+            rn.flush()
+        torch.cuda.synchronize()
+        m = float(np.mean(rn.ad.optim_step_record)) if rn.ad.optim_step_record else 0.0
+        tried.append((thr, m))
+        if 2.0 <= m <= 3.0:
+            break
+        if m < 2.0:
+            hi = thr
+        else:
+            lo = thr
+        thr = float(np.sqrt(lo * hi))
+    return thr, dict(one_minus_cos12_by_check_forced=d.tolist(), probes=tried)
 
 
 def main():
@@ -462,7 +484,7 @@ def main():
                          "1 = the single-sequence latency configuration")
     ap.add_argument("--groups", type=int, default=1,
                     help="split the --seqs sequences into this many lockstep groups, each issued by its own host thread on its own stream")
-    ap.add_argument("--replicas", type=str, default="1,2,4,5,8,16,48,64",
+    ap.add_argument("--replicas", type=str, default="1,2,4,5,8,16,37,48,64",
                     help="comma list: sequences-per-GPU sweep carried as a sub-record (short runs)")
     ap.add_argument("--percentile_frames", type=int, default=80, help="frames of the per-frame-time pass when --steps < 200")
     ap.add_argument("--probe", type=str, default="", help="mode,H,C,K,R: phase clocks of the throughput conv kernel for that layer (diagnostic)")
@@ -645,7 +667,9 @@ def main():
         if n_h2d:
             # PCIe-inclusive rate (never `value`): the same steps with every frame's inputs uploaded from pinned host memory inside the clock
             base = total + n_roof + n_pct
-            pinned = [{s_: {k: v.cpu().pin_memory() for k, v in rn.frames[r][s_].items()} for s_ in range(base, base + n_h2d)} for r in range(seqs)]
+            pinned = {r: {s_: rn.frames[r][s_] for s_ in range(base, base + n_h2d)} for r in range(seqs)}
+            pinned["stack"] = {s_: {k: torch.stack([rn.frames[r][s_][k] for r in range(seqs)]).cpu().pin_memory() for k in rn.frames[0][s_]}
+                               for s_ in range(base, base + n_h2d)}
             torch.cuda.synchronize()
             with torch.cuda.stream(main_stream):
                 rn.step_with_upload(base, pinned)                  # (first touch of the pinned buffers)
@@ -656,11 +680,11 @@ def main():
                 rn.flush()
             torch.cuda.synchronize()
             dth = time.perf_counter() - t0h
-            nb = sum(v.numel() * v.element_size() for v in pinned[0][base].values())
+            nb = sum(v.numel() * v.element_size() for v in pinned["stack"][base].values()) // seqs
             out["pcie_inclusive"] = {"value": (n_h2d - 1) * args.batch * seqs / dth, "unit": "adapted frames/s", "steps": n_h2d - 1,
                                      "ms_per_step": dth * 1e3 / (n_h2d - 1), "h2d_bytes_per_frame": nb,
                                      "note": "the headline loop with each frame's inputs (image, 2-D keypoints, ground-truth pose / shape / gender) "
-                                             "uploaded from pinned host memory on the issuing stream inside the clock, as the reference moves its "
+                                             "uploaded from pinned host memory (one stacked buffer per input kind and step) on the issuing stream inside the clock, as the reference moves its "
                                              "batch every frame (dynaboa_benchmark.py:86); `value` above has the inputs resident in HBM"}
             del pinned
         if world == 1 and not args.no_sub_records and simple and args.batch == 1:
@@ -740,7 +764,7 @@ def main():
                 out["full_default_losses_dynamic_S32"] = sub_record(device, "full_default_losses_dynamic_S32", 8, 2, 1, 1, note + "; 32 sequences in "
                                                                     "lockstep, the gate decided per sequence", roofline_peak=None, seqs=32, full_losses=1,
                                                                     cos_sim_threshold=thr)
-                out["full_default_losses_dynamic"]["one_minus_cos12_by_check"] = dtab
+                out["full_default_losses_dynamic"]["calibration"] = dtab
             except Exception as e:      # noqa: BLE001
                 out["full_default_losses_dynamic"] = dict(value=None, error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()

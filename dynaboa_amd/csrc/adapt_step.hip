@@ -269,7 +269,7 @@ struct Stepper {
   // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
   // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
   int upd_overlap = 1;
-  int upd_blocks = 1024;           // workgroups (all replicas together) of the ranged passes on the auxiliary stream, beside the forward's convolutions
+  int upd_blocks = 0;              // > 0: workgroup cap (all replicas together) of the ranged passes on the auxiliary stream (measured: no effect, 512 .. uncapped)
   hipEvent_t e_upd = nullptr;
   DybFwdGates gates{};
   bool gates_pending = false;
@@ -714,7 +714,7 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   HIPOK(hipEventRecord(S.e_upd, st));                 // the gradients' main-stream writers (and the first range) are behind this point
   HIPOK(hipStreamWaitEvent(aux, S.e_upd, 0));
   {
-    DybStreamCapScope cap(S.upd_blocks / R.n > 0 ? S.upd_blocks / R.n : 1);      // upd_blocks = workgroups over ALL replicas of the launch
+    DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / R.n > 0 ? S.upd_blocks / R.n : 1) : 0);   // upd_blocks = workgroups over ALL replicas
     RUN(range(S.grp_bounds[0], S.grp_bounds[1], aux));
     HIPOK(hipEventRecord(S.gates.ev[0], aux));
     RUN(range(S.grp_bounds[1], S.n_params, aux));

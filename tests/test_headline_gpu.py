@@ -147,3 +147,30 @@ def test_headline_32_sequences_one_frame(headline_switches):
         assert _rel(a.model.module.theta.detach(), singles[r][0]) < 5e-6, r
         assert _rel(st["exp_avg"], singles[r][1]) < 5e-3, r
         np.testing.assert_allclose(np.ravel(np.array(fl[r]["mpjpe"], np.float64)), np.ravel(np.array(singles[r][3]["mpjpe"], np.float64)), rtol=2e-3)
+
+
+def test_ranged_weight_updates_beside_the_forward_change_nothing(headline_switches, monkeypatch):
+    """Replica groups update the weights by arena ranges - [stem .. layer2] on the chain's stream, [layer3] and [layer4 + regressor] on
+    the auxiliary stream beside the next forward's first layers (adapt_step.hip weight_update) - and the forward waits for each range
+    before its first reader: two frames of S = 8 sequences with the ranged updates on (default) and off give the same weights and Adam
+    state bit for bit (same kernels, same per-element arithmetic; only the streams differ)."""
+    from dynaboa_amd import native_step as NS
+    S, NF = 8, 2
+    frames = _frames(S, NF)
+    outs = []
+    for ovl in ("1", "0"):
+        monkeypatch.setenv("DYB_UPD_OVERLAP", ovl)
+        ads = [_mk(r) for r in range(S)]
+        grp = NS.ReplicaGroup(ads, NF)
+        for step in range(NF):
+            grp.step([frames[r][step] for r in range(S)], step)
+        fl = grp.flush_metrics()
+        row = []
+        for r in range(S):
+            st = ads[r].optimizer.state[ads[r].model.module.theta]
+            row += [ads[r].model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                    torch.from_numpy(np.ravel(np.array(fl[r]["mpjpe"], np.float64)))]
+        outs.append(row)
+        del grp, ads
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
