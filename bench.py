@@ -437,17 +437,18 @@ def calibrate_gate_threshold(device, frames=5):
     gl = nat.gate_log[0, :frames, :, 12].detach().cpu().numpy().astype(np.float64)       # [frame][check] cos of feature 12
     d = np.maximum(1.0 - gl, 1e-12)
     thr = float(np.median(d[:, 3]))
-    # the forced run adapts harder than a gated one, so refine on gated probes: bisect the threshold (log scale) until a 6-frame probe
-    # takes 2-3 extra steps per frame on average
+    # the forced run adapts harder than a gated one, so refine on gated probes: bisect the threshold (log scale) until a probe takes 2-3
+    # extra steps per frame on average
     lo, hi, tried = thr / 4.0, thr * 1.5, []
-    for _ in range(5):
-        rn = Runner(device, 1, 1, 1, 6, frame_base=710_000, full_losses=1, cos_sim_threshold=thr)
+    for _ in range(6):
+        # (the probe IS the one-sequence side run below: same frames - sub_record's frame_base -, 4 warm-up + 16 counted frames)
+        rn = Runner(device, 1, 1, 1, 20, frame_base=500_000, full_losses=1, cos_sim_threshold=thr)
         with torch.cuda.stream(st):
-            for s_ in range(6):
+            for s_ in range(20):
                 rn.step(s_)
             rn.flush()
         torch.cuda.synchronize()
-        m = float(np.mean(rn.ad.optim_step_record)) if rn.ad.optim_step_record else 0.0
+        m = float(np.mean(rn.ad.optim_step_record[4:])) if len(rn.ad.optim_step_record) > 4 else 0.0
         tried.append((thr, m))
         if 2.0 <= m <= 3.0:
             break

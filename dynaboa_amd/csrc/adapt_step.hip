@@ -688,7 +688,7 @@ static int issue_side_work(Stepper& S, hipStream_t side) {
 // as one launch on `st`, or (upd_overlap, replica groups with an auxiliary stream) by arena ranges: [0, layer3) on `st`, [layer3,
 // layer4) and [layer4, end) on `aux` behind everything `st` has issued, each followed by its gate event; the next pass_forward waits
 // for them where it first reads those weights.
-static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipStream_t st, hipStream_t aux) {
+static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipStream_t st, hipStream_t aux, bool ema = false) {
   const DybRep& R = dyb_rep_current();
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
   if (adam) {
@@ -702,9 +702,13 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
     }
   }
   auto range = [&](size_t lo, size_t hi, hipStream_t s) -> int {
-    if (adam)
-      return dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps,
-                               hi - lo, s);
+    if (adam) {
+      RUN(dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps,
+                            hi - lo, s));
+      // update_teacher (base_adaptor.py:193-201) of the same range right behind it: the teacher's next reader is a forward too
+      if (ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
+      return DYB_OK;
+    }
     return dyb_fastweight_update(p + lo, S.grads + lo, out + lo, (float)S.fastlr, hi - lo, s);
   };
   const bool ranged = S.upd_overlap && S.nrep > 1 && aux && aux != st && S.grp_bounds[0] > 0 && S.grp_bounds[1] > S.grp_bounds[0] &&
@@ -929,10 +933,8 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   }
   return DYB_OK;
 }
-static int adam_and_teacher(Stepper& S, hipStream_t st) {
-  RUN(adam_scope(S, st));
-  if (S.use_teacher && S.teacher) RUN(dyb_ema_update(S.teacher, S.theta, (float)S.alpha, S.n_params, st));   // base_adaptor.py:193-201
-  return DYB_OK;
+static int adam_and_teacher(Stepper& S, hipStream_t st, hipStream_t aux) {
+  return weight_update(S, true, nullptr, nullptr, st, aux, S.use_teacher && S.teacher);      // Adam, then the teacher's EMA (base_adaptor.py:193-201)
 }
 // features of two forwards -> 15 cosines per replica of the current scope (device log row + host-visible copy); cos12[r] (indexed
 // by PHYSICAL replica) = cos[12] read from the host copy
@@ -1052,11 +1054,11 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
     // (the level's gradient is complete; the metric record of the previous inner step reads this level's forward)
     if (metrics && S.eval_lower && i > 0) RUN(record_metrics(S, P, gender, slot++, st));
     if (i < K) {
-      RUN(dyb_fastweight_update(cur, S.grads, S.theta_fast, (float)S.fastlr, S.n_params, st));
+      RUN(weight_update(S, false, cur, S.theta_fast, st, aux));
       cur = S.theta_fast;
     }
   }
-  RUN(adam_and_teacher(S, st));
+  RUN(adam_and_teacher(S, st, aux));
   const float* image = (const float*)C.in[IN_IMAGE];
   RUN(pass_forward(S, S.fin, S.theta, image, st));
   if (metrics) RUN(record_metrics(S, S.fin, gender, slot++, st));
@@ -1084,7 +1086,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
         DybRepScope scope(sub);
         C.level_row = K + step;
         RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
-        RUN(adam_and_teacher(S, st));
+        RUN(adam_and_teacher(S, st, aux));
         RUN(pass_forward(S, S.fin, S.theta, image, st));
         RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, cos12, st));
         if (metrics) RUN(record_metrics(S, S.fin, gender, slot, st));

@@ -1,7 +1,7 @@
 """Rotation conversions and the camera projection with the reference's names (``utils/geometry.py``): rot6d_to_rotmat (:47-61),
 rotation_matrix_to_angle_axis (:184-213), perspective_projection (:63-91) on HIP kernels with hand-derived backward;
-batch_rodrigues (:9-24) as a few tiny torch ops - it only converts the ground-truth pose of
-retrieved exemplars / metric targets, never a learned quantity."""
+batch_rodrigues (:9-24) on the rodrigues kernel when no gradient flows (it only converts the ground-truth pose of retrieved
+exemplars / metric targets, never a learned quantity), as a few torch ops otherwise."""
 from __future__ import annotations
 
 import torch
@@ -64,6 +64,14 @@ def rotation_matrix_to_angle_axis(R):
 
 
 def batch_rodrigues(theta):
+    """(N,3) axis-angle -> (N,3,3), utils/geometry.py:9-24 (through the unit quaternion, 1e-8 added before the norm).  Its callers
+    convert ground-truth poses (metric targets, retrieved exemplars): without a gradient to carry it is one launch of the library's
+    rodrigues kernel (what the native stepper issues); an input that requires grad takes the torch composition below."""
+    if not (torch.is_grad_enabled() and theta.requires_grad) and theta.dim() == 2 and theta.shape[1] == 3 and theta.numel() > 0:
+        t = theta.detach().contiguous().float()
+        R = torch.empty(t.shape[0], 3, 3, device=t.device)
+        check(_lib.load().dyb_rodrigues_fwd(t.data_ptr(), R.data_ptr(), t.shape[0], stream_of(t)), "dyb_rodrigues_fwd")
+        return R
     ang = (theta + 1e-8).norm(dim=1, keepdim=True)
     axis = theta / ang
     half = 0.5 * ang

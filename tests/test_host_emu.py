@@ -351,6 +351,54 @@ def test_replica_group_ranged_weight_updates_under_adversarial_stream_order(emu_
             assert torch.equal(a, b)
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~10 min under the emulator; set DYB_EMU_FULL=1")
+def test_full_term_replica_group_ranged_updates_under_adversarial_stream_order(emu_lib, monkeypatch):
+    """The reference's default term set for S = 2 replicas with the ranged weight updates (fast-weight step, Adam + the teacher's EMA by
+    arena ranges on the auxiliary stream) in the emulator's lazy stream mode, drained chain-first and auxiliary-stream-first: weights,
+    Adam state and teacher of the in-line run bit for bit."""
+    from types import SimpleNamespace
+    from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    raw = _lib.load()
+    S = 2
+    frames = [assets.make_frame(100 * r, 1, seed=22) for r in range(S)]
+    orig = NS.NativeStepper.adapt_frames_full
+    outs = []
+    for order in (None, 0, 1):
+        used = []
+
+        def wrapped(self, *a, order=order, used=used, **kw):
+            self._aux = SimpleNamespace(cuda_stream=1)          # any non-null handle is a second stream to the emulator
+            if order is None:
+                return orig(self, *a, **kw)
+            raw.emu_lazy(1)
+            try:
+                return orig(self, *a, **kw)
+            finally:
+                used.append(raw.emu_flush(order))
+                raw.emu_lazy(0)
+        monkeypatch.setattr(NS.NativeStepper, "adapt_frames_full", wrapped)
+        ads = []
+        for r in range(S):
+            o = DB.parser.parse_args([])
+            o.inner_step, o.interval, o.dynamic_boa, o.deferred_metrics = 1, 2, 0, 1     # (no dynamic-BOA gate: its host poll cannot run inside a lazy section)
+            ads.append(DB.Adaptor(o, synthetic_bundle(seed=22 + r, identity_pose=False, randomize_norm=True), device="cpu"))
+        grp = NS.ReplicaGroup(ads, 1)
+        assert grp.stepper.full
+        grp.step(frames, 0)
+        grp.flush_metrics()
+        if order is not None:
+            assert used == [2], used
+        row = []
+        for r in range(S):
+            st = ads[r].optimizer.state[ads[r].model.module.theta]
+            row += [ads[r].model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), ads[r].teacher.theta.detach().clone()]
+        outs.append(row)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
     assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None
