@@ -60,6 +60,13 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def chain_stream(device):
+    """The stream a frame chain is issued on.  DYB_CHAIN_PRIORITY (0 default, -1 = high): the chain is the critical path, the library's
+    auxiliary stream (weight gradients, ranged weight updates) has slack - a higher dispatch priority for the chain is an experiment
+    switch, see DESIGN.md 5."""
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get("DYB_CHAIN_PRIORITY", "0")))
+
+
 def pmc_traffic():
     """HBM bytes per launch (read + write) of the conv kernel family from the newest committed PMC summary
     (profiles/r*_pmc_igemm_traffic.json, written by tools/pmc_summarize.py from two rocprofv3 runs of THIS command:
@@ -252,7 +259,7 @@ class Runner:
             # against each other - one group's streaming phases (GroupNorm backward, optimiser) overlap another's convolutions
             self.grps = [NS.ReplicaGroup(self.ads[g * per:(g + 1) * per], nframes) for g in range(self.G)]
             self.grp = self.grps[0]
-            self.gstreams = [torch.cuda.Stream(device=device) for _ in range(self.G)] if self.G > 1 else None
+            self.gstreams = [chain_stream(device) for _ in range(self.G)] if self.G > 1 else None
             self.ad = self.ads[0]
 
     def step(self, s):
@@ -378,7 +385,7 @@ def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
     if S == 1:
         steps = max(steps, 200)
     rn = Runner(device, S, batch, inner_step, warmup + steps, rank=rank, frame_base=3_000, **kw)
-    r = timed_stream(rn, warmup, steps, torch.cuda.Stream(device=device), per_frame=(S == 1))
+    r = timed_stream(rn, warmup, steps, chain_stream(device), per_frame=(S == 1))
     out = dict(value=S * steps * batch / r["dt"], unit="adapted frames/s", seqs=S, steps=steps, warmup=warmup,
                ms_per_step=r["dt"] * 1e3 / steps, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
                pa_mpjpe_mm_synthetic_mean=pa_mean(r["metrics"]))
@@ -396,7 +403,7 @@ def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_pe
     try:
         extra = 2 if roofline_peak else 0
         rn = Runner(device, seqs, batch, inner_step, warmup + steps + extra, frame_base=500_000, **kw)
-        st = torch.cuda.Stream(device=device)
+        st = chain_stream(device)
         r = timed_stream(rn, warmup, steps, st)
         out = dict(value=seqs * steps * batch / r["dt"], unit="adapted frames/s", ms_per_step=r["dt"] * 1e3 / steps, steps=steps,
                    warmup=warmup, batch=batch, inner_step=inner_step, host_issue_ms_per_step=r["t_issue"] * 1e3 / steps,
@@ -427,7 +434,7 @@ def calibrate_gate_threshold(device, frames=5):
     (threshold -1: every frame takes all optim_steps), then the median over frames of 1 - cos(feature 12) at the check after the third
     extra step (frames whose feature still moves more than that continue)."""
     rn = Runner(device, 1, 1, 1, frames, frame_base=700_000, full_losses=1, cos_sim_threshold=-1.0)
-    st = torch.cuda.Stream(device=device)
+    st = chain_stream(device)
     with torch.cuda.stream(st):
         for s_ in range(frames):
             rn.step(s_)
@@ -448,7 +455,7 @@ def calibrate_gate_threshold(device, frames=5):
                 rn.step(s_)
             rn.flush()
         torch.cuda.synchronize()
-        m = float(np.mean(rn.ad.optim_step_record[4:])) if len(rn.ad.optim_step_record) > 4 else 0.0
+        m = float(np.mean(rn.ad.optim_step_record)) if rn.ad.optim_step_record else 0.0      # (over all 20 frames, as the side run reports it)
         tried.append((thr, m))
         if 2.0 <= m <= 3.0:
             break
@@ -457,6 +464,7 @@ def calibrate_gate_threshold(device, frames=5):
         else:
             lo = thr
         thr = float(np.sqrt(lo * hi))
+    thr = min(tried, key=lambda t: abs(t[1] - 2.5))[0]                  # the probed threshold closest to the target
     return thr, dict(one_minus_cos12_by_check_forced=d.tolist(), probes=tried)
 
 
@@ -533,7 +541,7 @@ def main():
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream
-    main_stream = torch.cuda.Stream(device=device)
+    main_stream = chain_stream(device)
     probe_buf = None
     if args.probe:
         from dynaboa_amd import _lib
@@ -781,7 +789,7 @@ def main():
             del rn
             torch.cuda.empty_cache()
             rn2 = Runner(device, s_real, args.batch, args.inner_step, 4 + 12, rank=rank, frame_base=500)
-            r2 = timed_stream(rn2, 4, 12, torch.cuda.Stream(device=device), dist)
+            r2 = timed_stream(rn2, 4, 12, chain_stream(device), dist)
             t = torch.tensor([r2["dt"]], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             if rank == 0:
