@@ -61,10 +61,10 @@ def csrc_sha16():
 
 
 def chain_stream(device):
-    """The stream a frame chain is issued on.  DYB_CHAIN_PRIORITY (0 default, -1 = high): the chain is the critical path, the library's
-    auxiliary stream (weight gradients, ranged weight updates) has slack - a higher dispatch priority for the chain is an experiment
-    switch, see DESIGN.md 5."""
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get("DYB_CHAIN_PRIORITY", "0")))
+    """The stream a frame chain is issued on: high dispatch priority (DYB_CHAIN_PRIORITY, -1 = high, 0 = normal) - the chain is the
+    critical path, the library's auxiliary stream (weight gradients, ranged weight updates; normal priority) has slack.  464.1 / 463.6
+    against 461.0 / 460.3 frames/s at 32 sequences in alternating runs (profiles/r04_sessions.txt s8)."""
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get("DYB_CHAIN_PRIORITY", "-1")))
 
 
 def pmc_traffic():

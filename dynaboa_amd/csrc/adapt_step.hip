@@ -273,6 +273,16 @@ struct Stepper {
   hipEvent_t e_upd = nullptr;
   DybFwdGates gates{};
   bool gates_pending = false;
+  int upd_late = 1;                // the last range (layer4 + regressor, 68 % of the parameters) is issued when the forward reaches layer3
+  struct LateUpd {                 // what gates.late needs to issue it
+    Stepper* S = nullptr;
+    bool adam = false, ema = false;
+    const float* p = nullptr;
+    float* out = nullptr;
+    hipStream_t aux = nullptr;
+    DybRep scope{};
+    float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
+  } late;
   size_t grp_bounds[2] = {0, 0};
   bool side_pending = false;
   // the final inference of a frame (side stream) is issued by the NEXT call, behind that frame's first level: the host cannot
@@ -398,12 +408,14 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   dyb_hmr_param_groups(plan, S->grp_bounds);
   if (const char* e = getenv("DYB_UPD_OVERLAP")) S->upd_overlap = atoi(e);       // (A/B runs; set_i "upd_overlap" afterwards wins)
   if (const char* e = getenv("DYB_UPD_BLOCKS")) S->upd_blocks = atoi(e);
+  if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_upd, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->gates.ev[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&S->gates.ev[1], hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&S->gates.ev[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&S->gates.mid, hipEventDisableTiming) != hipSuccess) {
     delete S;
     return DYB_ERR_LAUNCH;
   }
@@ -420,6 +432,7 @@ extern "C" void dyb_stepper_destroy(void* stepper) {
   if (S->e_upd) (void)hipEventDestroy(S->e_upd);
   if (S->gates.ev[0]) (void)hipEventDestroy(S->gates.ev[0]);
   if (S->gates.ev[1]) (void)hipEventDestroy(S->gates.ev[1]);
+  if (S->gates.mid) (void)hipEventDestroy(S->gates.mid);
   delete S;
 }
 
@@ -434,6 +447,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "upd_overlap") S->upd_overlap = (int)v;
   else if (k == "upd_blocks") S->upd_blocks = (int)v;
+  else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -684,6 +698,24 @@ static int issue_side_work(Stepper& S, hipStream_t side) {
   return DYB_OK;
 }
 // Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
+// the deferred last range of a ranged weight update (see weight_update): issued from inside the consuming forward at layer3
+static int late_update(void* user) {
+  Stepper& S = *reinterpret_cast<Stepper*>(user);
+  Stepper::LateUpd& L = S.late;
+  DybRepScope scope(L.scope);
+  const size_t lo = S.grp_bounds[1], n = S.n_params - lo;
+  HIPOK(hipStreamWaitEvent(L.aux, S.gates.mid, 0));
+  DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / L.scope.n > 0 ? S.upd_blocks / L.scope.n : 1) : 0);
+  if (L.adam) {
+    RUN(dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, L.ss, L.bc, (float)S.eps, n, L.aux));
+    if (L.ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
+  } else {
+    RUN(dyb_fastweight_update(L.p + lo, S.grads + lo, L.out + lo, (float)S.fastlr, n, L.aux));
+  }
+  HIPOK(hipEventRecord(S.gates.ev[1], L.aux));
+  S.gates.late = nullptr;
+  return DYB_OK;
+}
 // One weight update over the whole arena - the fast-weight step out = p - fastlr * grads (adam = false) or Adam in place on theta -
 // as one launch on `st`, or (upd_overlap, replica groups with an auxiliary stream) by arena ranges: [0, layer3) on `st`, [layer3,
 // layer4) and [layer4, end) on `aux` behind everything `st` has issued, each followed by its gate event; the next pass_forward waits
@@ -721,8 +753,17 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
     DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / R.n > 0 ? S.upd_blocks / R.n : 1) : 0);   // upd_blocks = workgroups over ALL replicas
     RUN(range(S.grp_bounds[0], S.grp_bounds[1], aux));
     HIPOK(hipEventRecord(S.gates.ev[0], aux));
-    RUN(range(S.grp_bounds[1], S.n_params, aux));
-    HIPOK(hipEventRecord(S.gates.ev[1], aux));
+    if (S.upd_late) {
+      // the last range waits until the forward that consumes it reaches layer3 (gates.late, called from inside that forward)
+      S.late.S = &S; S.late.adam = adam; S.late.ema = ema; S.late.p = p; S.late.out = out; S.late.aux = aux; S.late.scope = R;
+      for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { S.late.ss[r] = ss[r]; S.late.bc[r] = bc[r]; }
+      S.gates.late = &late_update;
+      S.gates.user = &S;
+    } else {
+      S.gates.late = nullptr;
+      RUN(range(S.grp_bounds[1], S.n_params, aux));
+      HIPOK(hipEventRecord(S.gates.ev[1], aux));
+    }
   }
   S.gates_pending = true;
   return DYB_OK;
@@ -730,6 +771,10 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
 // make `st` wait for a ranged update nobody has consumed yet (a consumer other than a forward follows)
 static int settle_update(Stepper& S, hipStream_t st) {
   if (!S.gates_pending) return DYB_OK;
+  if (S.gates.late) {                               // nobody's forward will call it: issue the deferred range now
+    HIPOK(hipEventRecord(S.gates.mid, st));
+    RUN(late_update(&S));
+  }
   HIPOK(hipStreamWaitEvent(st, S.gates.ev[0], 0));
   HIPOK(hipStreamWaitEvent(st, S.gates.ev[1], 0));
   S.gates_pending = false;

@@ -213,6 +213,12 @@ void dyb_hmr_events_destroy(DybEvents* e);
 // reader.  dyb_hmr_param_groups: the float offsets where those two ranges begin.
 struct DybFwdGates {
   hipEvent_t ev[2];
+  // optional: work the caller wants issued when the forward reaches layer3 (the last range's update: it then runs beside layer3's
+  // compute-bound convolutions instead of beside the stem / layer1 / layer2 GroupNorm applies) - called once, after `mid` has been
+  // recorded on the forward's stream; it must make ev[1] happen
+  hipEvent_t mid = nullptr;
+  int (*late)(void* user) = nullptr;
+  void* user = nullptr;
 };
 void dyb_hmr_param_groups(const void* plan, size_t bounds[2]);
 int dyb_hmr_forward_plain(void* plan, const float* params, const float* image, const float* init_state, int n_iter, float* acts,

@@ -568,7 +568,13 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
     const BlockL& b = P.blocks[bi];
     const ConvL &c1 = P.convs[b.c1], &c2 = P.convs[b.c2], &c3 = P.convs[b.c3];
     if (gates) {                   // weights updated by arena ranges on another stream: wait right before a range's first reader
-      if (bi == P.layer_last_block[1] + 1 && gates->ev[0] && hipStreamWaitEvent(st, gates->ev[0], 0) != hipSuccess) return DYB_ERR_LAUNCH;
+      if (bi == P.layer_last_block[1] + 1) {
+        if (gates->ev[0] && hipStreamWaitEvent(st, gates->ev[0], 0) != hipSuccess) return DYB_ERR_LAUNCH;
+        if (gates->late) {           // the forward has reached layer3: the caller's deferred work may start now
+          if (gates->mid && hipEventRecord(gates->mid, st) != hipSuccess) return DYB_ERR_LAUNCH;
+          RUN(gates->late(gates->user));
+        }
+      }
       if (bi == P.layer_last_block[2] + 1 && gates->ev[1] && hipStreamWaitEvent(st, gates->ev[1], 0) != hipSuccess) return DYB_ERR_LAUNCH;
     }
     // 3 launches per conv become 2 (or 1: the small 1x1 layers write their statistics themselves): bn1 / bn2 (+ReLU)
