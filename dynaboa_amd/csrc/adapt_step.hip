@@ -53,6 +53,9 @@ int dyb_aux_loss_terms(int, int, int, float, const float*, const float*, int, co
 int dyb_hmr_feature_info(const void*, int, long long*, int*, int*);
 }
 int dyb_adam_step_rep(float*, const float*, float*, float*, float, float, const float*, const float*, float, size_t, hipStream_t);   // optim.hip
+int dyb_adam_step_rep3(float*, const float*, const float*, const float*, float*, float*, float, float, const float*, const float*, float, size_t,
+                       hipStream_t);
+int dyb_fastweight_update3(const float*, const float*, const float*, const float*, float*, float, size_t, hipStream_t);
 
 #define STATE_LD 160
 #define NV 6890
@@ -231,7 +234,8 @@ struct Stepper {
   FeatCosArgs fca{};
   float gate_seq = 0.f;
   Pass lvl0{}, ex{}, hist{}, teach{};
-  float *grads2 = nullptr, *zeros = nullptr, *ex_rot = nullptr;
+  float *grads2 = nullptr, *grads3 = nullptr, *zeros = nullptr, *ex_rot = nullptr;
+  const float *lvl_g2 = nullptr, *lvl_g3 = nullptr;      // the current level's further gradient arenas (history pass, exemplar pass): summed by the update
   float *ext_rot = nullptr, *ext_shape = nullptr, *ext_cam = nullptr, *ext_joints = nullptr;     // aux-term gradients on the image pass
   float *exg_rot = nullptr, *exg_shape = nullptr, *exg_cam = nullptr, *exg_joints = nullptr;     // ... on the exemplar pass
   float *hg_cam = nullptr, *hg_joints = nullptr;                                                 // ... on the history pass
@@ -277,6 +281,7 @@ struct Stepper {
   struct LateUpd {                 // what gates.late needs to issue it
     Stepper* S = nullptr;
     bool adam = false, ema = false;
+    const float *g2 = nullptr, *g3 = nullptr;
     const float* p = nullptr;
     float* out = nullptr;
     hipStream_t aux = nullptr;
@@ -367,6 +372,7 @@ static size_t carve(Stepper& S, char* base) {
     pass(S.hist, true);
     pass(S.teach, false);
     S.grads2 = take_f(S.n_params);
+    S.grads3 = take_f(S.n_params);
     S.zeros = take_f(B * 216);
     S.ex_rot = take_f(B * 216);
     S.ext_rot = take_f(B * 216); S.ext_shape = take_f(B * 10); S.ext_cam = take_f(B * 3); S.ext_joints = take_f(B * NJ * 3);
@@ -594,6 +600,7 @@ extern "C" int dyb_stepper_bind_workspace(void* stepper, void* ws, size_t bytes,
       auto at = [&](float* p0) { return reinterpret_cast<char*>(p0) + (size_t)r * S->blob; };
       HIPOK(hipMemsetAsync(at(S->zeros), 0, (size_t)S->B * 216 * sizeof(float), st));
       HIPOK(hipMemsetAsync(at(S->grads2), 0, S->n_params * sizeof(float), st));
+      HIPOK(hipMemsetAsync(at(S->grads3), 0, S->n_params * sizeof(float), st));
       HIPOK(hipMemsetAsync(at(S->ex.d_state), 0, (size_t)S->B * STATE_LD * sizeof(float), st));
       HIPOK(hipMemsetAsync(at(S->hist.d_state), 0, (size_t)S->B * STATE_LD * sizeof(float), st));
     }
@@ -706,11 +713,13 @@ static int late_update(void* user) {
   const size_t lo = S.grp_bounds[1], n = S.n_params - lo;
   HIPOK(hipStreamWaitEvent(L.aux, S.gates.mid, 0));
   DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / L.scope.n > 0 ? S.upd_blocks / L.scope.n : 1) : 0);
+  const float *g2 = L.g2 ? L.g2 + lo : nullptr, *g3 = L.g3 ? L.g3 + lo : nullptr;
   if (L.adam) {
-    RUN(dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, L.ss, L.bc, (float)S.eps, n, L.aux));
+    RUN(dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2, g3, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, L.ss, L.bc,
+                           (float)S.eps, n, L.aux));
     if (L.ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
   } else {
-    RUN(dyb_fastweight_update(L.p + lo, S.grads + lo, L.out + lo, (float)S.fastlr, n, L.aux));
+    RUN(dyb_fastweight_update3(L.p + lo, S.grads + lo, g2, g3, L.out + lo, (float)S.fastlr, n, L.aux));
   }
   HIPOK(hipEventRecord(S.gates.ev[1], L.aux));
   S.gates.late = nullptr;
@@ -722,6 +731,8 @@ static int late_update(void* user) {
 // for them where it first reads those weights.
 static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipStream_t st, hipStream_t aux, bool ema = false) {
   const DybRep& R = dyb_rep_current();
+  const float *g2 = S.lvl_g2, *g3 = S.lvl_g3;        // further gradient arenas of the level just differentiated (full term set), consumed here
+  S.lvl_g2 = S.lvl_g3 = nullptr;
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
   if (adam) {
     for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
@@ -735,13 +746,13 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   }
   auto range = [&](size_t lo, size_t hi, hipStream_t s) -> int {
     if (adam) {
-      RUN(dyb_adam_step_rep(S.theta + lo, S.grads + lo, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps,
-                            hi - lo, s));
+      RUN(dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, S.adam_m + lo, S.adam_v + lo,
+                             (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, hi - lo, s));
       // update_teacher (base_adaptor.py:193-201) of the same range right behind it: the teacher's next reader is a forward too
       if (ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
       return DYB_OK;
     }
-    return dyb_fastweight_update(p + lo, S.grads + lo, out + lo, (float)S.fastlr, hi - lo, s);
+    return dyb_fastweight_update3(p + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, out + lo, (float)S.fastlr, hi - lo, s);
   };
   const bool ranged = S.upd_overlap && S.nrep > 1 && aux && aux != st && S.grp_bounds[0] > 0 && S.grp_bounds[1] > S.grp_bounds[0] &&
                       S.grp_bounds[1] < S.n_params;
@@ -756,6 +767,7 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
     if (S.upd_late) {
       // the last range waits until the forward that consumes it reaches layer3 (gates.late, called from inside that forward)
       S.late.S = &S; S.late.adam = adam; S.late.ema = ema; S.late.p = p; S.late.out = out; S.late.aux = aux; S.late.scope = R;
+      S.late.g2 = g2; S.late.g3 = g3;
       for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { S.late.ss[r] = ss[r]; S.late.bc[r] = bc[r]; }
       S.gates.late = &late_update;
       S.gates.user = &S;
@@ -968,13 +980,18 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   const size_t n = S.n_params;
   RUN(pass_backward_ext(S, P, cur, S.grads, true, ext ? S.ext_rot : nullptr, ext ? S.ext_shape : nullptr, ext ? S.ext_cam : nullptr,
                         ext ? S.ext_joints : nullptr, st, aux));
+  // (the level's gradient = (image pass + history pass) + exemplar pass: the passes keep their own arenas and the weight update that
+  // follows every level adds them while it reads them - no accumulation passes)
+  (void)n;
+  S.lvl_g2 = S.lvl_g3 = nullptr;
   if (motion) {
     RUN(pass_backward_ext(S, S.hist, cur, S.grads2, false, nullptr, nullptr, S.hg_cam, S.hg_joints, st, aux));
-    RUN(dyb_axpby(S.grads2, S.grads, 1.f, 1.f, n, st));
+    S.lvl_g2 = S.grads2;
   }
   if (label) {
-    RUN(pass_backward_ext(S, S.ex, cur, S.grads2, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, st, aux));
-    RUN(dyb_axpby(S.grads2, S.grads, 1.f, 1.f, n, st));
+    RUN(pass_backward_ext(S, S.ex, cur, S.grads3, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, st, aux));
+    if (S.lvl_g2) S.lvl_g3 = S.grads3;
+    else S.lvl_g2 = S.grads3;
   }
   return DYB_OK;
 }

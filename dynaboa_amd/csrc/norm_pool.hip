@@ -659,7 +659,6 @@ struct GnOnepass {
   size_t slab_stride;
   int nslabs, HW, C, rows, relu;
   int poll_sleep;          // s_sleep(8) repetitions between two polls of the slab's counter
-  int lab_nowait;          // LAB ONLY (dyb_debug_gn_onepass_replicas): skip the wait - wrong results, timing of the streaming part
 };
 template <int OP_T>
 __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRep R) {
@@ -789,7 +788,7 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
     if (tid == 0) {
       atomicAdd(a.ctr + g, 1u);
       const long long t0 = wall_clock64();
-      while (!a.lab_nowait && __hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
+      while (__hip_atomic_load(a.ctr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
         for (int i = 0; i < a.poll_sleep; ++i) __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
           atomicAdd(a.ctr + G, 1u);
@@ -877,7 +876,7 @@ int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const f
   const int rows = dyb_cdiv(HW, k);
   DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= 1024 * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
   GnOnepass a{din, addend, out, y, stats, gamma, beta, dm == din ? nullptr : dm, dy, dgamma, dbeta, part, ctr, slab_stride, nslabs, HW, C,
-              rows, relu, dyb_tp_gn_poll() > 0 ? dyb_tp_gn_poll() : 1, dyb_tp_gn_poll() < 0 ? 1 : 0};
+              rows, relu, dyb_tp_gn_poll() > 0 ? dyb_tp_gn_poll() : 1};
   const DybRep& R = dyb_rep_current();
   const int items = rows * (C / 16);
   if (items <= 256 * OP_IT) hipLaunchKernelGGL(gn_bwd_onepass_kernel<256>, dim3(k, G, R.n), dim3(256), 0, st, a, R);

@@ -24,23 +24,31 @@ static int stream_blocks(size_t n4) {
   return (int)b;
 }
 
+// g2 / g3 (may be NULL): further gradient arenas of the same level - the history-frame pass and the exemplar pass of the full term set
+// (base_adaptor.py:380-398) - summed here, (g + g2) + g3, instead of in accumulation passes of their own (12 B per parameter each)
 __global__ __launch_bounds__(256) void fastweight_kernel(const float4* __restrict__ p, const float4* __restrict__ g,
+                                                         const float4* __restrict__ g2, const float4* __restrict__ g3,
                                                          float4* __restrict__ out, float lr, size_t n4, DybRep Rp) {
   DYB_REP_PROLOGUE(Rp);
-  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, out);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, g2); DYB_RB(Rp, g3); DYB_RB(Rp, out);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 a = p[i], b = g[i];
+    if (g2) { const float4 c = g2[i]; b.x = c.x + b.x; b.y = c.y + b.y; b.z = c.z + b.z; b.w = c.w + b.w; }
+    if (g3) { const float4 c = g3[i]; b.x = c.x + b.x; b.y = c.y + b.y; b.z = c.z + b.z; b.w = c.w + b.w; }
     a.x -= lr * b.x; a.y -= lr * b.y; a.z -= lr * b.z; a.w -= lr * b.w;
     out[i] = a;
   }
 }
-extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, hipStream_t st) {
+int dyb_fastweight_update3(const float* p, const float* g, const float* g2, const float* g3, float* out, float lr, size_t n, hipStream_t st) {
   DYB_REQUIRE(p && g && out && n % 4 == 0, DYB_ERR_ARG);
   const DybRep& Rp = dyb_rep_current();
   hipLaunchKernelGGL(fastweight_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (const float4*)p, (const float4*)g,
-                     (float4*)out, lr, n / 4, Rp);
+                     (const float4*)g2, (const float4*)g3, (float4*)out, lr, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, hipStream_t st) {
+  return dyb_fastweight_update3(p, g, nullptr, nullptr, out, lr, n, st);
 }
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float step_size,
@@ -57,14 +65,17 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 struct AdamRepScal {
   float step_size[DYB_MAX_REPLICAS], bc2_sqrt[DYB_MAX_REPLICAS];
 };
-__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, const float4* __restrict__ g2,
+                                                   const float4* __restrict__ g3, float4* __restrict__ m,
                                                    float4* __restrict__ v, float b1, float b2, AdamRepScal sc, float eps, size_t n4,
                                                    DybRep Rp) {
   DYB_REP_PROLOGUE(Rp);
-  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, m); DYB_RB(Rp, v);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, g2); DYB_RB(Rp, g3); DYB_RB(Rp, m); DYB_RB(Rp, v);
   const float step_size = sc.step_size[dyb_rep], bc2_sqrt = sc.bc2_sqrt[dyb_rep];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    if (g2) { const float4 c = g2[i]; gg.x = c.x + gg.x; gg.y = c.y + gg.y; gg.z = c.z + gg.z; gg.w = c.w + gg.w; }   // (see fastweight_kernel)
+    if (g3) { const float4 c = g3[i]; gg.x = c.x + gg.x; gg.y = c.y + gg.y; gg.z = c.z + gg.z; gg.w = c.w + gg.w; }
     adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
     adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2_sqrt, eps);
     adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2_sqrt, eps);
@@ -107,23 +118,27 @@ extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float
   const DybRep& Rp = dyb_rep_current();
   AdamRepScal sc;
   for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size; sc.bc2_sqrt[r] = bc2_sqrt; }
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
-                     (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (const float4*)nullptr,
+                     (const float4*)nullptr, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 // the same with the two bias-correction scalars given per physical replica (host arrays of DYB_MAX_REPLICAS = 64 floats; entries of
 // replicas outside the current launch scope are ignored)
-int dyb_adam_step_rep(float* p, const float* g, float* m, float* v, float beta1, float beta2, const float* step_size,
-                      const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
+int dyb_adam_step_rep3(float* p, const float* g, const float* g2, const float* g3, float* m, float* v, float beta1, float beta2,
+                       const float* step_size, const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
   DYB_REQUIRE(p && g && m && v && step_size && bc2_sqrt && n % 4 == 0, DYB_ERR_ARG);
   const DybRep& Rp = dyb_rep_current();
   AdamRepScal sc;
   for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size[r]; sc.bc2_sqrt[r] = bc2_sqrt[r]; }
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
-                     (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (const float4*)g2,
+                     (const float4*)g3, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+int dyb_adam_step_rep(float* p, const float* g, float* m, float* v, float beta1, float beta2, const float* step_size,
+                      const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
+  return dyb_adam_step_rep3(p, g, nullptr, nullptr, m, v, beta1, beta2, step_size, bc2_sqrt, eps, n, st);
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const float4* __restrict__ p, float alpha, size_t n4,

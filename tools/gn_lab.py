@@ -2,8 +2,9 @@
 """Kernel lab for the one-pass GroupNorm backward: ONE layer for S sequence replicas in one launch, timed alone with HIP events over a
 list of switch settings; prints us per launch and GB/s of algorithmic traffic.
     python tools/gn_lab.py S HW C relu mode  "tp_gn_threads=256,tp_gn_poll=1" "tp_gn_threads=256,tp_gn_poll=16" ...
-mode bits: 1 = mask from the saved activation (one more tensor read), 2 = write dm (one more tensor written).  tp_gn_poll = -1: no wait
-(timing of the streaming part only; results wrong)."""
+mode bits: 1 = mask from the saved activation (one more tensor read), 2 = write dm (one more tensor written).  (The "tp_gn_poll=-1" rows of
+profiles/r04_gn_lab.txt - no wait at all, results wrong, timing of the streaming part - came from a lab-only flag that has been removed
+again.)"""
 import json
 import os
 import sys
