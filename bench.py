@@ -61,10 +61,12 @@ def csrc_sha16():
 
 
 def chain_stream(device):
-    """The stream a frame chain is issued on: high dispatch priority (DYB_CHAIN_PRIORITY, -1 = high, 0 = normal) - the chain is the
-    critical path, the library's auxiliary stream (weight gradients, ranged weight updates; normal priority) has slack.  464.1 / 463.6
-    against 461.0 / 460.3 frames/s at 32 sequences in alternating runs (profiles/r04_sessions.txt s8)."""
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get("DYB_CHAIN_PRIORITY", "-1")))
+    """The stream a frame chain is issued on.  DYB_CHAIN_PRIORITY = -1 gives it a high dispatch priority (the chain is the critical path,
+    the library's auxiliary stream has slack): +0.7 % at 32 sequences (464.1 / 463.6 against 461.0 / 460.3 frames/s, alternating runs) - but a
+    second-order autograd run issued on a high-priority stream sporadically falls to a FIFTH of its rate (6.7 instead of 31 frames/s,
+    profiles/r04_sessions.txt s10; the runtime's high-priority queue against the engine's normal-priority side streams), so the default stays
+    normal priority."""
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get("DYB_CHAIN_PRIORITY", "0")))
 
 
 def pmc_traffic():
