@@ -151,6 +151,11 @@ struct ConvDesc {
 };
 // forward conv that may leave `*nslabs` (>1) un-reduced split-K slabs in `ws` for the GroupNorm
 // statistics kernel to fold (igemm_conv.hip)
+// operand pairs of the tangent passes (igemm_conv.hip): out = op(a1, b1) + op(a2, b2) (+ addend, data gradient only) as one launch;
+// mode 0 / 1 / 2 = forward / data gradient / weight gradient.  Latency form only: ask dyb_conv_pair_supported first.
+bool dyb_conv_pair_supported(int mode, const ConvDesc& d);
+int dyb_conv_pair(int mode, const ConvDesc& d, const float* a1, const float* b1, const float* a2, const float* b2, float* out,
+                  const float* addend, void* ws, size_t ws_bytes, hipStream_t st);
 int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y, void* ws, size_t ws_bytes,
                      int* nslabs, hipStream_t st);
 // chunking of the GroupNorm-backward partial sums (norm_pool.hip): nch row chunks x ncolb column blocks

@@ -66,6 +66,9 @@ struct IgemmArgs {
                          // COMPACT (class-local index) into slabs of slab_rows rows; a scatter fold places them (run_igemm_tp)
   int slab_rows;         // rows of one split-K slab (M unless compact)
   unsigned long long* probe;   // throughput form: per-wave phase clocks (dyb_conv_probe_set), normally NULL
+  const float* A2;       // operand PAIR (latency form, no fused loaders): out = A (x) B + A2 (x) B2 as ONE K loop - K-tiles [0, ktiles1)
+  const float* B2;       // read (A, B), K-tiles [ktiles1, ktiles) read (A2, B2) at tile index - ktiles1.  The tangent passes of the exact
+  int ktiles1;           // Hessian-vector product are made of such pairs (hvp_engine.inc); ktiles1 == ktiles: a plain conv
   float* gn_part;        // throughput forward, one image, nsplit == 1: the GroupNorm statistics of the OUTPUT leave with the tile - one
                          // [G][2] (sum, sum of squares) record per wave tile, [(lx * WM + wm) * ntiles_n * WN + ly * WN + wn] - instead of
                          // a statistics launch re-reading y (igemm_tp.inc epilogue)
@@ -92,7 +95,7 @@ __device__ __forceinline__ FwdARow fwd_a_row(const IgemmArgs& g, int m) {
   r.wi0 = wo * g.stride - g.pad;
   return r;
 }
-__device__ __forceinline__ float4 fwd_a_load(const IgemmArgs& g, const FwdARow& row, int k) {
+__device__ __forceinline__ float4 fwd_a_load(const IgemmArgs& g, const float* __restrict__ A, const FwdARow& row, int k) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row.valid && k < g.Kdim) {
     int rs = k >> g.logC;
@@ -101,7 +104,7 @@ __device__ __forceinline__ float4 fwd_a_load(const IgemmArgs& g, const FwdARow& 
     int s = rs - r * g.S;
     int hi = row.hi0 + r, wi = row.wi0 + s;
     if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
-      v = *reinterpret_cast<const float4*>(g.A + (((size_t)(row.base_n + hi * g.W + wi)) << g.logC) + c);
+      v = *reinterpret_cast<const float4*>(A + (((size_t)(row.base_n + hi * g.W + wi)) << g.logC) + c);
   }
   return v;
 }
@@ -134,7 +137,7 @@ __device__ __forceinline__ DgARow dg_a_row(const IgemmArgs& g, int m) {
   r.n = t / g.H;
   return r;
 }
-__device__ __forceinline__ float4 dg_a_load(const IgemmArgs& g, const DgARow& row, int kk) {
+__device__ __forceinline__ float4 dg_a_load(const IgemmArgs& g, const float* __restrict__ A, const DgARow& row, int kk) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row.valid && kk < g.Kdim) {
     int rs = kk >> g.logK;
@@ -146,7 +149,7 @@ __device__ __forceinline__ float4 dg_a_load(const IgemmArgs& g, const DgARow& ro
     if (th >= 0 && tw >= 0 && (th & sm) == 0 && (tw & sm) == 0) {
       int ho = th >> (g.stride >> 1), wo = tw >> (g.stride >> 1);
       if (ho < g.Ho && wo < g.Wo)
-        v = *reinterpret_cast<const float4*>(g.A + (((size_t)((row.n * g.Ho + ho) * g.Wo + wo)) << g.logK) + ko);
+        v = *reinterpret_cast<const float4*>(A + (((size_t)((row.n * g.Ho + ho) * g.Wo + wo)) << g.logK) + ko);
     }
   }
   return v;
@@ -168,12 +171,12 @@ __device__ __forceinline__ long dg_a_off(const IgemmArgs& g, const DgARow& row, 
   return -1;
 }
 // rows = cin, k = (r,s,ko) with ko fastest: W[(rs*C + c)*K + ko]         (dgrad B, transposing)
-__device__ __forceinline__ float4 dg_b_load(const IgemmArgs& g, int c, int kk) {
+__device__ __forceinline__ float4 dg_b_load(const IgemmArgs& g, const float* __restrict__ Bw, int c, int kk) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < g.Ncols && kk < g.Kdim) {
     int rs = kk >> g.logK;
     int ko = kk & (g.K - 1);
-    v = *reinterpret_cast<const float4*>(g.B + ((((size_t)rs << g.logC) + c) << g.logK) + ko);
+    v = *reinterpret_cast<const float4*>(Bw + ((((size_t)rs << g.logC) + c) << g.logK) + ko);
   }
   return v;
 }
@@ -198,7 +201,7 @@ __device__ __forceinline__ WgARow wg_a_row(const IgemmArgs& g, int i) {
   w.s = rs - w.r * g.S;
   return w;
 }
-__device__ __forceinline__ float4 wg_a_load(const IgemmArgs& g, const WgARow& row, int p) {
+__device__ __forceinline__ float4 wg_a_load(const IgemmArgs& g, const float* __restrict__ A, const WgARow& row, int p) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row.valid && p < g.Kdim) {
     int wo = p % g.Wo;
@@ -207,7 +210,7 @@ __device__ __forceinline__ float4 wg_a_load(const IgemmArgs& g, const WgARow& ro
     int n = t / g.Ho;
     int hi = ho * g.stride - g.pad + row.r, wi = wo * g.stride - g.pad + row.s;
     if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
-      v = *reinterpret_cast<const float4*>(g.A + (((size_t)((n * g.H + hi) * g.W + wi)) << g.logC) + row.c);
+      v = *reinterpret_cast<const float4*>(A + (((size_t)((n * g.H + hi) * g.W + wi)) << g.logC) + row.c);
   }
   return v;
 }
@@ -278,7 +281,7 @@ struct GnFwdFuse {
 // replica rebasing of the argument blocks (dyb_common.h: sequence replicas in the grid)
 __device__ __forceinline__ void rebase(IgemmArgs& g, const DybRep& R, int rep) {
   g.A = dyb_rb(g.A, R, rep); g.B = dyb_rb(g.B, R, rep); g.out = dyb_rb(g.out, R, rep); g.addend = dyb_rb(g.addend, R, rep);
-  g.gn_part = dyb_rb(g.gn_part, R, rep);
+  g.gn_part = dyb_rb(g.gn_part, R, rep); g.A2 = dyb_rb(g.A2, R, rep); g.B2 = dyb_rb(g.B2, R, rep);
 }
 __device__ __forceinline__ void rebase(GnBwdFuse& f, const DybRep& R, int rep) {
   f.y = dyb_rb(f.y, R, rep); f.stats = dyb_rb(f.stats, R, rep); f.gpart = dyb_rb(f.gpart, R, rep); f.gamma = dyb_rb(f.gamma, R, rep);
@@ -471,7 +474,11 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     if (n0 + d_q < g.Ncols) wg_gamma = *reinterpret_cast<const float4*>(f.gamma + n0 + d_q);
   }
 
+  // the second operand pair of a paired launch (uniform per K-step; the fused loaders never see one: run_igemm)
   auto load_a = [&](int kt, int h, Frag& o) {
+    const bool second = kt >= g.ktiles1;
+    const float* __restrict__ Ap = second ? g.A2 : g.A;
+    if constexpr (!(GB || FA)) kt = second ? kt - g.ktiles1 : kt;
     if constexpr (MODE == MODE_FWD) {
       if constexpr (FA) {
         const int k = kt * BK + 16 * h + t_kq;
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         o.v = *reinterpret_cast<const float4*>(nf.gamma + (k & (g.C - 1)));
         o.ga = *reinterpret_cast<const float4*>(nf.beta + (k & (g.C - 1)));
       } else {
-        o.d = fwd_a_load(g, fa, kt * BK + 16 * h + t_kq);
+        o.d = fwd_a_load(g, Ap, fa, kt * BK + 16 * h + t_kq);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       if constexpr (GB) {
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         o.v = *reinterpret_cast<const float4*>(f.y + off);
         o.ga = *reinterpret_cast<const float4*>(f.gamma + ((kt * BK + 16 * h + t_kq) & (g.K - 1)));
       } else {
-        o.d = dg_a_load(g, da, kt * BK + 16 * h + t_kq);
+        o.d = dg_a_load(g, Ap, da, kt * BK + 16 * h + t_kq);
       }
     } else {
       if constexpr (FA) {
@@ -502,13 +509,16 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         o.ok = off >= 0;
         o.d = *reinterpret_cast<const float4*>(g.A + (o.ok ? off : 0));
       } else {
-        o.d = wg_a_load(g, wa, kt * BK + 16 * h + d_k);
+        o.d = wg_a_load(g, Ap, wa, kt * BK + 16 * h + d_k);
       }
     }
   };
   auto load_b = [&](int kt, int h, Frag& o) {
-    if constexpr (MODE == MODE_FWD) o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
-    else if constexpr (MODE == MODE_DGRAD) o.d = dg_b_load(g, n0 + t_row, kt * BK + 16 * h + t_kq);
+    const bool second = kt >= g.ktiles1;
+    const float* __restrict__ Bp = second ? g.B2 : g.B;
+    if constexpr (!(GB || FA)) kt = second ? kt - g.ktiles1 : kt;
+    if constexpr (MODE == MODE_FWD) o.d = direct_load(Bp, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+    else if constexpr (MODE == MODE_DGRAD) o.d = dg_b_load(g, Bp, n0 + t_row, kt * BK + 16 * h + t_kq);
     else {
       if constexpr (GB) {
         const int p = kt * BK + 16 * h + d_k, col = n0 + d_q;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         o.d = *reinterpret_cast<const float4*>(g.B + off);
         o.v = *reinterpret_cast<const float4*>(f.y + off);
       } else {
-        o.d = direct_load(g.B, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
+        o.d = direct_load(Bp, g.K, g.Kdim, g.Ncols, kt * BK + 16 * h + d_k, n0 + d_q);
       }
     }
   };
@@ -1075,6 +1085,7 @@ static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
   else if (mode == MODE_DGRAD) { g.M = d.N * d.H * d.W; g.Ncols = d.C; g.Kdim = d.R * d.S * d.K; }
   else { g.M = d.R * d.S * d.C; g.Ncols = d.K; g.Kdim = d.N * g.Ho * g.Wo; }
   g.ktiles = dyb_cdiv(g.Kdim, BK);
+  g.ktiles1 = g.ktiles;
   return DYB_OK;
 }
 
@@ -1122,7 +1133,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1144,6 +1155,7 @@ struct DybSwitches {
     tp_gn_fuse_stats = env("DYB_TP_GN_FUSE_STATS", 1);
     tp_gn_poll = env("DYB_TP_GN_POLL", 8);
     tp_fwd_nosplit2 = env("DYB_TP_FWD_NOSPLIT2", 1);
+    pair = env("DYB_CONV_PAIR", 1);
   }
 };
 static DybSwitches& switches() {
@@ -1174,6 +1186,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_gn_fuse_stats")) return &s.tp_gn_fuse_stats;
   if (!strcmp(name, "tp_gn_poll")) return &s.tp_gn_poll;
   if (!strcmp(name, "tp_fwd_nosplit2")) return &s.tp_fwd_nosplit2;
+  if (!strcmp(name, "conv_pair")) return &s.pair;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1579,14 +1592,19 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
 // GroupNorm statistics kernel); otherwise the result lands in `out`.
 static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B, float* out, const float* addend,
                      void* ws, size_t ws_bytes, int* raw_slabs_out, hipStream_t st, const GnBwdFuse* fuse = nullptr,
-                     const GnFwdFuse* nfuse = nullptr, float* stats_part = nullptr, int* stats_nrec = nullptr) {
+                     const GnFwdFuse* nfuse = nullptr, float* stats_part = nullptr, int* stats_nrec = nullptr, const float* A2 = nullptr,
+                     const float* B2 = nullptr) {
   DYB_REQUIRE(A && B && out, DYB_ERR_ARG);
   IgemmArgs g{};
   int rc = fill_args(g, d, mode);
   if (rc != DYB_OK) return rc;
   g.A = A; g.B = B;
   if (stats_nrec) *stats_nrec = 0;
-  if (tp_eligible(mode, d, fuse)) return run_igemm_tp(mode, d, g, out, addend, ws, ws_bytes, raw_slabs_out, st, nfuse, stats_part, stats_nrec);
+  if (A2 || B2) {            // operand pair: one K loop over both (latency form without fused loaders only - dyb_conv_pair_supported)
+    DYB_REQUIRE(A2 && B2 && !fuse && !nfuse && !tp_eligible(mode, d, nullptr) && !dyb_bf16_current(), DYB_ERR_UNSUPPORTED);
+    g.A2 = A2; g.B2 = B2;
+    g.ktiles = 2 * g.ktiles1;
+  } else if (tp_eligible(mode, d, fuse)) return run_igemm_tp(mode, d, g, out, addend, ws, ws_bytes, raw_slabs_out, st, nfuse, stats_part, stats_nrec);
   g.nsplit = choose_split(g, ws ? ws_bytes / sizeof(float) : 0, mode, raw_slabs_out != nullptr && mode != MODE_FWD);
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
   g.nsplit = dyb_cdiv(g.ktiles, g.tiles_per_split);       // drop empty tail splits
@@ -1642,6 +1660,30 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     DYB_CHECK_LAUNCH();
   }
   return DYB_OK;
+}
+
+// Operand pairs (internal: the tangent passes of hvp_engine.inc).  mode 0 / 1 / 2 = forward / data gradient / weight gradient:
+//   forward          out = conv(a1, b1) + conv(a2, b2)                 a = activations, b = weights
+//   data gradient    out = dgrad(a1, b1) + dgrad(a2, b2) (+ addend)    a = output gradients, b = weights
+//   weight gradient  out = wgrad(a1, b1) + wgrad(a2, b2)               a = activations, b = output gradients
+// as one launch with a K loop over both pairs (and one split-K fold instead of two folds and an add).
+bool dyb_conv_pair_supported(int mode, const ConvDesc& d) {
+  return switches().pair.load(std::memory_order_relaxed) && !tp_eligible(mode, d, nullptr) && !dyb_bf16_current();
+}
+int dyb_conv_pair(int mode, const ConvDesc& d, const float* a1, const float* b1, const float* a2, const float* b2, float* out,
+                  const float* addend, void* ws, size_t ws_bytes, hipStream_t st) {
+  DYB_REQUIRE(mode >= 0 && mode <= 2 && a2 && b2, DYB_ERR_ARG);
+  DYB_REQUIRE(mode == MODE_DGRAD || !addend, DYB_ERR_UNSUPPORTED);
+  return run_igemm(mode, d, a1, b1, out, addend, ws, ws_bytes, nullptr, st, nullptr, nullptr, nullptr, nullptr, a2, b2);
+}
+
+extern "C" int dyb_debug_conv_pair(int mode, const float* a1, const float* b1, const float* a2, const float* b2, float* out,
+                                   const float* addend, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws,
+                                   size_t ws_bytes, hipStream_t st) {
+  ConvDesc d{N, H, W, C, K, R, S, stride, pad};
+  DYB_REQUIRE(mode >= 0 && mode <= 2, DYB_ERR_ARG);
+  DYB_REQUIRE(dyb_conv_pair_supported(mode, d), DYB_ERR_UNSUPPORTED);
+  return dyb_conv_pair(mode, d, a1, b1, a2, b2, out, addend, ws, ws_bytes, st);
 }
 
 int dyb_conv_fwd_raw(const ConvDesc& d, const float* x, const float* w, float* y, void* ws, size_t ws_bytes,

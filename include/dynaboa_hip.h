@@ -146,6 +146,17 @@ int dyb_gn_jvp_fwd(const float* y, float* ty, const float* ty2, const float* sta
 int dyb_gn_jvp_bwd(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty, const float* stats,
                    const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm, float* dy, float* tdy,
                    float* scratch, float* tdgamma, float* tdbeta, int N, int HW, int C, int relu, dyb_stream_t stream);
+/* The same two as ONE launch each (the chunks of a slab meet on an arrival counter inside the launch instead of between two launches):
+ * sync = dyb_gn_jvp_sync_words(N) 32-bit words - an error word, then one counter per (image, group) slab - zero on entry and private to
+ * the call until it has finished on the stream.  A wait that lasts 0.2 s raises sync[0] and goes on (results then wrong). */
+size_t dyb_gn_jvp_sync_words(int N);
+int dyb_gn_jvp_fwd_onepass(const float* y, float* ty, const float* ty2, const float* stats, const float* gamma, const float* beta,
+                           const float* tgamma, const float* tbeta, const float* res, const float* tres, float* out, float* tout,
+                           float* tstats, float* scratch, unsigned* sync, int N, int HW, int C, int relu, dyb_stream_t stream);
+int dyb_gn_jvp_bwd_onepass(const float* dout, const float* tdout, const float* out_mask, const float* y, const float* ty,
+                           const float* stats, const float* tstats, const float* gamma, const float* tgamma, float* dm, float* tdm,
+                           float* dy, float* tdy, float* scratch, unsigned* sync, float* tdgamma, float* tdbeta, int N, int HW, int C,
+                           int relu, dyb_stream_t stream);
 /* Exact Hessian-vector product through HMR, forward-over-reverse (hvp_engine.inc).  acts = the arena dyb_hmr_forward filled at
  * (params, image); tparams = the direction v (parameter arena layout); dual = scratch of dyb_hmr_hvp_dual_floats floats shared by
  * the two passes.  _jvp_forward leaves the tangent of the regressor's final state [B][160] at dual + dyb_hmr_hvp_offset_tstate;
@@ -320,6 +331,13 @@ int dyb_debug_conv_replicas(int mode, const float* x, const float* w, const floa
  * stats(8) | dgamma | dbeta | workspace }, blob_floats per replica; mode bit 0: mask from the saved activation, bit 1: write dm */
 int dyb_debug_gn_onepass_replicas(float* blob, size_t blob_floats, int nrep, const float* gamma, const float* beta, int HW, int C, int relu,
                                   int mode, dyb_stream_t stream);
+/* diagnostic / tests: the operand-pair convolution the tangent passes of the exact Hessian-vector product are made of (latency form,
+ * csrc/hvp_engine.inc): out = op(a1, b1) + op(a2, b2) (+ addend; data gradient only) as ONE launch with a K loop over both pairs.
+ * mode 0 forward (a = x [N][H][W][C], b = w [R][S][C][K]), 1 data gradient (a = dy [N][Ho][Wo][K], b = w), 2 weight gradient (a = x,
+ * b = dy).  DYB_ERR_UNSUPPORTED where the throughput schedule or the bf16 form is in force (option "conv_pair" = 0 turns pairs off). */
+int dyb_debug_conv_pair(int mode, const float* a1, const float* b1, const float* a2, const float* b2, float* out, const float* addend,
+                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
+                        dyb_stream_t stream);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 

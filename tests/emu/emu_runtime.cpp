@@ -3,8 +3,8 @@
 // yield at __syncthreads() / cross-lane operations, which gives exactly the barrier semantics the
 // kernels rely on.  The workgroups of a grid are spread over a few OS threads (DYB_EMU_THREADS, default = the CPU
 // count, max 16): every piece of executor state, the built-in index variables and the kernels' __shared__ arrays are
-// thread_local.  Workgroups are claimed in id order, so the few kernels whose workgroups meet on a counter (groups of <= 32
-// consecutive ids; the pool has 32 threads) make progress as they do on the device.  x86-64 SysV only.
+// thread_local.  Workgroups are claimed in id order, so the few kernels whose workgroups meet on a counter (groups of <= 64
+// consecutive ids; the pool has 72 threads) make progress as they do on the device.  x86-64 SysV only.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
@@ -20,7 +20,42 @@
 #include <thread>
 #include <vector>
 
-void emu_os_yield() { std::this_thread::yield(); }
+// Run permits: the pool has many more threads (72) than cores because the workgroups of a meeting (kernels whose workgroups wait for each
+// other on a counter) must all be claimed at once; only `permits` of them run workgroups at any time, and a workgroup that sleeps in a
+// wait loop (s_sleep -> emu_os_yield) lends its permit to another thread meanwhile.
+namespace emu_permits {
+static std::mutex& mu = *new std::mutex();
+static std::condition_variable& cv = *new std::condition_variable();
+static int avail = -1;
+static thread_local bool held = false;
+static void init_locked() {
+  if (avail >= 0) return;
+  long v = sysconf(_SC_NPROCESSORS_ONLN);
+  if (const char* e = getenv("DYB_EMU_PERMITS")) v = atol(e);
+  avail = (int)(v < 4 ? 4 : v > 16 ? 16 : v);
+}
+static void acquire() {
+  std::unique_lock<std::mutex> lk(mu);
+  init_locked();
+  cv.wait(lk, [] { return avail > 0; });
+  --avail;
+  held = true;
+}
+static void release() {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    ++avail;
+    held = false;
+  }
+  cv.notify_one();
+}
+}  // namespace emu_permits
+void emu_os_yield() {
+  if (!emu_permits::held) { std::this_thread::yield(); return; }
+  emu_permits::release();
+  std::this_thread::yield();
+  emu_permits::acquire();
+}
 
 namespace emu {
 thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
@@ -276,6 +311,8 @@ static int g_active = 0;
 
 static void work_on(const Job& j) {
   for (;;) {
+    emu_permits::acquire();                          // before the claim: workgroups start in id order
+    struct Rel { ~Rel() { emu_permits::release(); } } rel;
     unsigned long long b = g_next.fetch_add(1, std::memory_order_relaxed);
     if (b >= j.total) return;
     unsigned bx = (unsigned)(b % j.grid.x), by = (unsigned)((b / j.grid.x) % j.grid.y), bz = (unsigned)(b / ((unsigned long long)j.grid.x * j.grid.y));
@@ -304,7 +341,8 @@ static int pool_size() {
     const char* e = getenv("DYB_EMU_THREADS");
     long v = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
     if (v > 16) v = 16;
-    if (v < 32) v = 32;                // kernels that meet on a counter need every workgroup of a meeting claimed (<= 32 of consecutive ids)
+    if (v < 72) v = 72;                // kernels that meet on a counter need every workgroup of a meeting claimed (<= 64 of consecutive ids + the
+                                       // 4 per-group workgroups of the GroupNorm tangent's backward that wait for every image)
     return (int)v;
   }();
   return n;

@@ -109,6 +109,16 @@ void emu_os_yield();
 static inline void __builtin_amdgcn_s_sleep(int) { emu_os_yield(); }
 static inline long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+static inline long long __double_as_longlong(double d) {
+  long long v;
+  std::memcpy(&v, &d, sizeof v);
+  return v;
+}
+static inline double __longlong_as_double(long long v) {
+  double d;
+  std::memcpy(&d, &v, sizeof d);
+  return d;
+}
 static inline float __uint_as_float(unsigned u) {
   float f;
   memcpy(&f, &u, 4);

@@ -73,6 +73,38 @@ def _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, xr, wr, dyr):
     return e
 
 
+def case_conv_pair(be, N, H, W, C, K, R, stride, pad, seed=0):
+    """dyb_debug_conv_pair (the tangent passes' operand pairs: one launch, one K loop over both pairs) against torch:
+    forward conv(x1, w1) + conv(x2, w2); data gradient dgrad(dy1, w1) + dgrad(dy2, w2) + addend; weight gradient wgrad(x1, dy1) +
+    wgrad(x2, dy2)."""
+    rng = _rng(seed)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    xs = [rng.standard_normal((N, H, W, C)).astype(np.float32) for _ in range(2)]
+    ws_ = [(rng.standard_normal((R, R, C, K)) / np.sqrt(R * R * C)).astype(np.float32) for _ in range(2)]
+    dys = [rng.standard_normal((N, Ho, Wo, K)).astype(np.float32) for _ in range(2)]
+    add = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    y_ref, dx_ref, dw_ref = 0, add.copy(), 0
+    for x, w, dy in zip(xs, ws_, dys):
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        wt = torch.from_numpy(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+        yt = F.conv2d(xt, wt, stride=stride, padding=pad)
+        gx, gw = torch.autograd.grad(yt, [xt, wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+        y_ref = y_ref + yt.detach().permute(0, 2, 3, 1).numpy()
+        dx_ref = dx_ref + gx.permute(0, 2, 3, 1).numpy()
+        dw_ref = dw_ref + gw.permute(2, 3, 1, 0).numpy()
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad)
+    ws = be.empty((max(wsb, 16) // 4,))
+    X, Wd, DY, ADD = [be.dev(x) for x in xs], [be.dev(w) for w in ws_], [be.dev(d) for d in dys], be.dev(add)
+    y_, dx_, dw_ = be.empty(dys[0].shape), be.empty(xs[0].shape), be.empty(ws_[0].shape)
+    g = (N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb, be.stream)
+    check(be.lib.dyb_debug_conv_pair(0, be.ptr(X[0]), be.ptr(Wd[0]), be.ptr(X[1]), be.ptr(Wd[1]), be.ptr(y_), None, *g), "pair fwd")
+    check(be.lib.dyb_debug_conv_pair(1, be.ptr(DY[0]), be.ptr(Wd[0]), be.ptr(DY[1]), be.ptr(Wd[1]), be.ptr(dx_), be.ptr(ADD), *g), "pair dgrad")
+    check(be.lib.dyb_debug_conv_pair(2, be.ptr(X[0]), be.ptr(DY[0]), be.ptr(X[1]), be.ptr(DY[1]), be.ptr(dw_), None, *g), "pair wgrad")
+    e = dict(fwd=rel_err(be.host(y_), y_ref), dgrad=rel_err(be.host(dx_), dx_ref), wgrad=rel_err(be.host(dw_), dw_ref))
+    assert max(e.values()) < TOL, e
+    return e
+
+
 # ---------------------------------------------------------------------------------------- groupnorm
 def case_groupnorm(be, N, HW, C, relu, with_res, nslabs, seed=1):
     rng = _rng(seed)
@@ -1065,9 +1097,10 @@ def case_aux_terms(be, B=3, seed=91):
 
 
 # ---------------------------------------------------------------------------------------- tangent (JVP) kernels
-def case_gn_jvp(be, N, HW, C, relu, with_res, split_ty=False, seed=31):
+def case_gn_jvp(be, N, HW, C, relu, with_res, split_ty=False, seed=31, onepass=False):
     """dyb_gn_jvp_fwd / dyb_gn_jvp_bwd against torch (float64): forward tangent of relu?(GN(y) + res) along (ty, tgamma, tbeta,
-    tres), and the tangent of its backward (dy, dgamma, dbeta, dres) along the same direction plus tdout."""
+    tres), and the tangent of its backward (dy, dgamma, dbeta, dres) along the same direction plus tdout.  onepass: the one-launch
+    entry points (a slab's chunks meet on an arrival counter inside the launch)."""
     rng = _rng(seed)
     f32 = lambda *s: rng.standard_normal(s).astype(np.float32)
     y, ty = f32(N, HW, C) * 1.5 + 0.3, f32(N, HW, C)
@@ -1111,15 +1144,25 @@ def case_gn_jvp(be, N, HW, C, relu, with_res, split_ty=False, seed=31):
     if split_ty:            # the tangent arrives as two halves (a convolution's conv(tx, w) + conv(x, tw)); the sums launch adds them
         h = f32(N, HW, C)
         TY, TY2 = be.dev(ty - h), be.dev(h)
-    check(be.lib.dyb_gn_jvp_fwd(be.ptr(Y), be.ptr(TY), be.ptr(TY2) if split_ty else None, be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(TG),
-                                be.ptr(TB), be.ptr(RES) if with_res else None, be.ptr(TRES) if with_res else None, be.ptr(OUT),
-                                be.ptr(TOUT), be.ptr(TST), be.ptr(SCR), N, HW, C, relu, be.stream), "gn jvp fwd")
+    nsync = int(be.lib.dyb_gn_jvp_sync_words(N))
+    SY1, SY2 = be.zeros((nsync,)), be.zeros((nsync,))          # 32-bit words, zero on entry
+    fa = (be.ptr(Y), be.ptr(TY), be.ptr(TY2) if split_ty else None, be.ptr(ST), be.ptr(GA), be.ptr(BE_), be.ptr(TG), be.ptr(TB),
+          be.ptr(RES) if with_res else None, be.ptr(TRES) if with_res else None, be.ptr(OUT), be.ptr(TOUT), be.ptr(TST), be.ptr(SCR))
+    if onepass:
+        check(be.lib.dyb_gn_jvp_fwd_onepass(*fa, be.ptr(SY1), N, HW, C, relu, be.stream), "gn jvp fwd onepass")
+    else:
+        check(be.lib.dyb_gn_jvp_fwd(*fa, N, HW, C, relu, be.stream), "gn jvp fwd")
     e = dict(out=rel_err(be.host(OUT), out_ref.numpy()), tout=rel_err(be.host(TOUT), tout_ref.numpy()))
     DM, TDM, DY, TDY = be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C)), be.empty((N, HW, C))
     TDG, TDB = be.empty((C,)), be.empty((C,))
-    check(be.lib.dyb_gn_jvp_bwd(be.ptr(be.dev(dout)), be.ptr(be.dev(tdout)), be.ptr(OUT), be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(TST),
-                                be.ptr(GA), be.ptr(TG), be.ptr(DM), be.ptr(TDM), be.ptr(DY), be.ptr(TDY), be.ptr(SCR), be.ptr(TDG),
-                                be.ptr(TDB), N, HW, C, relu, be.stream), "gn jvp bwd")
+    DO, TDO = be.dev(dout), be.dev(tdout)
+    ba = (be.ptr(DO), be.ptr(TDO), be.ptr(OUT), be.ptr(Y), be.ptr(TY), be.ptr(ST), be.ptr(TST), be.ptr(GA), be.ptr(TG), be.ptr(DM),
+          be.ptr(TDM), be.ptr(DY), be.ptr(TDY), be.ptr(SCR))
+    if onepass:
+        check(be.lib.dyb_gn_jvp_bwd_onepass(*ba, be.ptr(SY2), be.ptr(TDG), be.ptr(TDB), N, HW, C, relu, be.stream), "gn jvp bwd onepass")
+        assert be.host(SY1).view(np.uint32)[0] == 0 and be.host(SY2).view(np.uint32)[0] == 0          # no wait timed out
+    else:
+        check(be.lib.dyb_gn_jvp_bwd(*ba, be.ptr(TDG), be.ptr(TDB), N, HW, C, relu, be.stream), "gn jvp bwd")
     e.update(dy=rel_err(be.host(DY), g_ref[0].detach().numpy()), tdy=rel_err(be.host(TDY), tg_ref[0].numpy()),
              tdgamma=rel_err(be.host(TDG), tg_ref[1].numpy()), tdbeta=rel_err(be.host(TDB), tg_ref[2].numpy()))
     if with_res:

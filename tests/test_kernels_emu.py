@@ -27,6 +27,17 @@ def test_conv(be, cfg):
     K.case_conv(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg), c_real=3 if C == 4 else None)
 
 
+@pytest.mark.parametrize("cfg", [
+    (1, 8, 8, 64, 64, 1, 1, 0),        # 1x1, exact tiles
+    (1, 7, 7, 64, 128, 3, 1, 1),       # 3x3, ragged rows, split-K over the doubled K loop
+    (2, 10, 10, 64, 64, 3, 2, 1),      # stride 2, batch 2
+    (1, 20, 20, 4, 64, 7, 2, 3),       # 7x7 s2 with a ragged K tile per pair (196 = 6 x 32 + 4)
+])
+def test_conv_operand_pair(be, cfg):
+    """One launch for op(a1, b1) + op(a2, b2) (the tangent passes' pairs): forward, data gradient + addend, weight gradient."""
+    print(K.case_conv_pair(be, *cfg, seed=sum(cfg)))
+
+
 @pytest.fixture(params=[2, 1, 3], ids=["pipelined", "phased", "pipelined2"])
 def throughput_mode(be, request):
     """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas), once with each loop
@@ -369,6 +380,13 @@ def test_groupnorm_tangent_kernels(be, cfg):
     """Forward tangent of GroupNorm(+ReLU)(+residual) and the tangent of its backward (the building blocks of the exact
     Hessian-vector product) against torch's forward-over-reverse in float64."""
     K.case_gn_jvp(be, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1, 49, 64, 1, True), (3, 20, 256, 0, True), (1, 3136, 64, 1, True, True), (2, 200, 512, 1, False, True)])
+def test_groupnorm_tangent_kernels_one_launch(be, cfg):
+    """The same with sums and apply as ONE launch each (the chunks of a slab meet on an arrival counter; the group's channel sums wait
+    for every image's chunks)."""
+    K.case_gn_jvp(be, *cfg, onepass=True)
 
 
 def test_side_stream_schedules_hold_under_adversarial_stream_order(be, ckpt_rand):

@@ -32,6 +32,13 @@ def test_conv_all_resnet_shapes(be, shape):
     K.case_conv(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc, c_real=3 if C == 4 else None)
 
 
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_operand_pair_all_resnet_shapes(be, shape):
+    """The tangent passes' operand pairs - op(a1, b1) + op(a2, b2) in one launch - on every ResNet-50 conv shape."""
+    H, W, C, Kc, R, st, pad = shape
+    K.case_conv_pair(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc + 1)
+
+
 @pytest.mark.parametrize("shape", [(56, 56, 64, 64, 3, 1, 1), (28, 28, 512, 1024, 1, 2, 0), (7, 7, 512, 512, 3, 1, 1)])
 def test_conv_batch8(be, shape):
     H, W, C, Kc, R, st, pad = shape
@@ -315,6 +322,13 @@ def test_groupnorm_tangent_kernels(be, cfg):
     """Forward tangent of GroupNorm(+ReLU)(+residual) and the tangent of its backward (exact Hessian-vector product building
     blocks) against torch's forward-over-reverse in float64, at ResNet-50 layer sizes."""
     K.case_gn_jvp(be, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1, 3136, 64, 1, False), (1, 784, 512, 1, True, True), (2, 196, 1024, 0, False), (1, 49, 2048, 1, True),
+                                 (1, 12544, 64, 1, False, True), (16, 196, 1024, 1, True)])
+def test_groupnorm_tangent_kernels_one_launch(be, cfg):
+    """The same with sums and apply as ONE launch each (a slab's row chunks meet on an arrival counter inside the launch)."""
+    K.case_gn_jvp(be, *cfg, onepass=True)
 
 
 @pytest.mark.parametrize("side", [True, False])
