@@ -716,7 +716,7 @@ def main():
                      "configuration); the headline `value` uses S = %d" % seqs, **reps)
             out["second_order"] = sub_record(device, "second_order", 8, 2, 1, args.inner_step,
                                              "configs[1] second-order arm: one sequence, second_order=1, exact Hessian-vector products "
-                                             "(tangent passes through the network, forward-over-reverse; the default)", second_order=1,
+                                             "(tangent passes through the network, forward-over-reverse, both halves of every tangent pair in one conv launch; the default)", second_order=1,
                                              hvp="exact")
             out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 12, 3, 1, args.inner_step,
                                                     "the same with --hvp fd: Hessian-vector products as central differences of two "

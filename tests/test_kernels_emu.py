@@ -403,3 +403,15 @@ def test_hmr_exact_hessian_vector_product(be, ckpt_rand, B):
     """The tangent passes through the whole network (exact H v, forward-over-reverse) against torch differentiating the oracle
     twice: tangent of the regressor state and every tensor of H v; batch 1 and 2."""
     print(K.case_hmr_hvp(be, ckpt_rand, B=B))
+
+
+@pytest.mark.slow
+def test_hmr_exact_hessian_vector_product_one_launch_groupnorm_tangents(be, ckpt_rand, monkeypatch):
+    """The same with DYB_HVP_GN_ONEPASS=1 (the engine's per-layer arrival counters, zeroed per pass) and with the operand pairs off
+    (two launches per tangent pair, second halves collected in hv2)."""
+    monkeypatch.setenv("DYB_HVP_GN_ONEPASS", "1")
+    be.lib.dyb_set_option(b"conv_pair", 0)
+    try:
+        print(K.case_hmr_hvp(be, ckpt_rand, B=1))
+    finally:
+        be.lib.dyb_set_option(b"conv_pair", 1)

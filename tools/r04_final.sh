@@ -51,4 +51,13 @@ for k,v in d.items():
 sw = d.get("sequences_per_gpu_sweep", {})
 print("sweep", {k: (round(v["value"],1) if isinstance(v, dict) and v.get("value") else None) for k, v in sw.items() if k != "note"})
 PY
+# second order, one sequence: launches per frame with the tangent pairs as one launch (kernel stats of 8 frames)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trso -o trace -- python $R/bench.py --second_order 1 --seqs 1 --steps 8 --warmup 2 $Q) > $O/trace_so.log 2>&1
+f=$(find $O/trso -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_SO_S1.csv && python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/kernel_stats_SO_S1.csv")))
+calls = sum(int(r["Calls"]) for r in rows); tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("second order, one sequence: %d launches, %.1f ms of kernels over the run (10 frames incl. warm-up: %.0f launches per frame)" % (calls, tot / 1e6, calls / 10.0))
+PY
+rm -rf $O/trso
 timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
