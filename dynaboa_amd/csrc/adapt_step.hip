@@ -19,8 +19,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "dyb_common.h"
 
@@ -214,6 +218,9 @@ struct Pass {
   float* pred17;
 };
 
+struct SideIssuer;
+struct Stepper;
+static void side_shutdown(Stepper& S);
 struct Stepper {
   void* plan = nullptr;
   int B = 1, H = 224, W = 224;
@@ -305,6 +312,13 @@ struct Stepper {
     const float *pose = nullptr, *betas = nullptr;
   } gtjob;
   hipStream_t tail_stream = nullptr;
+  // "side_thread" (one sequence with a side stream): the side stream's launches - the previous frame's final forward, this frame's
+  // ground-truth meshes, ~130 launches - are issued by a helper thread while the calling thread goes on with the frame's chain.  At one
+  // sequence the frame is bound by the host's launch rate (~1 400 launches at ~8 us; profiles/r04_frame_timeline_S1.txt: the main queue
+  // sat idle for 1.1 ms per frame while the calling thread issued them).  The calling thread waits for the helper before it first
+  // touches anything the helper writes (e_gt, side_pending, the tail slot).
+  int side_thread = 0;
+  SideIssuer* issuer = nullptr;
   std::string err;
   // host-side issue time by section (always on: two clock reads per section), read back through dyb_stepper_get_f
   double h_fwd = 0, h_bwd = 0, h_head = 0, h_update = 0, h_tail = 0, h_total = 0;
@@ -431,6 +445,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
 extern "C" void dyb_stepper_destroy(void* stepper) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   if (!S) return;
+  side_shutdown(*S);
   dyb_hmr_events_destroy(S->ev);
   if (S->e_theta) (void)hipEventDestroy(S->e_theta);
   if (S->e_side) (void)hipEventDestroy(S->e_side);
@@ -452,6 +467,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "eval_lower") S->eval_lower = (int)v;
   else if (k == "use_side") S->use_side = (int)v;
   else if (k == "upd_overlap") S->upd_overlap = (int)v;
+  else if (k == "side_thread") S->side_thread = (int)v;
   else if (k == "upd_blocks") S->upd_blocks = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
@@ -636,11 +652,12 @@ static int check_ready(const Stepper& S) {
 }
 
 // HMR forward at `theta` -> rotmat / shape / cam in the pass's arena -> SMPL (neutral) vertices + 49 joints
-static int pass_forward(Stepper& S, Pass& P, const float* theta, const float* image, hipStream_t st) {
+static int pass_forward(Stepper& S, Pass& P, const float* theta, const float* image, hipStream_t st, bool chain = true) {
   // (a ranged weight update may still be running on the auxiliary stream: this forward - the first reader of the new weights -
-  // waits for each range where it first reads it)
-  const DybFwdGates* gates = S.gates_pending ? &S.gates : nullptr;
-  S.gates_pending = false;
+  // waits for each range where it first reads it).  chain = false: the side stream's forward (possibly issued by the helper thread)
+  // - never a consumer of a ranged update (replica groups have no side stream) and it leaves the chain's gate state alone
+  const DybFwdGates* gates = (chain && S.gates_pending) ? &S.gates : nullptr;
+  if (chain) S.gates_pending = false;
   RUN(dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st, gates));
   const float* rot = P.acts + S.off_rot;
   const float* state = P.acts + S.off_state;
@@ -691,7 +708,7 @@ static int record_metrics(Stepper& S, Pass& P, const long long* gender, int slot
 static int issue_side_work(Stepper& S, hipStream_t side) {
   if (S.tail.on) {
     HIPOK(hipStreamWaitEvent(side, S.e_theta, 0));
-    RUN(pass_forward(S, S.fin, S.theta, S.tail.image, side));
+    RUN(pass_forward(S, S.fin, S.theta, S.tail.image, side, false));
     if (S.tail.metrics) RUN(record_metrics(S, S.fin, S.tail.gender, S.tail.slot, side));
     HIPOK(hipEventRecord(S.e_side, side));
     S.side_pending = true;
@@ -703,6 +720,72 @@ static int issue_side_work(Stepper& S, hipStream_t side) {
     S.gtjob.on = false;
   }
   return DYB_OK;
+}
+struct SideIssuer {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool has_job = false, quit = false;
+  std::atomic<int> busy{0};          // 1 from the post until every launch of the job has been issued
+  int rc = DYB_OK;
+  int device = 0;
+  Stepper* S = nullptr;
+  hipStream_t side = nullptr;
+  void main() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return has_job || quit; });
+        if (quit) return;
+        has_job = false;
+      }
+      rc = issue_side_work(*S, side);
+      busy.store(0, std::memory_order_release);
+    }
+  }
+};
+// the helper is idle and what it wrote is visible; returns its last result
+static int side_wait(Stepper& S) {
+  SideIssuer* I = S.issuer;
+  if (!I) return DYB_OK;
+  while (I->busy.load(std::memory_order_acquire)) std::this_thread::yield();
+  const int rc = I->rc;
+  I->rc = DYB_OK;
+  return rc;
+}
+// issue_side_work, by the helper thread when there is one
+static int side_post(Stepper& S, hipStream_t side) {
+  if (!S.side_thread || dyb_rep_current().n != 1) return issue_side_work(S, side);
+  if (!S.issuer) {
+    S.issuer = new SideIssuer();
+    S.issuer->S = &S;
+    if (hipGetDevice(&S.issuer->device) != hipSuccess) S.issuer->device = 0;
+    S.issuer->th = std::thread([I = S.issuer] { I->main(); });
+  }
+  RUN(side_wait(S));
+  SideIssuer* I = S.issuer;
+  I->side = side;
+  I->busy.store(1, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(I->mu);
+    I->has_job = true;
+  }
+  I->cv.notify_one();
+  return DYB_OK;
+}
+static void side_shutdown(Stepper& S) {
+  SideIssuer* I = S.issuer;
+  if (!I) return;
+  (void)side_wait(S);
+  {
+    std::lock_guard<std::mutex> lk(I->mu);
+    I->quit = true;
+  }
+  I->cv.notify_one();
+  if (I->th.joinable()) I->th.join();
+  delete I;
+  S.issuer = nullptr;
 }
 // Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
 // the deferred last range of a ranged weight update (see weight_update): issued from inside the consuming forward at layer3
@@ -817,6 +900,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
   // the frame the side stream is still busy with the previous frame's final forward, and waiting there stalled the main
   // chain for that whole tail (1.1 ms per frame in the kernel trace)
   bool gt_waited = !(metrics && side);
+  RUN(side_wait(S));                                  // (idle long since: the previous frame posted its job at its first level)
   HostTimer t_all(S.h_total);
   ++S.h_frames;
   const float* cur = S.theta;                    // clone(): the learner starts as an alias of theta
@@ -836,6 +920,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
       // inference() after inner step i-1 = this level's forward (same weights, same image: dynaboa_benchmark.py:142)
       if (metrics && S.eval_lower && i > 0) {
         if (!gt_waited) {
+          RUN(side_wait(S));                          // e_gt has been recorded
           HIPOK(hipStreamWaitEvent(st, S.e_gt, 0));
           gt_waited = true;
         }
@@ -848,7 +933,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     }
     if (i == 0 && side) {
       HostTimer t(S.h_tail);
-      RUN(issue_side_work(S, side));
+      RUN(side_post(S, side));
     }
     if (i < K) {
       HostTimer t(S.h_update);
@@ -858,6 +943,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
   }
   HostTimer t_tail(S.h_tail);
   // optimizer.step(): theta is about to change in place - the previous frame's tail on the side stream reads it
+  RUN(side_wait(S));
   if (S.side_pending) {
     HIPOK(hipStreamWaitEvent(st, S.e_side, 0));
     S.side_pending = false;
@@ -1260,6 +1346,7 @@ extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs
   for (int i = 0; i < na; ++i) DYB_REQUIRE(inputs[0 * n + act[i]] && inputs[1 * n + act[i]], DYB_ERR_ARG);
   // previous frame's tail on the side stream still reads the staged inputs
   hipStream_t gst = st;
+  RUN(side_wait(S));
   if (S.side_pending) HIPOK(hipStreamWaitEvent(gst, S.e_side, 0));
   RUN(stage_inputs(S, inputs, n, IN_IMAGE, 5, gst));
   const bool have_gt = inputs[2 * n + act[0]] && inputs[3 * n + act[0]] && inputs[4 * n + act[0]];
@@ -1275,6 +1362,7 @@ extern "C" int dyb_stepper_adapt_frames(void* stepper, const void* const* inputs
 extern "C" int dyb_stepper_join(void* stepper, hipStream_t st) {
   Stepper* S = reinterpret_cast<Stepper*>(stepper);
   DYB_REQUIRE(S, DYB_ERR_ARG);
+  RUN(side_wait(*S));
   if ((S->tail.on || S->gtjob.on) && S->tail_stream) RUN(issue_side_work(*S, S->tail_stream));      // the last frame's final inference
   if (S->side_pending) {
     HIPOK(hipStreamWaitEvent(st, S->e_side, 0));

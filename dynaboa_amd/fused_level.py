@@ -110,6 +110,7 @@ class _LevelFunction(torch.autograd.Function):
                                    drot_l.data_ptr(), dshape_l.data_ptr(), 10, dcam_l.data_ptr(), 3, djoints_l.data_ptr(), B,
                                    lws.data_ptr(), B * 16, st), "dyb_frame_losses")
         ctx.L, ctx.n_iter, ctx.smpl, ctx.B = L, n_iter, smpl, B
+        ctx.set_materialize_grads(False)            # unused outputs arrive as None in backward (handled there), not as zero-filled tensors
         _LAST_FORWARD[(B, H, W, str(dev))] = (_fwd_key(theta, image, init_state, n_iter), acts, theta, image, init_state)
         ctx.save_for_backward(theta, acts, buf)
         ctx.sizes = sizes

@@ -7,6 +7,8 @@ order as the autograd composition, issued from C++.  torch still owns every buff
 buffers are tensors; the stepper only holds their addresses."""
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import Dict, Optional
 
@@ -109,6 +111,9 @@ class NativeStepper:
             self.dynamic, self.optim_steps = int(g("dynamic_boa", 1)), int(g("optim_steps", 7))
         self.use_side = 1 if (S == 1 and getattr(adaptor, "_side", None) is not None) else 0
         si("use_side", self.use_side)
+        # the side stream's launches (previous frame's final forward + record, ground-truth meshes) from a helper thread of the library: at
+        # one sequence the frame is bound by the calling thread's launch rate (csrc/adapt_step.hip "side_thread"; DYB_SIDE_THREAD=0: in line)
+        si("side_thread", 1 if (self.use_side and hmr.theta.is_cuda and os.environ.get("DYB_SIDE_THREAD", "1") != "0") else 0)
         for k in ("lr", "beta1", "beta2", "fastlr", "s2dloss_weight", "shape_prior_weight", "pose_prior_weight"):
             sf(k, getattr(o, k))
         sf("eps", adaptor.optimizer.param_groups[0]["eps"])

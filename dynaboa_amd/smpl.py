@@ -41,6 +41,7 @@ class _LBSFunction(torch.autograd.Function):
         check(lib.dyb_lbs_fwd(smpl._pf, smpl._pi, betas.data_ptr(), betas.stride(0), rot.data_ptr(), verts.data_ptr(),
                               joints.data_ptr(), saved.data_ptr(), B, stream_of(betas)), "dyb_lbs_fwd")
         ctx.smpl = smpl
+        ctx.set_materialize_grads(False)            # an unused output's gradient arrives as None (backward handles both)
         ctx.save_for_backward(rot, saved)
         return verts, joints
 

@@ -125,6 +125,8 @@ static inline float __uint_as_float(unsigned u) {
   return f;
 }
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { emu::event_delete(e); return hipSuccess; }

@@ -258,6 +258,42 @@ def test_native_stepper_is_bit_identical_to_autograd_path(emu_lib):
     assert abs(a[6]["ul/total"] - g["upper_loss"][0]) < 1e-4 * abs(g["upper_loss"][0])
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~3 min under the emulator; set DYB_EMU_FULL=1")
+def test_native_stepper_side_stream_work_from_the_helper_thread(emu_lib, monkeypatch):
+    """"side_thread": the side stream's launches (previous frame's final forward + record, this frame's ground-truth meshes) issued by the
+    library's helper thread while the calling thread goes on with the chain.  The emulator executes a launch where it is issued, so the
+    two threads really interleave here: weights, Adam state and every metric record must equal the in-line run bit for bit - i.e. the
+    calling thread waits for the helper before it touches anything the helper writes."""
+    from types import SimpleNamespace
+    from dynaboa_amd import assets, benchmark as DB, native_step as NS
+    from dynaboa_amd._abi import check
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    frames = [assets.make_frame(s, 1, seed=22) for s in range(3)]
+    orig = NS.NativeStepper.adapt_frames
+    outs = []
+    for helper in (0, 1):
+        def wrapped(self, batches, side_stream=None, helper=helper):
+            self.use_side = 1
+            check(self.lib.dyb_stepper_set_i(self.h, b"use_side", 1), "use_side")
+            check(self.lib.dyb_stepper_set_i(self.h, b"side_thread", helper), "side_thread")
+            return orig(self, batches, SimpleNamespace(cuda_stream=2))       # any non-null handle is a stream to the emulator
+        monkeypatch.setattr(NS.NativeStepper, "adapt_frames", wrapped)
+        o = DB.frame_only_options(inner_step=1)
+        o.native_step, o.deferred_metrics = 1, 1
+        ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=True, randomize_norm=True), device="cpu")
+        res = ad.excute(frames, nframes=3)
+        assert ad._native is not None
+        st = ad.optimizer.state[ad.model.module.theta]
+        outs.append((ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                     np.ravel(np.array(res["pampjpe"], np.float64)), np.ravel(np.array(res["mpjpe"], np.float64)),
+                     np.ravel(np.array(res["pve"], np.float64))))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][3:], outs[1][3:]):
+        assert a.size == 3 and np.isfinite(a).all()                          # one final record per frame
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~4 min under the emulator; set DYB_EMU_FULL=1")
 def test_native_stepper_side_stream_schedule_under_adversarial_stream_order(emu_lib, monkeypatch):
     """The native frame step with its weight-gradient convolutions on the auxiliary stream, in the emulator's lazy stream mode (see

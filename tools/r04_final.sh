@@ -51,6 +51,19 @@ for k,v in d.items():
 sw = d.get("sequences_per_gpu_sweep", {})
 print("sweep", {k: (round(v["value"],1) if isinstance(v, dict) and v.get("value") else None) for k, v in sw.items() if k != "note"})
 PY
+# one sequence: the side stream's launches from the library's helper thread (default) against in line
+for tag in on off on2 off2; do
+  case $tag in on*) E=DYB_SIDE_THREAD=1;; *) E=DYB_SIDE_THREAD=0;; esac
+  env $E timeout 200 python bench.py --seqs 1 --steps 60 --warmup 10 $Q > $O/bench_s1_$tag.json 2> $O/bench_s1_$tag.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("$O/bench_s1_$tag.json").read().strip().splitlines()[-1])
+    print("one sequence, helper thread $tag:", round(d["value"], 2), "frames/s", round(d["ms_per_step"], 3), "ms/frame, host issue", round(d.get("host_issue_ms_per_step", 0), 3), flush=True)
+except Exception as e:
+    print("s1 $tag failed:", e, open("$O/bench_s1_$tag.err").read()[-500:])
+PY
+done
 # second order, one sequence: launches per frame with the tangent pairs as one launch (kernel stats of 8 frames)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trso -o trace -- python $R/bench.py --second_order 1 --seqs 1 --steps 8 --warmup 2 $Q) > $O/trace_so.log 2>&1
 f=$(find $O/trso -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_SO_S1.csv && python - <<PY
