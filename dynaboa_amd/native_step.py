@@ -111,9 +111,11 @@ class NativeStepper:
             self.dynamic, self.optim_steps = int(g("dynamic_boa", 1)), int(g("optim_steps", 7))
         self.use_side = 1 if (S == 1 and getattr(adaptor, "_side", None) is not None) else 0
         si("use_side", self.use_side)
-        # the side stream's launches (previous frame's final forward + record, ground-truth meshes) from a helper thread of the library: at
-        # one sequence the frame is bound by the calling thread's launch rate (csrc/adapt_step.hip "side_thread"; DYB_SIDE_THREAD=0: in line)
-        si("side_thread", 1 if (self.use_side and hmr.theta.is_cuda and os.environ.get("DYB_SIDE_THREAD", "1") != "0") else 0)
+        # DYB_SIDE_THREAD=1: the side stream's launches (previous frame's final forward + record, ground-truth meshes) from a helper thread of
+        # the library (csrc/adapt_step.hip "side_thread").  Off by default: measured on MI355X it changes nothing (93.7 frames/s either way,
+        # host issue 10.41 ms per frame both: the one-sequence frame is bound by the device's chain of ~950 dependent kernels, the
+        # calling thread merely keeps up with it - profiles/r04_sessions.txt, closing session)
+        si("side_thread", 1 if (self.use_side and hmr.theta.is_cuda and os.environ.get("DYB_SIDE_THREAD", "0") == "1") else 0)
         for k in ("lr", "beta1", "beta2", "fastlr", "s2dloss_weight", "shape_prior_weight", "pose_prior_weight"):
             sf(k, getattr(o, k))
         sf("eps", adaptor.optimizer.param_groups[0]["eps"])
