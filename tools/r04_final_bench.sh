@@ -2,7 +2,7 @@
 # Round 4: the driver's bench command once more at the final sources (the closing session's record was taken with the chain stream at
 # high priority, which broke two second-order side runs: see bench.chain_stream); PMC summaries under profiles/ stay valid (same csrc hash).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/final4; mkdir -p $O
+O=gpurun_out/final7; mkdir -p $O
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --conv_table $O/conv_table_S32.csv > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
 tail -3 $O/bench_time.txt
 python tools/conv_table.py $O/conv_table_S32.csv 80 > $O/conv_table_S32.txt 2>/dev/null; head -7 $O/conv_table_S32.txt
