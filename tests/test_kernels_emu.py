@@ -38,6 +38,33 @@ def test_conv_operand_pair(be, cfg):
     print(K.case_conv_pair(be, *cfg, seed=sum(cfg)))
 
 
+def test_conv_operand_pair_declines_what_it_does_not_cover(be):
+    """-1 for a bad mode or a missing second pair, -3 where the throughput schedule is in force or the option is off - never a silent
+    single-pair result."""
+    N, H, W, C, Kc, R, st, pad = 1, 8, 8, 64, 64, 1, 1, 0
+    x, w, y = be.dev(np.zeros((N, H, W, C), np.float32)), be.dev(np.zeros((R, R, C, Kc), np.float32)), be.empty((N, H, W, Kc))
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, Kc, R, R, st, pad)
+    ws = be.empty((max(wsb, 16) // 4,))
+    g = (N, H, W, C, Kc, R, R, st, pad, be.ptr(ws), wsb, be.stream)
+    call = lambda mode, a2, b2: be.lib.dyb_debug_conv_pair(mode, be.ptr(x), be.ptr(w), a2, b2, be.ptr(y), None, *g)
+    assert call(0, be.ptr(x), be.ptr(w)) == 0
+    assert call(3, be.ptr(x), be.ptr(w)) == -1
+    assert call(0, None, be.ptr(w)) == -1
+    be.lib.dyb_set_option(b"conv_pair", 0)
+    try:
+        assert call(0, be.ptr(x), be.ptr(w)) == -3
+    finally:
+        be.lib.dyb_set_option(b"conv_pair", 1)
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)             # throughput schedule for plain calls: the pair has no form there
+    try:
+        assert call(0, be.ptr(x), be.ptr(w)) == -3
+    finally:
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)
+    assert be.lib.dyb_gn_jvp_sync_words(0) == 0 and be.lib.dyb_gn_jvp_sync_words(2) == 2 * 4 + 1
+
+
 @pytest.fixture(params=[2, 1, 3], ids=["pipelined", "phased", "pipelined2"])
 def throughput_mode(be, request):
     """Throughput schedule forced on for plain calls (normally: launches covering >= 8 sequence replicas), once with each loop
