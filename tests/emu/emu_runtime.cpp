@@ -30,9 +30,9 @@ static int avail = -1;
 static thread_local bool held = false;
 static void init_locked() {
   if (avail >= 0) return;
-  long v = sysconf(_SC_NPROCESSORS_ONLN);
+  long v = 2 * sysconf(_SC_NPROCESSORS_ONLN);         // (fibers of a workgroup switch often: a little oversubscription pays)
   if (const char* e = getenv("DYB_EMU_PERMITS")) v = atol(e);
-  avail = (int)(v < 4 ? 4 : v > 16 ? 16 : v);
+  avail = (int)(v < 4 ? 4 : v > 32 ? 32 : v);
 }
 static void acquire() {
   std::unique_lock<std::mutex> lk(mu);

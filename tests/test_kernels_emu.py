@@ -432,7 +432,7 @@ def test_hmr_exact_hessian_vector_product(be, ckpt_rand, B):
     print(K.case_hmr_hvp(be, ckpt_rand, B=B))
 
 
-@pytest.mark.slow
+@pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): +40 s; the option paths, both off by default")
 def test_hmr_exact_hessian_vector_product_one_launch_groupnorm_tangents(be, ckpt_rand, monkeypatch):
     """The same with DYB_HVP_GN_ONEPASS=1 (the engine's per-layer arrival counters, zeroed per pass) and with the operand pairs off
     (two launches per tangent pair, second halves collected in hv2)."""
