@@ -135,6 +135,26 @@ def test_first_frame_first_order_outer_gradient_matches_reference(native):
     assert_first_frame_outer_gradient(ad, g)
 
 
+@pytest.mark.parametrize("native", [1, 0], ids=["native_stepper", "autograd_path"])
+def test_first_frame_outer_gradient_of_the_default_term_set_matches_reference(native):
+    """The same for the reference's DEFAULT flags (golden g5_fo_inner1_full: teacher term + labelled exemplars in both levels, the
+    dynamic-BOA gate - closed on frame 0 in the reference run too, so frame 0 ends after ONE Adam step): the first outer gradient
+    of the full term set, tensor by tensor, against the reference's own (base_adaptor.py:222-398, dynaboa_benchmark.py:126-193)."""
+    from dynaboa_amd import assets
+    g = golden("g5_fo_inner1_full.npz")
+    assert int(g["extra_steps"][0]) == 0
+    opts, ident = STREAMS["fo_inner1_full"]
+    ad, _ = make_adaptor(dict(opts, native_step=native), ident)
+    ad.reset_records(1)
+    ad.global_step = 0
+    ad.fit_losses = {}
+    ad.model.eval()
+    ad.adaptation({k: v.to(ad.device) for k, v in assets.make_frame(0, 1, seed=22).items()})
+    assert (ad._native is not None and ad._native.full) == bool(native)
+    assert ad.optim_step_record[-1] == 0
+    assert_first_frame_outer_gradient(ad, g)
+
+
 def test_deferred_metrics_equal_immediate():
     from dynaboa_amd import assets
     opts, ident = STREAMS["fo_inner1_frameonly_identity"]
