@@ -61,6 +61,7 @@ struct IgemmArgs {
   int M, Ncols, Kdim;    // GEMM sizes for this mode
   int ktiles, tiles_per_split, nsplit;
   int xcd;               // throughput form: XCD-contiguous workgroup order
+  int wt;                // throughput form: cache policy of the result stores ("tp_wt": 0 plain, 1 sc1 write-through, 2 nt, 3 sc0 sc1)
   int cls_tile0[4];      // throughput data gradient: first tile (grid x) of each phase class (stride 2)
   int compact;           // throughput data gradient of a 1x1 stride-2 conv: only the one class that has a tap is computed, rows written
                          // COMPACT (class-local index) into slabs of slab_rows rows; a scatter fold places them (run_igemm_tp)
@@ -1133,7 +1134,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1156,6 +1157,7 @@ struct DybSwitches {
     tp_gn_poll = env("DYB_TP_GN_POLL", 8);
     tp_fwd_nosplit2 = env("DYB_TP_FWD_NOSPLIT2", 1);
     pair = env("DYB_CONV_PAIR", 1);
+    tp_wt = env("DYB_TP_WT", 1);
   }
 };
 static DybSwitches& switches() {
@@ -1187,6 +1189,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_gn_poll")) return &s.tp_gn_poll;
   if (!strcmp(name, "tp_fwd_nosplit2")) return &s.tp_fwd_nosplit2;
   if (!strcmp(name, "conv_pair")) return &s.pair;
+  if (!strcmp(name, "tp_wt")) return &s.tp_wt;
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1450,6 +1453,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   const int TM = form == 0 ? 128 : form == 1 ? 64 : 256, TN = form == 0 ? 128 : form == 1 ? 256 : 64;
   g.ktiles = dyb_cdiv(g.Kdim, TPK);
   g.xcd = switches().tp_xcd.load(std::memory_order_relaxed);
+  g.wt = switches().tp_wt.load(std::memory_order_relaxed);
   int mtiles = dyb_cdiv(g.M, TM), work_mtiles = mtiles;
   g.cls_tile0[0] = g.cls_tile0[1] = g.cls_tile0[2] = g.cls_tile0[3] = 0;
   if (classes) {

@@ -241,6 +241,8 @@ class NativeStepper:
         # the weight-gradient stream is this stepper's own: several steppers (sequence replicas on one GPU) must not
         # serialise on one shared auxiliary stream
         self._aux = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        if os.environ.get("DYB_NO_AUX") == "1":      # diagnostic: every launch on the chain's stream (per-kernel durations without company)
+            self._aux = None
 
     def __del__(self):
         try:

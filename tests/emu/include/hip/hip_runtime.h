@@ -95,6 +95,13 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
   memcpy(&v, r.p + off, 16);
   return v;
 }
+// raw buffer store: a per-lane offset >= num_records is dropped (cache-policy bits ignored)
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  if ((unsigned)voff >= r.n) return;
+  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  if (off + 16 > r.n) { fprintf(stderr, "emu: buffer store leaves the buffer (%llu + 16 > %u)\n", off, r.n); abort(); }
+  memcpy(const_cast<char*>(r.p) + off, &v, 16);
+}
 static inline void __threadfence_system() {}
 // Inter-workgroup hand-offs (the one-pass GroupNorm backward: a few workgroups of consecutive ids meet on a counter).  The
 // emulator claims workgroups in id order on a pool of OS threads (emu_runtime.cpp: at least 8), so a workgroup that polls for
