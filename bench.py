@@ -502,6 +502,9 @@ def main():
     ap.add_argument("--probe_out", type=str, default="")
     ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")
     ap.add_argument("--cpu_baseline_only", action="store_true")
+    ap.add_argument("--all_sub_records", action="store_true",
+                    help="also the side runs whose kernels have not changed since round 3 (finite-difference HVP, batch 16 on the latency "
+                         "schedule, the 32-sequence bf16 arm)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args.inner_step)))
@@ -718,10 +721,21 @@ def main():
                                              "configs[1] second-order arm: one sequence, second_order=1, exact Hessian-vector products "
                                              "(tangent passes through the network, forward-over-reverse, both halves of every tangent pair in one conv launch; the default)", second_order=1,
                                              hvp="exact")
-            out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 12, 3, 1, args.inner_step,
-                                                    "the same with --hvp fd: Hessian-vector products as central differences of two "
-                                                    "first-order gradients of the level (+2 forward+backward per inner step)",
-                                                    second_order=1, hvp="fd")
+            # the two literal readings of BASELINE's metric as first-class keys: ONE bs=1 stream, first order and second order
+            s1 = reps.get("S1") or {}
+            out["single_stream"] = dict(value=s1.get("value"), unit="adapted frames/s", ms_per_step=s1.get("ms_per_step"),
+                                        note="ONE sequence on the GPU, batch 1, 3 inner + 1 outer step, first order, frame losses: the literal "
+                                             "'bs=1' reading of the metric (= sequences_per_gpu_sweep.S1)")
+            s5 = reps.get("S5") or {}
+            out["pw3d_operating_point"] = dict(value=s5.get("value"), unit="adapted frames/s", sequences_per_gpu=5, ms_per_step=s5.get("ms_per_step"),
+                                               note="ceil(37 / 8) = 5 sequences per GPU: what an 8-GPU sharded run of the real 3DPW test stream (~37 "
+                                                    "person tracks) keeps in flight per GPU (= sequences_per_gpu_sweep.S5; with --gpus N > 1 the timed loop "
+                                                    "is re-run at ceil(37 / N) on all ranks)")
+            if args.all_sub_records:
+                out["second_order_fd_hvp"] = sub_record(device, "second_order_fd_hvp", 12, 3, 1, args.inner_step,
+                                                        "the same with --hvp fd: Hessian-vector products as central differences of two "
+                                                        "first-order gradients of the level (+2 forward+backward per inner step)",
+                                                        second_order=1, hvp="fd")
             out["batch8_exemplars"] = sub_record(device, "batch8_exemplars", 10, 3, 8, args.inner_step,
                                                  "configs[2]: batch 8, lower+upper level labelled exemplars mixed in (S=8 per level), "
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
@@ -735,11 +749,12 @@ def main():
                                 "bf16 MFMA for the convolutions (v_mfma_f32_32x32x16_bf16 in the throughput kernel; fp32 master weights / "
                                 "activations / statistics / accumulators)", roofline_peak=PEAK_BF16_MFMA_TFLOPS, bf16_mfma=1))
             __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(16).set_bf16(False)
-            out["bf16_S32"] = sub_record(
-                device, "bf16_S32", 10, 3, 1, args.inner_step, "the headline workload (32 sequences in lockstep, first-order, frame losses) with the "
-                "convolutions on the bf16 matrix cores - NOT the parity configuration (operands rounded to bf16; fp32 master weights / activations / "
-                "statistics / accumulators)", roofline_peak=PEAK_BF16_MFMA_TFLOPS, seqs=32, bf16_mfma=1)
-            __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(1).set_bf16(False)
+            if args.all_sub_records:
+                out["bf16_S32"] = sub_record(
+                    device, "bf16_S32", 10, 3, 1, args.inner_step, "the headline workload (32 sequences in lockstep, first-order, frame losses) with the "
+                    "convolutions on the bf16 matrix cores - NOT the parity configuration (operands rounded to bf16; fp32 master weights / activations / "
+                    "statistics / accumulators)", roofline_peak=PEAK_BF16_MFMA_TFLOPS, seqs=32, bf16_mfma=1)
+                __import__("dynaboa_amd.hmr", fromlist=["get_layout"]).get_layout(1).set_bf16(False)
             torch.cuda.empty_cache()
             out["batch16_first_vs_second_order"] = dict(
                 first_order=dict(value=out["batch16_fp32_vs_bf16"]["fp32"].get("value"), unit="adapted frames/s",
@@ -747,13 +762,14 @@ def main():
                 second_order=sub_record(device, "b16_so", 6, 2, 16, args.inner_step, "configs[4] arm: batch 16, SECOND-order outer gradient "
                                         "(exact Hessian-vector products), frame losses, fp32", second_order=1, hvp="exact"))
             from dynaboa_amd import _lib as _L
-            try:
-                _L.load().dyb_set_option(b"tp_batch_min", 0)
-                out["batch16_fp32_vs_bf16"]["fp32_latency_schedule"] = sub_record(
-                    device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
-                    "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
-            finally:
-                _L.load().dyb_set_option(b"tp_batch_min", 16)
+            if args.all_sub_records:
+                try:
+                    _L.load().dyb_set_option(b"tp_batch_min", 0)
+                    out["batch16_fp32_vs_bf16"]["fp32_latency_schedule"] = sub_record(
+                        device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
+                        "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
+                finally:
+                    _L.load().dyb_set_option(b"tp_batch_min", 16)
             out["full_default_losses"] = sub_record(device, "full_default_losses", 24, 6, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)
@@ -806,7 +822,15 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(inner_step=args.inner_step)
-        print(json.dumps(out))
+        # the literal one-stream readings as scalars right behind `value` (full records further down the line)
+        front = ("metric", "value", "unit")
+        line = {k: out[k] for k in front if k in out}
+        if isinstance(out.get("single_stream"), dict):
+            line["single_stream_frames_per_s"] = out["single_stream"].get("value")
+        if isinstance(out.get("second_order"), dict):
+            line["second_order_single_stream_frames_per_s"] = out["second_order"].get("value")
+        line.update({k: v for k, v in out.items() if k not in front})
+        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -554,6 +554,21 @@ class Adaptor(BaseAdaptor):
         return flush_metrics_of([self])[0]
 
 
+def check_sync_errors():
+    """The library's in-kernel hand-offs (one-pass GroupNorm backward: the workgroups of a slab meet on a counter) give up after ~0.2 s
+    rather than block the queue, and the launch then goes on with incomplete sums.  Called where the host synchronises anyway (the
+    metric flush): a non-zero count means adapted weights since the last check cannot be trusted - fail loudly."""
+    import ctypes
+    if not torch.cuda.is_available():
+        return
+    from . import _lib
+    n = ctypes.c_uint(0)
+    rc = _lib.load().dyb_sync_error_count(ctypes.byref(n), torch.cuda.current_stream().cuda_stream)
+    if rc != 0 or n.value != 0:
+        raise RuntimeError(f"libdynaboa_hip: {n.value} in-kernel hand-off(s) timed out (rc {rc}): results are invalid; "
+                           "set DYB_TP_GN_ONEPASS=1 (single-workgroup slabs only) on a shared or partitioned GPU")
+
+
 def flush_metrics_of(adaptors):
     """`Adaptor.flush_metrics` for several adaptors at once (the sequences of a ReplicaGroup): the deferred records of all of them
     go through ONE Procrustes launch and ONE device->host transfer instead of one of each per adaptor.  -> list of the per-adaptor
@@ -577,6 +592,7 @@ def flush_metrics_of(adaptors):
         pa_t = pa_mpjpe_device(pred.reshape(n * B, 14, 3), gt.reshape(n * B, 14, 3)).view(n, B)
         allm = torch.cat([torch.stack([r['mpjpe'] for r in flat]).reshape(n, B), pa_t,
                           torch.stack([r['pve'] for r in flat]).reshape(n, 1)], 1).cpu().numpy() * 1000
+    check_sync_errors()
     outs, i0 = [], 0
     for rec in recs:
         out = dict(mpjpe=[], pampjpe=[], pve=[], records=[])

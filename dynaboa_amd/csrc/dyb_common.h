@@ -130,6 +130,20 @@ struct DybRepScope {
   ~DybRepScope();
 };
 
+// counter region of the in-kernel split-K fold for the calling host thread's conv launches (igemm_conv.hip): `nwords` words, zero
+// before the first launch that uses them (every launch leaves them zero); one word per (replica slot of the launch, tile), shared by
+// the replicas of a launch (never rebased).  One region per stream that convolutions are issued on concurrently.
+struct DybConvSync {
+  unsigned* ctr;
+  int nwords;
+};
+struct DybConvSyncScope {
+  DybConvSync saved;
+  DybConvSyncScope(unsigned* ctr, int nwords);
+  ~DybConvSyncScope();
+};
+#define DYB_CONV_SYNC_WORDS 16384
+
 // bf16 matrix-core mode of the calling host thread (igemm_conv.hip)
 bool dyb_bf16_current();
 struct DybBf16Scope {

@@ -261,7 +261,8 @@ static HmrPlan* build_plan(int B, int H, int W) {
   // regressor gradient scratch: d_st[4][B][160], d_h2[3][B][1024], d_h1[3][B][1024], d_xc[B][2208], two [B][1024] for sum_t d_h1[t]
   P.ws_reg = align64((size_t)B * (4 * STATE_LD + 8 * HID + FC1_IN_PAD)) * 4;
   // arrival counters of the one-pass GroupNorm backward: SYNC_WORDS per conv layer (4 groups + the error word), zeroed per backward
-  P.ws_sync = align64(P.convs.size() * SYNC_WORDS) * 4;
+  // + two counter regions of the convolutions' in-kernel split-K fold (chain stream | auxiliary stream), zeroed per pass
+  P.ws_sync = (align64(P.convs.size() * SYNC_WORDS) + 2 * (size_t)DYB_CONV_SYNC_WORDS) * 4;
   P.ws_total = P.ws_conv + P.ws_conv_aux + 3 * P.ws_gn + P.ws_gnb + P.ws_lin + 3 * P.ws_grad_each + P.ws_dy + P.ws_reg + P.ws_dy2 + P.ws_sync;
   return pp;
 }
@@ -439,6 +440,10 @@ static WsCarve carve(const HmrPlan& P, void* ws) {
   return c;
 }
 
+// counter region `which` (0: the chain's stream, 1: the auxiliary stream) of the in-kernel split-K fold (igemm_conv.hip)
+static unsigned* conv_ctr(const HmrPlan& P, const WsCarve& w, int which) {
+  return w.sync + align64(P.convs.size() * SYNC_WORDS) + (size_t)which * DYB_CONV_SYNC_WORDS;
+}
 // one forward layer: conv (+ the producer's GroupNorm/ReLU applied in its loader when `prev` is given) and the
 // GroupNorm statistics of its raw output into `part_out` (*nch_out partial records)
 static int conv_stats(const HmrPlan& P, const ConvL& c, const float* params, float* acts, const float* x, const ConvL* prev,
@@ -557,6 +562,9 @@ static int forward_body(const HmrPlan& P, const float* params, const float* init
   DybBf16Scope bf(P.bf16 != 0);
   const int B = P.B;
   const ConvL& stem = P.convs[0];
+  // split-K folds happen inside the conv launches, on this pass's counters (zero before the first launch; every launch leaves them zero)
+  RUN(dyb_zero_words(conv_ctr(P, w, 0), DYB_CONV_SYNC_WORDS, st));
+  DybConvSyncScope conv_sync(conv_ctr(P, w, 0), DYB_CONV_SYNC_WORDS);
   int nA = 0, nB = 0, nD = 0;                 // partial counts behind w.gn[0], [1], [2]
   RUN(conv_stats(P, stem, params, acts, acts + P.a_x4, nullptr, nullptr, 0, w.gn[0], &nA, w, st));
   RUN(dyb_groupnorm_apply_n(acts + stem.y, w.gn[0], nA, params + stem.gam, params + stem.bet, nullptr, nullptr, 0, nullptr,
@@ -664,6 +672,7 @@ static int run_wgrad(HmrPlan& P, const WgradJob& j, const float* params, const f
   const ConvL& c = P.convs[j.ci];
   const float* part = w.gnb + c.gnb;
   const ConvL* ip = j.in_prev;       // non-null: the conv's input was relu(gn(y_prev)), never materialised
+  DybConvSyncScope conv_sync(conv_ctr(P, w, slabs == (void*)w.conv_aux ? 1 : 0), DYB_CONV_SYNC_WORDS);   // auxiliary stream: its own counters
   if (j.dy) {
     ConvDesc d{P.B, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad};
     return dyb_conv_wgrad_plain(d, ip ? nullptr : j.conv_in, ip ? acts + ip->y : nullptr, ip ? acts + ip->stats : nullptr,
@@ -908,8 +917,10 @@ static int backward_body(HmrPlan& P, const float* params, const float* acts, con
   // branch, Rb holds the shortcut branch's data gradient; the residual-edge gradient of a block is the
   // dm of its third GroupNorm (the ReLU-masked incoming gradient), used in place.
   float *D0 = w.g[0], *D1 = w.g[1], *Rb = w.g[2];
-  if (dyb_throughput_mode(P.B) && dyb_tp_gn_onepass() > 1 && P.B == 1)      // arrival counters of the one-pass GroupNorm backward
-    RUN(dyb_zero_words(w.sync, (int)(P.convs.size() * SYNC_WORDS), st));
+  // arrival counters of the one-pass GroupNorm backward and of the convolutions' in-kernel split-K fold (both streams' regions: the
+  // auxiliary stream's launches of this call are ordered behind this point by the per-layer events)
+  RUN(dyb_zero_words(w.sync, (int)(align64(P.convs.size() * SYNC_WORDS) + 2 * DYB_CONV_SYNC_WORDS), st));
+  DybConvSyncScope conv_sync(conv_ctr(P, w, 0), DYB_CONV_SYNC_WORDS);
   RUN(dyb_avgpool_bwd(d_xf, FC1_IN_PAD, D0, B, P.featHW, FEAT, st));
   Pending cur = plain(D0);
   float* free_buf = D1;          // the D buffer `cur` does not occupy (a pending `cur` lives in the slab region)

@@ -35,6 +35,11 @@ __device__ __forceinline__ float jvp_load_dev(const float* p) {
 }
 // thread 0 of a workgroup: arrive on `ctr` (after the workgroup's device-scope stores have drained: callers put s_waitcnt vmcnt(0) and a
 // barrier in front) and wait until `need` workgroups have
+__device__ unsigned g_jvp_sync_errors = 0u;              // timed-out waits since load (norm_pool.hip dyb_sync_error_count)
+int dyb_hvp_sync_errors(unsigned* host_out, hipStream_t st) {
+  return hipMemcpyFromSymbolAsync(host_out, HIP_SYMBOL(g_jvp_sync_errors), sizeof(unsigned), 0, hipMemcpyDeviceToHost, st) == hipSuccess
+             ? DYB_OK : DYB_ERR_LAUNCH;
+}
 __device__ __forceinline__ void jvp_arrive(unsigned* ctr) { atomicAdd(ctr, 1u); }
 __device__ __forceinline__ void jvp_wait(unsigned* ctr, unsigned need, unsigned* err) {
   const long long t0 = wall_clock64();
@@ -42,6 +47,7 @@ __device__ __forceinline__ void jvp_wait(unsigned* ctr, unsigned need, unsigned*
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
       atomicAdd(err, 1u);
+      atomicAdd(&g_jvp_sync_errors, 1u);
       break;
     }
   }

@@ -70,7 +70,10 @@ struct IgemmArgs {
   const float* A2;       // operand PAIR (latency form, no fused loaders): out = A (x) B + A2 (x) B2 as ONE K loop - K-tiles [0, ktiles1)
   const float* B2;       // read (A, B), K-tiles [ktiles1, ktiles) read (A2, B2) at tile index - ktiles1.  The tangent passes of the exact
   int ktiles1;           // Hessian-vector product are made of such pairs (hvp_engine.inc); ktiles1 == ktiles: a plain conv
-  float* gn_part;        // throughput forward, one image, nsplit == 1: the GroupNorm statistics of the OUTPUT leave with the tile - one
+  float* fold_out;       // in-kernel split-K fold (nsplit > 1, a counter region in scope): the workgroup that arrives LAST on a tile's counter adds
+  const float* fold_addend;  // the tile's nsplit slabs in split order (+ fold_addend) into fold_out and, forward, leaves the tile's GroupNorm
+  unsigned* fold_ctr;    // statistics in gn_part; NULL: slabs are left for a fold launch / the consumer.  fold_ctr: one word per tile, zero
+  float* gn_part;        // throughput forward, one image, nsplit == 1 (or folded in-kernel): the GroupNorm statistics of the OUTPUT leave with the tile - one
                          // [G][2] (sum, sum of squares) record per wave tile, [(lx * WM + wm) * ntiles_n * WN + ly * WN + wn] - instead of
                          // a statistics launch re-reading y (igemm_tp.inc epilogue)
 };
@@ -283,6 +286,7 @@ struct GnFwdFuse {
 __device__ __forceinline__ void rebase(IgemmArgs& g, const DybRep& R, int rep) {
   g.A = dyb_rb(g.A, R, rep); g.B = dyb_rb(g.B, R, rep); g.out = dyb_rb(g.out, R, rep); g.addend = dyb_rb(g.addend, R, rep);
   g.gn_part = dyb_rb(g.gn_part, R, rep); g.A2 = dyb_rb(g.A2, R, rep); g.B2 = dyb_rb(g.B2, R, rep);
+  g.fold_out = dyb_rb(g.fold_out, R, rep); g.fold_addend = dyb_rb(g.fold_addend, R, rep);     // (fold_ctr is shared: indexed by the launch's replica slot)
 }
 __device__ __forceinline__ void rebase(GnBwdFuse& f, const DybRep& R, int rep) {
   f.y = dyb_rb(f.y, R, rep); f.stats = dyb_rb(f.stats, R, rep); f.gpart = dyb_rb(f.gpart, R, rep); f.gamma = dyb_rb(f.gamma, R, rep);
@@ -393,6 +397,32 @@ __device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, 
   __syncthreads();
 }
 
+// buffer resource over [p, p + bytes) (raw, stride 0; gfx9 data-format word) and a 16-byte load through it
+#define TP_OOB 0x80000000u
+typedef unsigned tp_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tp_rsrc(const float* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
+__device__ __forceinline__ float4 tp_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;      // (bit_cast straight from a vector element reads element 0 on host clang)
+  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
+}
+// 16-byte store through a buffer resource with cache policy AUX (0 plain, 16 = sc1: write-through at device scope, 2 = nt, 17 = sc0 sc1);
+// a per-lane offset >= num_records (TP_OOB) is dropped by the hardware
+template <int AUX>
+__device__ __forceinline__ void tp_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  tp_u4 x;
+  x.x = __builtin_bit_cast(unsigned, v.x); x.y = __builtin_bit_cast(unsigned, v.y);
+  x.z = __builtin_bit_cast(unsigned, v.z); x.w = __builtin_bit_cast(unsigned, v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)voff, 0, AUX);
+}
+// the same load past the vector L1 (sc1): data another workgroup of this launch stored write-through
+__device__ __forceinline__ float4 tp_buf_load4_dev(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16);
+  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;
+  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
+}
 // BF: the bf16 matrix-core variant (BASELINE configs[4]).  Everything up to the staging store is the same fp32 code - operands
 // come from fp32 HBM tensors (master weights, fp32 activations), the GroupNorm arithmetic of the fused loaders and the
 // accumulators stay fp32 - but the operand tiles are rounded to bf16 (nearest-even) when they are staged and the product runs
@@ -635,6 +665,7 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
 
   // C/D fragment of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* outp = g.out + (g.nsplit > 1 ? (size_t)dyb_bz * g.M * g.Ncols : 0);
+  if constexpr (BF) {
   const int col = n0 + wn * 32 + (lane & 31);
   if (g.nsplit == 1 && g.addend) {
     // the 16 addend values are fetched together (clamped addresses), not one conditional load + wait per row
@@ -653,6 +684,119 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
     for (int r = 0; r < 16; ++r) {
       int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row < g.M) outp[(size_t)row * g.Ncols + col] = acc[r];
+    }
+  }
+  } else {
+    // The 64 x 64 tile goes through LDS (the operand stages are free: the K loop ended on a barrier) so that a work-item holds four
+    // 16-byte row pieces instead of sixteen scalars of one column: 16-byte stores, and a layout in which
+    //   * a split launch with a counter region in scope folds in-kernel ("lat_fold"): every workgroup stores its partial tile
+    //     write-through into its split's slab and arrives on the tile's counter; the LAST to arrive adds the nsplit slabs in split
+    //     order (the result does not depend on who was last), adds the addend and writes the result - no fold launch;
+    //   * a forward launch of ONE image leaves the tile's GroupNorm statistics (one [G][2] record per workgroup tile) - from the
+    //     accumulators when K is unsplit, from the folded tile otherwise - instead of a statistics launch re-reading y.
+    float(*T)[LDS_LD] = reinterpret_cast<float(*)[LDS_LD]>(&As[0][0][0]);
+    __shared__ float s_st[4][4][2];
+    __shared__ int s_last;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn * 32 + (lane & 31)] = acc[r];
+    __syncthreads();
+    const int er = tid >> 4, ec = (tid & 15) * 4;
+    const int col4 = n0 + ec;
+    float4 v[4];
+    unsigned vo[4];                                      // byte offset of the piece in the result matrix, TP_OOB: past the end
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + er + 16 * j;
+      v[j] = *reinterpret_cast<const float4*>(&T[er + 16 * j][ec]);
+      vo[j] = (row < g.M && col4 < g.Ncols) ? (unsigned)(((size_t)row * g.Ncols + col4) * 4) : TP_OOB;
+    }
+    const size_t mat_bytes = (size_t)g.M * g.Ncols * sizeof(float);
+    const bool fold = g.fold_out != nullptr;
+    bool finish = true;                                  // this workgroup holds the finished tile in v[]
+    const float* addp = g.addend;
+    float* dst = outp;
+    if (fold) {
+      const __amdgpu_buffer_rsrc_t rsP = tp_rsrc(outp, mat_bytes);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tp_buf_store4<16>(rsP, vo[j], v[j]);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // the write-through stores have left before this workgroup arrives
+      __syncthreads();
+      if (tid == 0) {
+        unsigned* c = g.fold_ctr + (((size_t)dyb_lrep * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y);
+        const unsigned old = atomicAdd(c, 1u);
+        const bool last = old + 1u == (unsigned)g.nsplit;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last ? 1 : 0;
+      }
+      __syncthreads();
+      finish = s_last != 0;
+      if (finish) {
+        float4 sum[4] = {zero4, zero4, zero4, zero4};
+        for (int z0 = 0; z0 < g.nsplit; z0 += 4) {       // four slabs' pieces in flight per trip; added in split order
+          float4 tz[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int z = z0 + q;
+            const __amdgpu_buffer_rsrc_t rsZ = tp_rsrc(g.out + (size_t)(z < g.nsplit ? z : 0) * g.M * g.Ncols, z < g.nsplit ? mat_bytes : 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tz[q][j] = tp_buf_load4_dev(rsZ, vo[j]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sum[j].x += tz[q][j].x; sum[j].y += tz[q][j].y; sum[j].z += tz[q][j].z; sum[j].w += tz[q][j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sum[j];
+        addp = g.fold_addend;
+        dst = g.fold_out;
+      }
+    } else if (g.nsplit > 1) {
+      addp = nullptr;
+    }
+    if (finish) {
+      if (addp) {
+        float4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(addp + (vo[j] != TP_OOB ? vo[j] / 4 : 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w; }
+      }
+      if constexpr (MODE == MODE_FWD) {
+        if (g.gn_part != nullptr && (g.nsplit == 1 || fold)) {
+          // rows / columns past the end hold exact zeros.  A work-item's pieces lie in one group (4 adjacent columns, groups are >= 16
+          // wide); lanes l, l^16, l^32 hold other rows of the same columns; qpg = 16-byte column pieces of the tile per group
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s1 += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            s2 += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+          }
+          s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          const int cpg = g.K >> 2;                        // columns per group (>= 16, a power of two: host-checked)
+          const int qpg = (cpg < 64 ? cpg : 64) >> 2;      // 4, 8 or 16
+          for (int m = 1; m < qpg; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+          if (lane < 16 && (lane & (qpg - 1)) == 0) { s_st[wave][lane / qpg][0] = s1; s_st[wave][lane / qpg][1] = s2; }
+          __syncthreads();
+          if (tid < DYB_GN_GROUPS) {
+            const int gi = tid, c0 = gi * cpg;             // group gi covers columns [c0, c0 + cpg)
+            const int lo = c0 > n0 ? c0 : n0, hi = (c0 + cpg) < (n0 + 64) ? (c0 + cpg) : (n0 + 64);
+            float t1 = 0.f, t2 = 0.f;
+            if (lo < hi) {
+              const int seg = (lo - n0) / (4 * qpg);
+              t1 = (s_st[0][seg][0] + s_st[1][seg][0]) + (s_st[2][seg][0] + s_st[3][seg][0]);
+              t2 = (s_st[0][seg][1] + s_st[1][seg][1]) + (s_st[2][seg][1] + s_st[3][seg][1]);
+            }
+            float* rec = g.gn_part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (DYB_GN_GROUPS * 2);
+            rec[gi * 2] = t1;
+            rec[gi * 2 + 1] = t2;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (vo[j] != TP_OOB) *reinterpret_cast<float4*>(dst + vo[j] / 4) = v[j];
     }
   }
 
@@ -1121,6 +1265,20 @@ const DybRep& dyb_rep_current() { return t_rep; }
 DybRepScope::DybRepScope(const DybRep& r) : saved(t_rep) { t_rep = r; }
 DybRepScope::~DybRepScope() { t_rep = saved; }
 
+// Counter region for the in-kernel split-K fold of the calling host thread's conv launches (the engine sets one per stream it issues
+// convolutions on: two launches that may run concurrently must not share counters).  Outside a scope: no region, split launches
+// leave slabs as before.  The words must be zero when the first launch uses them; every launch leaves them zero.  One word per
+// (replica slot of the launch, tile): the region is NOT replicated - a pointer into replica 0's workspace serves every replica.
+static thread_local DybConvSync t_conv_sync = {nullptr, 0};
+DybConvSyncScope::DybConvSyncScope(unsigned* ctr, int nwords) : saved(t_conv_sync) { t_conv_sync = DybConvSync{ctr, nwords}; }
+DybConvSyncScope::~DybConvSyncScope() { t_conv_sync = saved; }
+// tests / lab: a region for the calling thread's plain conv calls until reset with (NULL, 0)
+extern "C" int dyb_debug_set_conv_sync(unsigned* ctr, int nwords) {
+  DYB_REQUIRE((ctr == nullptr) == (nwords == 0) && nwords >= 0, DYB_ERR_ARG);
+  t_conv_sync = DybConvSync{ctr, nwords};
+  return DYB_OK;
+}
+
 // ---- run-time switches ------------------------------------------------------------------------------------
 // Read from the environment ONCE (first use), never on the dispatch path; dyb_set_option changes one afterwards
 // (tests / A-B runs).  Names: "k4" (single-launch 1x1 forward + statistics), "k4_bwd" (1x1 data gradient carries the
@@ -1134,7 +1292,7 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt, tp_fold, lat_fold, stat_folds;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1158,6 +1316,9 @@ struct DybSwitches {
     tp_fwd_nosplit2 = env("DYB_TP_FWD_NOSPLIT2", 1);
     pair = env("DYB_CONV_PAIR", 1);
     tp_wt = env("DYB_TP_WT", 1);
+    tp_fold = env("DYB_TP_FOLD", 0);       // measured (r05 s3): 32 sequences 461 vs 463 frames/s off, 16: 362 vs 376 - the folding workgroups are a tail
+    lat_fold = env("DYB_LAT_FOLD", 1);
+    stat_folds = 0;
   }
 };
 static DybSwitches& switches() {
@@ -1190,6 +1351,9 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_fwd_nosplit2")) return &s.tp_fwd_nosplit2;
   if (!strcmp(name, "conv_pair")) return &s.pair;
   if (!strcmp(name, "tp_wt")) return &s.tp_wt;
+  if (!strcmp(name, "tp_fold")) return &s.tp_fold;
+  if (!strcmp(name, "lat_fold")) return &s.lat_fold;
+  if (!strcmp(name, "stat_folds")) return &s.stat_folds;      // (a counter, not a switch: conv launches that folded their split in-kernel)
   return nullptr;
 }
 extern "C" int dyb_set_option(const char* name, int value) {
@@ -1506,18 +1670,26 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.out = (split || g.compact) ? reinterpret_cast<float*>(ws) : out;          // (compact: always through the scatter fold)
   g.addend = (split || g.compact) ? nullptr : addend;
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
-  g.gn_part = nullptr;
-  if (stats_nrec) *stats_nrec = 0;
-  if (stats_fusable && !split) {
-    g.gn_part = stats_part;
-    *stats_nrec = stats_records;
-  }
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);
   // 1: round 2's phase-separated loop (also what the phase probe and
   // weight gradients over maps too small for the branch-free pixel walk use)
   const int tpk = switches().tp_kernel.load(std::memory_order_relaxed);
   const int pipe = (tpk >= 2 && !g.probe && !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho)) ? (tpk >= 3 ? 2 : 1) : 0;
+  // in-kernel fold ("tp_fold"): a counter region in scope, the pipelined kernel, plain slabs (not the compact stride-2 form)
+  const bool fold = split && !g.compact && pipe != 0 && t_conv_sync.ctr && (long)grid.x * grid.y * R.n <= (long)t_conv_sync.nwords &&
+                    !(raw_slabs_out && mode != MODE_FWD) && switches().tp_fold.load(std::memory_order_relaxed);
+  g.fold_out = nullptr; g.fold_addend = nullptr; g.fold_ctr = nullptr;
+  if (fold) {
+    g.fold_out = out; g.fold_addend = addend; g.fold_ctr = t_conv_sync.ctr;
+    switches().stat_folds.fetch_add(1, std::memory_order_relaxed);
+  }
+  g.gn_part = nullptr;
+  if (stats_nrec) *stats_nrec = 0;
+  if (stats_fusable && (!split || fold)) {
+    g.gn_part = stats_part;
+    *stats_nrec = stats_records;
+  }
   const bool bf = dyb_bf16_current();
   DYB_REQUIRE(!bf || pipe != 0, DYB_ERR_UNSUPPORTED);
   GnFwdFuse nf{};
@@ -1579,6 +1751,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
     DYB_CHECK_LAUNCH();
     return DYB_OK;
   }
+  if (fold) return DYB_OK;                       // the result (and, forward, its statistics) left with the last workgroup of every tile
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
     size_t n4 = per / 4;
@@ -1618,6 +1791,23 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   g.addend = split ? nullptr : addend;
   const DybRep& R = dyb_rep_current();
   dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit * R.n);
+  // in-kernel split-K fold ("lat_fold": a counter region in scope; fp32 form - its epilogue goes through LDS) and, forward of one
+  // image, the output's GroupNorm statistics with the tiles (one record per workgroup tile; what a layer's partial slot holds)
+  const bool lat = !dyb_bf16_current() && (size_t)g.M * g.Ncols * sizeof(float) < 0x7fffffffu && switches().lat_fold.load(std::memory_order_relaxed);
+  // (not where the caller's next kernel folds the slabs while it reads them anyway: a gradient handed on as raw slabs)
+  const bool kfold = split && lat && t_conv_sync.ctr && (long)grid.x * grid.y * R.n <= (long)t_conv_sync.nwords &&
+                     !(raw_slabs_out && mode != MODE_FWD);
+  g.fold_out = nullptr; g.fold_addend = nullptr; g.fold_ctr = nullptr;
+  if (kfold) {
+    g.fold_out = out; g.fold_addend = addend; g.fold_ctr = t_conv_sync.ctr;
+    switches().stat_folds.fetch_add(1, std::memory_order_relaxed);
+  }
+  g.gn_part = nullptr;
+  if (mode == MODE_FWD && stats_part && stats_nrec && lat && d.N == 1 && (!split || kfold) && d.K >= 64 && d.K % 64 == 0 && dyb_is_pow2(d.K) &&
+      !A2 && (int)(grid.x * grid.y) <= (g.Ho * g.Wo < 256 ? g.Ho * g.Wo : 256)) {
+    g.gn_part = stats_part;
+    *stats_nrec = (int)(grid.x * grid.y);
+  }
   GnBwdFuse f{};
   GnFwdFuse nf{};
   if (fuse) f = *fuse;
@@ -1654,6 +1844,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
 #undef DYB_IGEMM_LAUNCH
 #undef DYB_IGEMM_LAUNCH1
   DYB_CHECK_LAUNCH();
+  if (kfold) return DYB_OK;                      // folded by the last workgroup of every tile
   if (split) {
     if (raw_slabs_out) { *raw_slabs_out = g.nsplit; return DYB_OK; }
     size_t n4 = (size_t)g.M * g.Ncols / 4;

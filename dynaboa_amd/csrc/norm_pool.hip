@@ -632,6 +632,10 @@ int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, con
 // Deterministic (fixed summation orders); agrees with the two-launch form to fp32 rounding (different orders).
 #define OP_IT 8
 #define OP_KMAX 32
+// Process-wide count of hand-offs that TIMED OUT (a poll that lasted longer than ~0.2 s goes on with incomplete sums: the results of
+// that launch are wrong).  The launch's own error word is lost with the next zero fill of the counters; this one stays, and the host
+// reads it wherever it synchronises anyway (dyb_sync_error_count: the drivers' metric flush raises on a non-zero count).
+__device__ unsigned g_gn_sync_errors = 0u;
 // device-scope (write-through, cache-bypassing) accesses for the few words the workgroups of a slab exchange: global_store /
 // global_load ... sc1.  With them the hand-off needs NO cache-wide fence - a release fence at device scope writes back, an acquire
 // fence invalidates, the WHOLE L2 of the XCD, and ~900 workgroups doing both per launch made the first version of this kernel run
@@ -792,6 +796,7 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
         for (int i = 0; i < a.poll_sleep; ++i) __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 20000000LL) {            // 100 MHz: 0.2 s
           atomicAdd(a.ctr + G, 1u);
+          atomicAdd(&g_gn_sync_errors, 1u);
           break;
         }
       }
@@ -830,6 +835,20 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
     *reinterpret_cast<float4*>(a.dbeta + cc) = make_float4(uA[0], uA[1], uA[2], uA[3]);
     *reinterpret_cast<float4*>(a.dgamma + cc) = make_float4(uB[0], uB[1], uB[2], uB[3]);
   }
+}
+int dyb_hvp_sync_errors(unsigned* host_out, hipStream_t st);      // hvp_kernels.hip: the tangent kernels' own count
+// Timed-out in-kernel hand-offs since the library was loaded (one-pass GroupNorm backward, one-launch GroupNorm tangents): copies the
+// count to the host and WAITS for `stream` - call it where the host synchronises anyway.  Non-zero: some launch went on with
+// incomplete sums (co-residency of a slab's workgroups not met within 0.2 s) and results since the last check are not to be trusted.
+extern "C" int dyb_sync_error_count(unsigned* count_host, hipStream_t st) {
+  DYB_REQUIRE(count_host, DYB_ERR_ARG);
+  unsigned a = 0u, b = 0u;
+  if (hipMemcpyFromSymbolAsync(&a, HIP_SYMBOL(g_gn_sync_errors), sizeof(unsigned), 0, hipMemcpyDeviceToHost, st) != hipSuccess) return DYB_ERR_LAUNCH;
+  int rc = dyb_hvp_sync_errors(&b, st);
+  if (rc != DYB_OK) return rc;
+  if (hipStreamSynchronize(st) != hipSuccess) return DYB_ERR_LAUNCH;
+  *count_host = a + b;
+  return DYB_OK;
 }
 // zero fill of a small per-replica region (the arrival counters): replica-aware, unlike a memset node
 __global__ void zero_words_kernel(unsigned* p, int n, DybRep R) {

@@ -338,6 +338,14 @@ int dyb_debug_gn_onepass_replicas(float* blob, size_t blob_floats, int nrep, con
 int dyb_debug_conv_pair(int mode, const float* a1, const float* b1, const float* a2, const float* b2, float* out, const float* addend,
                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
                         dyb_stream_t stream);
+/* In-kernel hand-offs (one-pass GroupNorm backward: the workgroups of a slab meet on a counter) give up after ~0.2 s and go on with
+ * incomplete sums rather than block the queue.  This returns how many did since the library was loaded; it waits for `stream`.
+ * The reference has no counterpart (PyTorch kernels do not rendezvous); the drivers check it at their metric flush and raise. */
+int dyb_sync_error_count(unsigned* count_host, dyb_stream_t stream);
+/* tests / lab: counter region (nwords zeroed 32-bit words, device memory) for the in-kernel split-K fold of the calling thread's plain
+ * conv calls, until reset with (NULL, 0).  With a region in scope a split launch's last-arriving workgroup per tile adds the slabs
+ * itself (csrc/igemm_tp.inc); the engine passes its own regions per pass.  Option "stat_folds" counts such launches. */
+int dyb_debug_set_conv_sync(unsigned* ctr, int nwords);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 

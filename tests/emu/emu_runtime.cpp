@@ -459,6 +459,20 @@ void stream_wait(void* stream, Event* e) {
 }
 }  // namespace emu
 
+// hipStreamSynchronize: in immediate mode everything has run; in lazy mode the stream's queue is drained (waits pull in what they need)
+void emu_stream_synchronize(void* st) {
+  emu::Queue* q = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(emu::q_mu);
+    if (!emu::g_lazy) return;
+    q = &emu::queue_of(st);
+  }
+  const bool was = emu::g_lazy;
+  emu::g_lazy = false;
+  emu::drain(*q, nullptr, 0);
+  emu::g_lazy = was;
+}
+
 // test hooks (exported next to the product's C ABI in libdynaboa_emu.so)
 extern "C" void emu_lazy(int on) {
   std::lock_guard<std::mutex> lk(emu::q_mu);

@@ -132,6 +132,14 @@ static inline float __uint_as_float(unsigned u) {
   return f;
 }
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+// device globals are plain globals here; the copy runs in stream order like every other operation
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyFromSymbolAsync(void* d, const void* sym, size_t n, size_t off, hipMemcpyKind, hipStream_t st) {
+  emu::submit(st, [=]() { memcpy(d, (const char*)sym + off, n); });
+  return hipSuccess;
+}
+void emu_stream_synchronize(void* st);
+static inline hipError_t hipStreamSynchronize(hipStream_t st) { emu_stream_synchronize(st); return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }

@@ -73,6 +73,26 @@ def _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, xr, wr, dyr):
     return e
 
 
+def case_conv_inkernel_fold(be, N, H, W, C, K, R, stride, pad, seed=0):
+    """The same three checks with a counter region in scope: a launch that splits K lets the workgroup that arrives last on a tile add
+    the tile's slabs itself (igemm_tp.inc / igemm_conv.hip epilogues) instead of leaving them to a fold launch.  The counters must be
+    back at zero afterwards; returns how many launches folded in-kernel."""
+    import ctypes
+    ctr = be.zeros((1024,), dtype=np.uint32)
+    before = ctypes.c_int(0)
+    be.lib.dyb_get_option(b"stat_folds", ctypes.byref(before))
+    check(be.lib.dyb_debug_set_conv_sync(be.ptr(ctr), 1024), "set_conv_sync")
+    try:
+        case_conv(be, N, H, W, C, K, R, stride, pad, seed=seed, c_real=3 if C == 4 else None)
+        be.sync()
+    finally:
+        be.lib.dyb_debug_set_conv_sync(None, 0)
+    after = ctypes.c_int(0)
+    be.lib.dyb_get_option(b"stat_folds", ctypes.byref(after))
+    assert not np.asarray(be.host(ctr)).any(), "arrival counters not back at zero"
+    return after.value - before.value
+
+
 def case_conv_pair(be, N, H, W, C, K, R, stride, pad, seed=0):
     """dyb_debug_conv_pair (the tangent passes' operand pairs: one launch, one K loop over both pairs) against torch:
     forward conv(x1, w1) + conv(x2, w2); data gradient dgrad(dy1, w1) + dgrad(dy2, w2) + addend; weight gradient wgrad(x1, dy1) +

@@ -113,6 +113,33 @@ def test_conv_throughput_data_gradient_by_phase_class(be, throughput_mode, cfg, 
         be.lib.dyb_set_option(b"tp_grid", 512)
 
 
+@pytest.mark.parametrize("tp_grid", [512, 64])
+@pytest.mark.parametrize("cfg", [
+    (1, 12, 12, 128, 128, 3, 1, 1),    # 128x128 tiles, ragged M, K loop of 72 steps split deep
+    (1, 7, 7, 128, 256, 3, 1, 1),      # 64x256 form
+    (2, 10, 10, 64, 64, 3, 2, 1),      # 256x64 forms, stride-2 data gradient by phase class
+    (1, 14, 14, 64, 128, 3, 2, 1),     # stride 2, classes with 4 / 2 / 2 / 1 taps (some splits of a class are empty)
+    (1, 14, 14, 64, 128, 1, 2, 0),     # 1x1 stride 2: the compact form keeps its scatter fold
+])
+def test_conv_throughput_kernel_inkernel_fold(be, throughput_mode, cfg, tp_grid):
+    """Split-K launches of igemm_tp_kernel with a counter region in scope: the last workgroup to arrive on a tile folds the tile's
+    slabs in split order, adds the addend and writes the result (pipelined loop forms; the phased loop keeps the fold launch)."""
+    be.lib.dyb_set_option(b"tp_grid", tp_grid)
+    be.lib.dyb_set_option(b"tp_fold", 1)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
+    try:
+        folds = K.case_conv_inkernel_fold(be, *cfg, seed=sum(cfg))
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+        be.lib.dyb_set_option(b"tp_fold", 0)
+    import ctypes
+    v = ctypes.c_int(0)
+    be.lib.dyb_get_option(b"tp_kernel", ctypes.byref(v))
+    if v.value >= 2 and tp_grid == 512 and cfg[5] == 3:
+        assert folds >= 1, "no launch took the in-kernel fold"
+    if v.value < 2:
+        assert folds == 0
+
+
 @pytest.mark.parametrize("cfg", [(1, 12, 12, 128, 128, 1, 1, 0), (1, 7, 7, 128, 256, 3, 1, 1), (2, 10, 10, 64, 64, 3, 2, 1)])
 def test_conv_throughput_kernel_bf16(be, throughput_mode, cfg):
     """bf16 form of the pipelined throughput kernel (operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16, fp32
@@ -231,6 +258,49 @@ def test_layer_gnstats_from_the_throughput_kernels_epilogue(be, cfg):
         be.lib.dyb_set_option(b"tp_min", 8)
         be.lib.dyb_set_option(b"tp_grid", 512)
         be.lib.dyb_set_option(b"tp_gn_fuse_stats", 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, K, R, stride, pad     latency form (64x64 tiles): the epilogue goes through LDS; deep split-K at these sizes
+    (1, 14, 14, 64, 64, 3, 1, 1),      # 196 rows: ragged last tile
+    (2, 7, 7, 128, 64, 3, 1, 1),       # batch 2 (rows span images)
+    (1, 12, 12, 128, 256, 1, 1, 0),    # 1x1, four column tiles
+    (1, 10, 10, 64, 128, 3, 2, 1),     # stride 2
+    (1, 20, 20, 4, 64, 7, 2, 3),       # stem shape (Cin padded to 4)
+])
+def test_conv_inkernel_fold_latency_form(be, cfg):
+    """igemm_mfma_kernel with a counter region in scope: split launches fold in-kernel (the last workgroup to arrive on a tile adds
+    the slabs in split order), the unsplit ones store their tile through the same LDS-transposed epilogue."""
+    folds = K.case_conv_inkernel_fold(be, *cfg, seed=sum(cfg))
+    assert folds >= 1, "no launch of this case split its K loop"
+    be.lib.dyb_set_option(b"lat_fold", 0)
+    try:
+        assert K.case_conv_inkernel_fold(be, *cfg, seed=sum(cfg)) == 0
+    finally:
+        be.lib.dyb_set_option(b"lat_fold", 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, C, Ka, Ra, sa, Kb, Rb, sb       (one image, tiled path for both layers)
+    (1, 12, 12, 64, 64, 3, 1, 128, 3, 1),      # groups of 16 columns (four per tile), then 32 (two per tile); 144 rows: ragged
+    (1, 9, 9, 64, 256, 3, 1, 512, 3, 1),       # groups of 64 (one per tile) and 128 columns (two tiles per group)
+    (1, 16, 16, 128, 128, 3, 2, 64, 3, 1),     # stride 2
+])
+def test_layer_gnstats_from_the_latency_kernels_epilogue(be, cfg):
+    """One image on the latency schedule with a counter region in scope: the conv launch - split or not - leaves one statistics record
+    per workgroup tile (from the folded tile where K was split) and no statistics launch follows."""
+    ctr = be.zeros((1024,), dtype=np.uint32)
+    N, H, W, C, Ka, Ra, sa, Kb, Rb, sb = cfg
+    Ha = (H + 2 * (Ra // 2) - Ra) // sa + 1
+    assert be.lib.dyb_debug_set_conv_sync(be.ptr(ctr), 1024) == 0
+    try:
+        r = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+    finally:
+        be.lib.dyb_debug_set_conv_sync(None, 0)
+    assert r["nA"] == -(-Ha * Ha // 64) * (Ka // 64), r
+    assert not np.asarray(be.host(ctr)).any()
+    r0 = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))          # no region: unsplit launches still carry their statistics
+    assert r0["nA"] > 0
 
 
 def _random_conv_cfgs(n, seed):

@@ -93,6 +93,88 @@ def test_conv_throughput_kernel_split_policies(be, throughput_mode, shape, tp_gr
         be.lib.dyb_set_option(b"tp_grid", 512)
 
 
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_inkernel_fold_latency_form_all_resnet_shapes(be, shape):
+    """Latency form (64x64 tiles) with a counter region in scope on every ResNet-50 conv shape at one image: split launches fold
+    in-kernel - last workgroup to arrive on a tile, slabs added in split order - instead of leaving slabs to a fold launch."""
+    H, W, C, Kc, R, st, pad = shape
+    folds = K.case_conv_inkernel_fold(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc)
+    assert folds >= 1, shape                         # every shape splits at least one of its three modes at one image
+
+
+@pytest.mark.parametrize("tp_grid", [512, 4096])
+@pytest.mark.parametrize("shape", RESNET_SHAPES)
+def test_conv_inkernel_fold_throughput_kernel_all_resnet_shapes(be, throughput_mode, shape, tp_grid):
+    """Throughput kernel with a counter region in scope (pipelined forms fold in-kernel; the phased loop and the compact stride-2
+    data gradient keep their fold launches) at the policy's split depth and at the deepest one."""
+    H, W, C, Kc, R, st, pad = shape
+    be.lib.dyb_set_option(b"tp_grid", tp_grid)
+    be.lib.dyb_set_option(b"tp_fold", 1)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
+    try:
+        K.case_conv_inkernel_fold(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc + tp_grid)
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+        be.lib.dyb_set_option(b"tp_fold", 0)
+
+
+def test_conv_inkernel_fold_replicas_bit_identical_to_one_sequence(be):
+    """Eight replicas in one launch, in-kernel fold on each replica's own counters (region inside the replica arena is not needed for
+    plain pointers: the debug entry registers the workspace slices): every replica equals the same convolution run alone, bit for bit,
+    whatever the arrival order was (three repetitions)."""
+    import ctypes
+    import torch
+    S, H, C, Kc, R = 8, 14, 256, 256, 3
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(S, 1, H, H, C, generator=g).to(dev)
+    w = (torch.randn(S, R, R, C, Kc, generator=g) * 0.05).to(dev)
+    dy = torch.randn(S, 1, H, H, Kc, generator=g).to(dev)
+    wsb = 64 << 20
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    L = be.lib
+    L.dyb_set_option(b"rep_split", 1)
+    L.dyb_set_option(b"tp_fold", 1)
+    try:
+        ctr = torch.zeros(1024, dtype=torch.int32, device=dev)
+        for mode, ref_shape in ((0, dy), (1, x), (2, w)):
+            outs = []
+            for rep in range(3):
+                out = torch.empty_like(ref_shape)
+                assert L.dyb_debug_set_conv_sync(ctr.data_ptr(), 1024) == 0
+                try:
+                    assert L.dyb_debug_conv_replicas(mode, x.data_ptr(), w.data_ptr(), dy.data_ptr(), out.data_ptr(), S, 1, H, H, C, Kc, R, R, 1, 1,
+                                                     ws.data_ptr(), wsb, None) == 0
+                finally:
+                    L.dyb_debug_set_conv_sync(None, 0)
+                torch.cuda.synchronize()
+                outs.append(out.clone())
+            assert not bool(ctr.any())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), mode
+            # against the fold launch (tree order differs: rounding only)
+            ref = torch.empty_like(ref_shape)
+            assert L.dyb_debug_conv_replicas(mode, x.data_ptr(), w.data_ptr(), dy.data_ptr(), ref.data_ptr(), S, 1, H, H, C, Kc, R, R, 1, 1,
+                                             ws.data_ptr(), wsb, None) == 0
+            torch.cuda.synchronize()
+            assert float((outs[0] - ref).abs().max() / ref.abs().max()) < 1e-5, mode
+    finally:
+        L.dyb_set_option(b"rep_split", 0)
+        L.dyb_set_option(b"tp_fold", 0)
+
+
+@pytest.mark.parametrize("cfg", [(1, 14, 14, 256, 256, 3, 1, 512, 3, 1), (1, 56, 56, 64, 64, 3, 1, 256, 3, 1), (1, 28, 28, 128, 128, 3, 2, 512, 3, 1)])
+def test_layer_gnstats_from_the_latency_kernels_epilogue(be, cfg):
+    ctr = be.zeros((1024,), dtype=np.uint32)
+    N, H, W, C, Ka, Ra, sa, Kb, Rb, sb = cfg
+    Ha = (H + 2 * (Ra // 2) - Ra) // sa + 1
+    assert be.lib.dyb_debug_set_conv_sync(be.ptr(ctr), 1024) == 0
+    try:
+        r = K.case_layer_gnstats(be, *cfg, seed=sum(cfg))
+    finally:
+        be.lib.dyb_debug_set_conv_sync(None, 0)
+    assert r["nA"] == -(-Ha * Ha // 64) * (Ka // 64), r
+    assert not np.asarray(be.host(ctr)).any()
+
+
 @pytest.mark.parametrize("cfg", [(1, 12544, 64, 1, False, 1), (1, 3136, 256, 1, True, 1), (1, 784, 512, 1, True, 2),
                                  (1, 196, 1024, 0, False, 5), (1, 49, 2048, 1, True, 16), (8, 196, 256, 1, False, 1),
                                  (2, 49, 512, 1, False, 9)])
