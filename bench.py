@@ -502,6 +502,8 @@ def main():
     ap.add_argument("--probe_out", type=str, default="")
     ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")
     ap.add_argument("--cpu_baseline_only", action="store_true")
+    ap.add_argument("--seqs_full", type=int, default=0, help="1: --seqs also applies to --full_losses 1 (lab runs / traces of the replica-batched default term set)")
+    ap.add_argument("--cos_sim_threshold", type=float, default=None, help="--full_losses 1: the dynamic-BOA gate's threshold (default: the reference's 3.1e-4)")
     ap.add_argument("--all_sub_records", action="store_true",
                     help="also the side runs whose kernels have not changed since round 3 (finite-difference HVP, batch 16 on the latency "
                          "schedule, the 32-sequence bf16 arm)")
@@ -534,7 +536,8 @@ def main():
     torch.cuda.set_device(device)
 
     simple = not (args.second_order or args.full_losses)
-    seqs = args.seqs if simple else 1           # replica groups cover the first-order frame-loss configurations
+    # replica groups cover the first-order configurations: frame losses (the headline) and, given explicitly, the default term set
+    seqs = args.seqs if (simple or (args.full_losses and not args.second_order and args.seqs_full)) else 1
     total = args.warmup + args.steps
     n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
@@ -542,7 +545,7 @@ def main():
     nfr = total + n_roof + n_pct + n_h2d
     rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, groups=args.groups, full_losses=args.full_losses,
                 second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule,
-                hvp=args.hvp)
+                hvp=args.hvp, **({} if args.cos_sim_threshold is None else dict(cos_sim_threshold=args.cos_sim_threshold)))
 
     # the adaptation chain runs on a non-default stream: the engine's whole-call hipGraph cache cannot
     # capture on the legacy null stream

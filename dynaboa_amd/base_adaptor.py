@@ -43,7 +43,8 @@ def synthetic_bundle(seed: int = 22, identity_pose: bool = True, randomize_norm:
         checkpoint=A.make_synthetic_checkpoint(seed, mp, randomize_norm=randomize_norm),
         smpl_neutral=A.make_synthetic_smpl(smpl_seed), smpl_male=A.make_synthetic_smpl(smpl_seed + 1),
         smpl_female=A.make_synthetic_smpl(smpl_seed + 2),
-        exemplars=lambda step, n: A.make_exemplars(step, n), dataloader=None, gmm_folder=None)
+        exemplars=lambda step, n: A.make_exemplars(step, n),
+        exemplars_device=lambda step, n, device: A.make_exemplars_device(step, n, device), dataloader=None, gmm_folder=None)
 
 
 class BaseAdaptor:
@@ -175,6 +176,9 @@ class BaseAdaptor:
         the centres, `sample_num` members drawn with the seeded `random` module, their items concatenated along dim 0.
         The cluster index is the one host synchronisation of the level (the reference's `.item()`)."""
         if self.bundle is not None:
+            dev_fn = getattr(self.bundle, "exemplars_device", None)
+            if dev_fn is not None:            # synthetic exemplars: resident on the device, one generation per step for all sequences
+                return dev_fn(self.global_step, self.options.sample_num, self.device)
             batch = self.bundle.exemplars(self.global_step, self.options.sample_num)
         else:
             dists = 1 - F.cosine_similarity(feature, self.centers)

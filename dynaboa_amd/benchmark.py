@@ -300,12 +300,18 @@ class Adaptor(BaseAdaptor):
         o, ns, rr = self.options, self._native, getattr(self, "_native_replica", 0)
         K = o.inner_step
         log = self.fit_losses
+        cut = {}                                                 # one slice + one unbind per log row (16 views), not one index op per value
+
+        def lrow(row):
+            if row not in cut:
+                cut[row] = ns.level_row(f, row, rr).unbind(0)
+            return cut[row]
         for i in range(K):
-            self.kp2dlosses_lower.append(ns.level_row(f, i, rr)[0])
+            self.kp2dlosses_lower.append(lrow(i)[0])
         rows = ((("ll", K - 1, bool(o.use_temporal_losses_lower), bool(o.lower_level_mixtrain)),) if K > 0 else ()) + \
                (("ul", K + min(extra, o.optim_steps if o.dynamic_boa else 0), bool(o.use_temporal_losses_upper), bool(o.upper_level_mixtrain)),)
         for tag, row, temporal, mix in rows:
-            r = ns.level_row(f, row, rr)
+            r = lrow(row)
             log[f"{tag}/s2dloss"], log[f"{tag}/shape_prior"], log[f"{tag}/pose_prior"], log[f"{tag}/unlabelloss"] = r[0], r[1], r[2], r[3]
             if temporal and o.use_meanteacher:
                 for j, k in enumerate(("s2dloss", "s3dloss", "shape_loss", "pose_loss", "loss")):
@@ -316,7 +322,7 @@ class Adaptor(BaseAdaptor):
                 for j, k in enumerate(("labled_s2dloss", "labled_s3dloss", "labled_shape_loss", "labled_pose_loss", "labled_loss")):
                     log[f"{tag}/{k}"] = r[10 + j]
             log[f"{tag}/total"] = r[15]
-        self.kp2dlosses_upper[self.global_step] = ns.level_row(f, K, rr)[0]
+        self.kp2dlosses_upper[self.global_step] = lrow(K)[0]
         out = (None, None, None)
         nfinal = 1 + (min(extra, o.optim_steps) if o.dynamic_boa else 0)
         tags = ([('lower', i) for i in range(K)] if getattr(o, "eval_lower", 1) else []) + [('final', k) for k in range(nfinal)]
@@ -338,9 +344,9 @@ class Adaptor(BaseAdaptor):
         if self.global_step < len(self.mpjpe_statistics):
             self.mpjpe_statistics[self.global_step], self.pampjpe_statistics[self.global_step] = stats_m, stats_p
         if o.dynamic_boa:
-            gl = ns.gate_log[rr, f]
-            self.feat_sims[self.global_step] = [{i: {"cos": gl[k, i]} for i in range(15)} for k in range(nfinal)]
-            log["feat_sim/cos_sim"] = gl[nfinal - 1, :15].sum() / 14          # the reference divides by the last index (base_adaptor.py:218)
+            cos, means = ns.gate_views(f, rr)                                 # views cut once per frame for all sequences (native_step.py)
+            self.feat_sims[self.global_step] = [{i: {"cos": c} for i, c in enumerate(cos[k])} for k in range(nfinal)]
+            log["feat_sim/cos_sim"] = means[nfinal - 1]                         # the reference divides by the last index (base_adaptor.py:218)
             self.optimized_step = extra
             self.optim_step_record.append(extra)
         return out

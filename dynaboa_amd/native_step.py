@@ -309,8 +309,12 @@ class NativeStepper:
         return f, slot0, int(extra.value)
 
     def _sync_adam_steps(self):
-        for r, st in enumerate(self._adam):
-            st["step"] = int(self.lib.dyb_stepper_get_i(self.h, f"adam_step_{r}".encode()))
+        keys = getattr(self, "_adam_keys", None)
+        if keys is None:
+            keys = self._adam_keys = [f"adam_step_{r}".encode() for r in range(len(self._adam))]
+        get = self.lib.dyb_stepper_get_i
+        for st, k in zip(self._adam, keys):
+            st["step"] = int(get(self.h, k))
 
     def set_active(self, idx=None):
         """The replicas the following frame steps cover (ascending indices; None = all): a sequence whose stream has ended leaves
@@ -356,6 +360,18 @@ class NativeStepper:
         """16-float log row `row` of `frame` (full mode): frame {s2d, shape, pose, total} | teacher {s2d, s3d, shape, pose, loss} |
         motion | labelled {s2d, s3d, shape, pose, loss} | level total."""
         return self.loss_log[r, frame, 16 * row:16 * row + 16]
+
+    def gate_views(self, frame: int, r: int = 0):
+        """(cos, means) of the dynamic-BOA gate's checks of `frame` for replica r: cos[k] = the 15 feature cosines of check k (views),
+        means[k] = their sum / 14 (base_adaptor.py:218).  Cut / computed ONCE per frame for all replicas: per sequence this was 15 index
+        operations and two tiny launches (a sum and a division) per check - at 32 sequences milliseconds of host time per step."""
+        c = getattr(self, "_gate_cache", None)
+        if c is None or c[0] != frame:
+            g = self.gate_log[:, frame, :, :15]                                   # [S][checks][15]
+            means = (g.sum(-1) / 14).unbind(0)                                    # S x [checks]
+            cos = [[row.unbind(0) for row in rep.unbind(0)] for rep in g.unbind(0)]
+            c = self._gate_cache = (frame, cos, [m.unbind(0) for m in means])
+        return c[1][r], c[2][r]
 
     def join(self):
         check(self.lib.dyb_stepper_join(self.h, stream_of(self.theta)), "dyb_stepper_join")
