@@ -280,6 +280,7 @@ struct Stepper {
   // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
   // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
   int upd_overlap = 1;
+  int share_dyn_fwd = 1;           // dynamic loop: an extra step's upper level reuses the previous step's final inference as its forward
   int upd_blocks = 0;              // > 0: workgroup cap (all replicas together) of the ranged passes on the auxiliary stream (measured: no effect, 512 .. uncapped)
   hipEvent_t e_upd = nullptr;
   DybFwdGates gates{};
@@ -428,6 +429,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   dyb_hmr_param_groups(plan, S->grp_bounds);
   if (const char* e = getenv("DYB_UPD_OVERLAP")) S->upd_overlap = atoi(e);       // (A/B runs; set_i "upd_overlap" afterwards wins)
   if (const char* e = getenv("DYB_UPD_BLOCKS")) S->upd_blocks = atoi(e);
+  if (const char* e = getenv("DYB_SHARE_DYN_FWD")) S->share_dyn_fwd = atoi(e);
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
@@ -469,6 +471,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "upd_overlap") S->upd_overlap = (int)v;
   else if (k == "side_thread") S->side_thread = (int)v;
   else if (k == "upd_blocks") S->upd_blocks = (int)v;
+  else if (k == "share_dyn_fwd") S->share_dyn_fwd = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
@@ -651,14 +654,24 @@ static int check_ready(const Stepper& S) {
   return DYB_OK;
 }
 
+static int settle_update(Stepper& S, hipStream_t st);
 // HMR forward at `theta` -> rotmat / shape / cam in the pass's arena -> SMPL (neutral) vertices + 49 joints
 static int pass_forward(Stepper& S, Pass& P, const float* theta, const float* image, hipStream_t st, bool chain = true) {
   // (a ranged weight update may still be running on the auxiliary stream: this forward - the first reader of the new weights -
   // waits for each range where it first reads it).  chain = false: the side stream's forward (possibly issued by the helper thread)
   // - never a consumer of a ranged update (replica groups have no side stream) and it leaves the chain's gate state alone
   const DybFwdGates* gates = (chain && S.gates_pending) ? &S.gates : nullptr;
-  if (chain) S.gates_pending = false;
-  RUN(dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st, gates));
+  {
+    const int rc = dyb_hmr_forward_plain(S.plan, theta, image, S.init_state, S.n_iter, P.acts, P.ws, S.ws_bytes, st, gates);
+    if (rc != DYB_OK) {
+      // the forward may have stopped before it waited for / issued the later ranges: make the stream wait for the whole update so
+      // that nothing stale is read by whatever the caller does next, then report the failure
+      if (gates) (void)settle_update(S, st);
+      return rc;
+    }
+    // consumed: every range's gate was waited for inside the forward (the deferred one issued there)
+    if (gates) { DYB_REQUIRE(!S.gates.late, DYB_ERR_LAUNCH); S.gates_pending = false; }
+  }
   const float* rot = P.acts + S.off_rot;
   const float* state = P.acts + S.off_state;
   return dyb_lbs_fwd(S.smpl_f[0], S.smpl_i[0], state + 144, STATE_LD, rot, P.verts, P.joints, P.saved, S.B, st);
@@ -813,6 +826,10 @@ static int late_update(void* user) {
 // layer4) and [layer4, end) on `aux` behind everything `st` has issued, each followed by its gate event; the next pass_forward waits
 // for them where it first reads those weights.
 static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipStream_t st, hipStream_t aux, bool ema = false) {
+  // a ranged update nobody consumed (no chain forward followed it) must not be overtaken: its tail range would stay un-issued and
+  // its events would satisfy later waits with stale weights - settle it first
+  if (S.gates_pending) RUN(settle_update(S, st));
+  DYB_REQUIRE(!S.gates.late, DYB_ERR_LAUNCH);
   const DybRep& R = dyb_rep_current();
   const float *g2 = S.lvl_g2, *g3 = S.lvl_g3;        // further gradient arenas of the level just differentiated (full term set), consumed here
   S.lvl_g2 = S.lvl_g3 = nullptr;
@@ -988,11 +1005,13 @@ struct FullCtx {
 };
 // one level (reference base_adaptor.py:222-317 lower / upper_level_adaptation) at weights `cur` through pass P: loss terms,
 // log row, and the gradient of the level total w.r.t. `cur` in S.grads
-static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool upper, int level_index, hipStream_t st, hipStream_t aux) {
+// have_fwd: P already holds the forward of (cur, this frame's image) - the dynamic loop hands the previous step's final inference on
+static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool upper, int level_index, hipStream_t st, hipStream_t aux,
+                      bool have_fwd = false) {
   const int B = S.B;
   const float* image = (const float*)C.in[IN_IMAGE];
   const float* kp = (const float*)C.in[IN_KP];
-  RUN(pass_forward(S, P, cur, image, st));
+  if (!have_fwd) RUN(pass_forward(S, P, cur, image, st));
   RUN(pass_frame_head(S, P, kp, st));
   const float* rot = P.acts + S.off_rot;
   const float* state = P.acts + S.off_state;
@@ -1221,6 +1240,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
     for (int i = 0; i < outer.n; ++i)
       if (1.f - cos12[dyb_rep_phys(outer, i)] > (float)S.cos_thr) cont[ncont++] = dyb_rep_phys(outer, i);
     int step = 0;
+    Pass* post = &S.fin;                                   // where the latest final inference lives
     while (ncont > 0) {
       ++step;
       if (step > S.optim_steps) {
@@ -1233,11 +1253,27 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
         dyb_rep_set_map(sub, cont, ncont);
         DybRepScope scope(sub);
         C.level_row = K + step;
-        RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
-        RUN(adam_and_teacher(S, st, aux));
-        RUN(pass_forward(S, S.fin, S.theta, image, st));
-        RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, cos12, st));
-        if (metrics) RUN(record_metrics(S, S.fin, gender, slot, st));
+        // The upper level of this step starts with a forward at (theta, this image) - exactly the final inference the previous step
+        // ended with (same weights, same image, deterministic kernels): it is not repeated.  `up` = that forward's products with the
+        // chain's gradient buffers; the new final inference goes to the other activation arena (the gate compares the two), and the
+        // two arenas swap roles every step ("share_dyn_fwd"; 0: the literal two forwards per step).
+        if (S.share_dyn_fwd) {
+          Pass up = S.main;
+          up.acts = post->acts; up.verts = post->verts; up.joints = post->joints; up.saved = post->saved; up.pred17 = post->pred17;
+          Pass* nxt = (post == &S.fin) ? &S.main : &S.fin;
+          RUN(full_level(S, C, up, S.theta, true, K + step, st, aux, true));
+          RUN(adam_and_teacher(S, st, aux));
+          RUN(pass_forward(S, *nxt, S.theta, image, st));
+          RUN(gate_cosine(S, up.acts, nxt->acts, glog + 16 * step, cos12, st));
+          if (metrics) RUN(record_metrics(S, *nxt, gender, slot, st));
+          post = nxt;
+        } else {
+          RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
+          RUN(adam_and_teacher(S, st, aux));
+          RUN(pass_forward(S, S.fin, S.theta, image, st));
+          RUN(gate_cosine(S, S.main.acts, S.fin.acts, glog + 16 * step, cos12, st));
+          if (metrics) RUN(record_metrics(S, S.fin, gender, slot, st));
+        }
       }
       ++slot;
       int m = 0;

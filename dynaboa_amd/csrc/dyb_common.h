@@ -1,6 +1,12 @@
 // Shared internals of libdynaboa_hip.so (gfx950 / CDNA4 only).
 // Public C ABI lives in include/dynaboa_hip.h; this header is private to csrc/.
 #pragma once
+// gfx950 only.  The in-kernel hand-offs (one-pass GroupNorm backward, GroupNorm tangents, the convolutions' split-K fold) order their
+// device-scope write-through stores with a gfx9-encoded s_waitcnt vmcnt(0) and rely on sc1 cache policies: on a target where stores are
+// counted separately (vscnt) or the encodings differ they would silently hand over incomplete data - refuse to build for one.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdynaboa_hip is written for gfx950 (MI355X) only"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1678,7 +1678,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   const int pipe = (tpk >= 2 && !g.probe && !(mode == MODE_WGRAD && TPK / g.Wo >= g.Ho)) ? (tpk >= 3 ? 2 : 1) : 0;
   // in-kernel fold ("tp_fold"): a counter region in scope, the pipelined kernel, plain slabs (not the compact stride-2 form)
   const bool fold = split && !g.compact && pipe != 0 && t_conv_sync.ctr && (long)grid.x * grid.y * R.n <= (long)t_conv_sync.nwords &&
-                    !(raw_slabs_out && mode != MODE_FWD) && switches().tp_fold.load(std::memory_order_relaxed);
+                    !(raw_slabs_out && mode != MODE_FWD) && ((switches().tp_fold.load(std::memory_order_relaxed) >> mode) & 1);   // bit per mode
   g.fold_out = nullptr; g.fold_addend = nullptr; g.fold_ctr = nullptr;
   if (fold) {
     g.fold_out = out; g.fold_addend = addend; g.fold_ctr = t_conv_sync.ctr;

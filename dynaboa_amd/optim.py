@@ -69,7 +69,10 @@ class Adam:
                 # with a stale H v: say so loudly (use dynaboa_amd.optim.materialize_grad(p) before editing gradients, or
                 # MAML(defer_accumulate=False))
                 seen = getattr(p, "_so_grad_seen", None)
-                if seen is not None and seen != (id(p.grad), p.grad._version):
+                # (no hook record - .grad assigned by hand, a torch without post-accumulate hooks: fall back to the version counter,
+                # which is 0 for a gradient autograd has accumulated exactly once and nobody has touched since)
+                stale = (seen != (id(p.grad), p.grad._version)) if seen is not None else (p.grad._version != 0)
+                if stale:
                     import warnings
                     warnings.warn("second-order gradient: .grad was modified or replaced after backward() while its last accumulation "
                                   "(v - lr * H v) was still deferred to Adam.step", RuntimeWarning, stacklevel=2)

@@ -125,7 +125,7 @@ def test_conv_throughput_kernel_inkernel_fold(be, throughput_mode, cfg, tp_grid)
     """Split-K launches of igemm_tp_kernel with a counter region in scope: the last workgroup to arrive on a tile folds the tile's
     slabs in split order, adds the addend and writes the result (pipelined loop forms; the phased loop keeps the fold launch)."""
     be.lib.dyb_set_option(b"tp_grid", tp_grid)
-    be.lib.dyb_set_option(b"tp_fold", 1)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
+    be.lib.dyb_set_option(b"tp_fold", 7)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
     try:
         folds = K.case_conv_inkernel_fold(be, *cfg, seed=sum(cfg))
     finally:

@@ -109,7 +109,7 @@ def test_conv_inkernel_fold_throughput_kernel_all_resnet_shapes(be, throughput_m
     data gradient keep their fold launches) at the policy's split depth and at the deepest one."""
     H, W, C, Kc, R, st, pad = shape
     be.lib.dyb_set_option(b"tp_grid", tp_grid)
-    be.lib.dyb_set_option(b"tp_fold", 1)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
+    be.lib.dyb_set_option(b"tp_fold", 7)                 # (off by default: measured slower at 16 - 32 sequences, r05 s3)
     try:
         K.case_conv_inkernel_fold(be, 1, H, W, C, Kc, R, st, pad, seed=H + C + Kc + tp_grid)
     finally:
@@ -133,7 +133,7 @@ def test_conv_inkernel_fold_replicas_bit_identical_to_one_sequence(be):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     L = be.lib
     L.dyb_set_option(b"rep_split", 1)
-    L.dyb_set_option(b"tp_fold", 1)
+    L.dyb_set_option(b"tp_fold", 7)
     try:
         ctr = torch.zeros(1024, dtype=torch.int32, device=dev)
         for mode, ref_shape in ((0, dy), (1, x), (2, w)):
