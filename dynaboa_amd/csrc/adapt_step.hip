@@ -280,6 +280,7 @@ struct Stepper {
   // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
   // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
   int upd_overlap = 1;
+  bool out_in_main = false;        // where the latest final inference lives (dyb_stepper_output): fin, or main after an odd number of shared steps
   int share_dyn_fwd = 1;           // dynamic loop: an extra step's upper level reuses the previous step's final inference as its forward
   int upd_blocks = 0;              // > 0: workgroup cap (all replicas together) of the ranged passes on the auxiliary stream (measured: no effect, 512 .. uncapped)
   hipEvent_t e_upd = nullptr;
@@ -1241,6 +1242,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
       if (1.f - cos12[dyb_rep_phys(outer, i)] > (float)S.cos_thr) cont[ncont++] = dyb_rep_phys(outer, i);
     int step = 0;
     Pass* post = &S.fin;                                   // where the latest final inference lives
+    S.out_in_main = false;
     while (ncont > 0) {
       ++step;
       if (step > S.optim_steps) {
@@ -1267,6 +1269,7 @@ static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slo
           RUN(gate_cosine(S, up.acts, nxt->acts, glog + 16 * step, cos12, st));
           if (metrics) RUN(record_metrics(S, *nxt, gender, slot, st));
           post = nxt;
+          S.out_in_main = (post == &S.main);
         } else {
           RUN(full_level(S, C, S.main, S.theta, true, K + step, st, aux));
           RUN(adam_and_teacher(S, st, aux));
@@ -1411,11 +1414,14 @@ extern "C" int dyb_stepper_join(void* stepper, hipStream_t st) {
 extern "C" const float* dyb_stepper_output(const void* stepper, int which) {
   const Stepper* S = reinterpret_cast<const Stepper*>(stepper);
   if (!S || !S->bound) return nullptr;
+  // (the dynamic loop's steps alternate between the two activation arenas, "share_dyn_fwd": the last launch's final inference - for a
+  // replica that left the loop a step earlier than the last one, read its prediction from the records)
+  const Pass& F = (S->out_in_main ? S->main : S->fin);
   switch (which) {
-    case 0: return S->fin.acts + S->off_rot;
-    case 1: return S->fin.acts + S->off_state;
-    case 2: return S->fin.verts;
-    case 3: return S->fin.joints;
+    case 0: return F.acts + S->off_rot;
+    case 1: return F.acts + S->off_state;
+    case 2: return F.verts;
+    case 3: return F.joints;
     default: return nullptr;
   }
 }

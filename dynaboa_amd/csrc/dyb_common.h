@@ -117,6 +117,32 @@ __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
       return reinterpret_cast<T*>(const_cast<char*>(c) + (unsigned long long)rep * R.stride[a]);
   return p;
 }
+// buffer resource over [p, p + bytes) (raw, stride 0; gfx9 data-format word) and a 16-byte load through it
+#define TP_OOB 0x80000000u
+typedef unsigned tp_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tp_rsrc(const float* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
+__device__ __forceinline__ float4 tp_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;      // (bit_cast straight from a vector element reads element 0 on host clang)
+  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
+}
+// 16-byte store through a buffer resource with cache policy AUX (0 plain, 16 = sc1: write-through at device scope, 2 = nt, 17 = sc0 sc1);
+// a per-lane offset >= num_records (TP_OOB) is dropped by the hardware
+template <int AUX>
+__device__ __forceinline__ void tp_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  tp_u4 x;
+  x.x = __builtin_bit_cast(unsigned, v.x); x.y = __builtin_bit_cast(unsigned, v.y);
+  x.z = __builtin_bit_cast(unsigned, v.z); x.w = __builtin_bit_cast(unsigned, v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)voff, 0, AUX);
+}
+// the same load past the vector L1 (sc1): data another workgroup of this launch stored write-through
+__device__ __forceinline__ float4 tp_buf_load4_dev(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16);
+  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;
+  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
+}
 // replica index (dyb_lrep: within the launch; dyb_rep: physical, what arenas and per-replica argument tables are indexed with)
 // and the kernel's own z coordinates; then DYB_RB(ptr)... for every pointer the kernel dereferences
 #define DYB_REP_PROLOGUE(R)                                   \
@@ -214,6 +240,7 @@ int dyb_tp_gn_onepass();
 int dyb_tp_gn_cap();
 int dyb_tp_gn_threads();
 int dyb_tp_gn_poll();
+int dyb_tp_gn_wt();
 int dyb_gn_bwd_apply_dy(const float* dm, const float* y, const float* stats, const float* part, int nch, int ncolb,
                         const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int HW, int C, hipStream_t st);
 int dyb_conv_dgrad_plain_raw(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* addend, void* ws,

@@ -397,32 +397,6 @@ __device__ __forceinline__ void gnf_prologue(const GnFwdFuse& nf, int N, int C, 
   __syncthreads();
 }
 
-// buffer resource over [p, p + bytes) (raw, stride 0; gfx9 data-format word) and a 16-byte load through it
-#define TP_OOB 0x80000000u
-typedef unsigned tp_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tp_rsrc(const float* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
-}
-__device__ __forceinline__ float4 tp_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;      // (bit_cast straight from a vector element reads element 0 on host clang)
-  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
-}
-// 16-byte store through a buffer resource with cache policy AUX (0 plain, 16 = sc1: write-through at device scope, 2 = nt, 17 = sc0 sc1);
-// a per-lane offset >= num_records (TP_OOB) is dropped by the hardware
-template <int AUX>
-__device__ __forceinline__ void tp_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
-  tp_u4 x;
-  x.x = __builtin_bit_cast(unsigned, v.x); x.y = __builtin_bit_cast(unsigned, v.y);
-  x.z = __builtin_bit_cast(unsigned, v.z); x.w = __builtin_bit_cast(unsigned, v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)voff, 0, AUX);
-}
-// the same load past the vector L1 (sc1): data another workgroup of this launch stored write-through
-__device__ __forceinline__ float4 tp_buf_load4_dev(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-  const tp_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16);
-  const unsigned a = x.x, b = x.y, c = x.z, d = x.w;
-  return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
-}
 // BF: the bf16 matrix-core variant (BASELINE configs[4]).  Everything up to the staging store is the same fp32 code - operands
 // come from fp32 HBM tensors (master weights, fp32 activations), the GroupNorm arithmetic of the fused loaders and the
 // accumulators stay fp32 - but the operand tiles are rounded to bf16 (nearest-even) when they are staged and the product runs
@@ -1292,7 +1266,7 @@ extern "C" int dyb_debug_set_conv_sync(unsigned* ctr, int nwords) {
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt, tp_fold, lat_fold, stat_folds;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt, tp_fold, lat_fold, stat_folds, tp_gn_wt;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1319,6 +1293,7 @@ struct DybSwitches {
     tp_fold = env("DYB_TP_FOLD", 0);       // measured (r05 s3): 32 sequences 461 vs 463 frames/s off, 16: 362 vs 376 - the folding workgroups are a tail
     lat_fold = env("DYB_LAT_FOLD", 1);
     stat_folds = 0;
+    tp_gn_wt = env("DYB_TP_GN_WT", 0);
   }
 };
 static DybSwitches& switches() {
@@ -1353,6 +1328,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_wt")) return &s.tp_wt;
   if (!strcmp(name, "tp_fold")) return &s.tp_fold;
   if (!strcmp(name, "lat_fold")) return &s.lat_fold;
+  if (!strcmp(name, "tp_gn_wt")) return &s.tp_gn_wt;
   if (!strcmp(name, "stat_folds")) return &s.stat_folds;      // (a counter, not a switch: conv launches that folded their split in-kernel)
   return nullptr;
 }
@@ -2037,6 +2013,7 @@ int dyb_tp_gn_onepass() { return switches().tp_gn_onepass.load(std::memory_order
 int dyb_tp_gn_cap() { return switches().tp_gn_cap.load(std::memory_order_relaxed); }
 int dyb_tp_gn_threads() { return switches().tp_gn_threads.load(std::memory_order_relaxed); }
 int dyb_tp_gn_poll() { return switches().tp_gn_poll.load(std::memory_order_relaxed); }
+int dyb_tp_gn_wt() { return switches().tp_gn_wt.load(std::memory_order_relaxed); }
 bool dyb_throughput_mode(int batch) {
   const DybSwitches& sw = switches();
   if (sw.rep_split.load(std::memory_order_relaxed) != 0 && dyb_rep_current().n >= sw.tp_min.load(std::memory_order_relaxed)) return true;

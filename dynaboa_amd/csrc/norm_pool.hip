@@ -663,6 +663,7 @@ struct GnOnepass {
   size_t slab_stride;
   int nslabs, HW, C, rows, relu;
   int poll_sleep;          // s_sleep(8) repetitions between two polls of the slab's counter
+  int wt;                  // dy / dm leave write-through ("tp_gn_wt": as the convolutions' result tiles, igemm_tp.inc)
 };
 template <int OP_T>
 __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRep R) {
@@ -819,8 +820,14 @@ __global__ __launch_bounds__(OP_T) void gn_bwd_onepass_kernel(GnOnepass a, DybRe
       r.y = rstd * (ga.y * d[j].y - c1 - xh[j].y * c2);
       r.z = rstd * (ga.z * d[j].z - c1 - xh[j].z * c2);
       r.w = rstd * (ga.w * d[j].w - c1 - xh[j].w * c2);
-      *reinterpret_cast<float4*>(a.dy + off) = r;
-      if (a.dm) *reinterpret_cast<float4*>(a.dm + off) = d[j];
+      if (a.wt) {
+        const size_t tb = (size_t)a.HW * C * sizeof(float);
+        tp_buf_store4<16>(tp_rsrc(a.dy, tb), (unsigned)(off * 4), r);
+        if (a.dm) tp_buf_store4<16>(tp_rsrc(a.dm, tb), (unsigned)(off * 4), d[j]);
+      } else {
+        *reinterpret_cast<float4*>(a.dy + off) = r;
+        if (a.dm) *reinterpret_cast<float4*>(a.dm + off) = d[j];
+      }
     }
   }
   if (k > 1 && chunk == 0 && tid < cqg) {
@@ -895,7 +902,7 @@ int dyb_gn_bwd_onepass(const float* din, int nslabs, size_t slab_stride, const f
   const int rows = dyb_cdiv(HW, k);
   DYB_REQUIRE(dyb_is_pow2(C) && C >= 64 && C <= 2048 && rows * (C / 16) <= 1024 * OP_IT && dyb_cdiv(HW, rows) == k, DYB_ERR_UNSUPPORTED);
   GnOnepass a{din, addend, out, y, stats, gamma, beta, dm == din ? nullptr : dm, dy, dgamma, dbeta, part, ctr, slab_stride, nslabs, HW, C,
-              rows, relu, dyb_tp_gn_poll() > 0 ? dyb_tp_gn_poll() : 1};
+              rows, relu, dyb_tp_gn_poll() > 0 ? dyb_tp_gn_poll() : 1, dyb_tp_gn_wt()};
   const DybRep& R = dyb_rep_current();
   const int items = rows * (C / 16);
   if (items <= 256 * OP_IT) hipLaunchKernelGGL(gn_bwd_onepass_kernel<256>, dim3(k, G, R.n), dim3(256), 0, st, a, R);
