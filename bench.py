@@ -534,6 +534,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
+    if dist is not None and os.environ.get("DYB_BENCH_SMOKE_ONE_GPU") == "1":
+        # several PROCESSES on one GPU are time-sliced: the workgroups of a GroupNorm slab that meet on a counter inside one launch are
+        # then not co-resident for long stretches and the hand-off times out (the library counts it, the metric flush raises - round 5;
+        # the first closing session's smoke run failed exactly so: 96 timed-out hand-offs).  One-workgroup slabs only in this mode.
+        from dynaboa_amd import _lib as _L0
+        _L0.load().dyb_set_option(b"tp_gn_onepass", 1)
 
     simple = not (args.second_order or args.full_losses)
     # replica groups cover the first-order configurations: frame losses (the headline) and, given explicitly, the default term set

@@ -69,4 +69,14 @@ print("one stream:", round(d["value"],1), "frames/s", round(d["ms_per_step"],2),
 PY
 timeout 200 python tools/tp_lab.py 16 16 4096 4096 1 1 2>/dev/null | tail -1 > $O/gemm4096.json; cat $O/gemm4096.json
 timeout 200 python tools/host_floor.py 40 2>&1 | tail -1 | tee $O/host_floor.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee $O/smoke.txt
+DYB_BENCH_SMOKE_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 2 --no_cpu_baseline > $O/bench_two_ranks_one_gpu.json 2> $O/bench_two_ranks_one_gpu.err
+python - <<PY
+import json
+try:
+    d = json.loads(open("$O/bench_two_ranks_one_gpu.json").read().strip().splitlines()[-1])
+    print("two ranks on one GPU (control flow only):", d["n_gpus"], round(d["value"], 1), (d.get("pw3d_operating_point") or {}).get("value"))
+except Exception as e:
+    print("two-rank smoke failed:", e, open("$O/bench_two_ranks_one_gpu.err").read()[-600:])
+PY
 timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
