@@ -254,7 +254,7 @@ class Runner:
             # several sequences per launch: let the split-K policy see the replica-multiplied grid (fewer slabs to write and
             # fold; +5..7 % measured).  Summation order then differs from a sequence running alone - results equal to fp32
             # rounding (test_replica_group_with_replica_aware_split); with rep_split = 0 they are bit-identical
-            _lib.load().dyb_set_option(b"rep_split", 1)
+            NS.set_replica_policy(True)          # (+ the throughput schedule from 5 sequences per launch: native_step.TP_MIN_SEQUENCES)
             self.ads = [build_adaptor(device, batch, inner_step, **kw) for _ in range(seqs)]
             per = seqs // self.G
             # G > 1: the sequences form G lockstep groups, each with its own stepper, issuing thread and stream, free-running

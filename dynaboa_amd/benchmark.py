@@ -111,6 +111,10 @@ parser.add_argument('--num_shards', type=int, default=1,
 parser.add_argument('--shard_rank', type=int, default=0, help="this process's shard (torchrun's RANK overrides it)")
 parser.add_argument('--seqs_per_gpu', type=int, default=1,
                     help="sequences of this shard adapted at once, in lockstep launches (own weights / Adam state / records each)")
+parser.add_argument('--replica_policy', choices=['throughput', 'bitexact'], default='throughput',
+                    help="--seqs_per_gpu > 1: 'throughput' = split depth chosen for the replica-multiplied grid and, from 5 sequences per "
+                         "launch, the throughput schedule (results equal to a sequence adapted alone to fp32 rounding); 'bitexact' = the "
+                         "single-sequence policy (bit-identical to sequences adapted alone, about half the frame rate at 32 sequences)")
 parser.add_argument('--eval_lower', type=int, default=1, choices=[0, 1],
                     help='run inference() after every inner step like the reference (:142)')
 

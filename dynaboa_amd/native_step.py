@@ -407,6 +407,25 @@ class NativeStepper:
         return c[1][r][level]
 
 
+# Sequences per launch from which the throughput schedule (dy materialised once per layer by the one-pass GroupNorm backward, plain
+# gradient convolutions on igemm_tp_kernel) beats the latency schedule: measured crossover, frames/s latency | throughput at
+# 4: 173.6 | 169.3, 5: 185.8 | 198.9, 6: 198.4 | 222.9, 7: 206.1 | 247.9 (profiles/r05_sessions.txt s15; the library's own default
+# is 8)
+TP_MIN_SEQUENCES = 5
+
+
+def set_replica_policy(throughput: bool = True):
+    """Process-wide launch policy for replica groups (library switches "rep_split" / "tp_min").  throughput = True: the split-K
+    depth is chosen for the replica-multiplied grid and groups of >= TP_MIN_SEQUENCES run the throughput schedule - every sequence's
+    results equal the sequence adapted alone to fp32 rounding (different summation orders; tests/test_adaptation_gpu.py
+    test_replica_group_with_replica_aware_split).  False: the policy of a single sequence - bit-identical to sequences alone, at
+    32 sequences roughly half the frame rate."""
+    lib = _lib.load()
+    check(lib.dyb_set_option(b"rep_split", 1 if throughput else 0), "dyb_set_option rep_split")
+    if throughput:
+        check(lib.dyb_set_option(b"tp_min", TP_MIN_SEQUENCES), "dyb_set_option tp_min")
+
+
 class ReplicaGroup:
     """S independent sequences adapted on ONE GPU in lockstep (the shard axis of SURVEY 8e inside a device): S adaptors
     with identical options, one native stepper whose launches cover all of them.  ``step(batches)`` = one

@@ -114,6 +114,10 @@ def main(options):
     nsh = world if world > 1 else int(options.num_shards)
     dev = torch.device("cuda", torch.cuda.current_device())
     seqs = pw3d_sequences(options, dev)
+    if int(options.seqs_per_gpu) > 1:
+        # several sequences per launch: the throughput policy unless bit-identity with sequences adapted alone is asked for
+        from . import native_step as NS
+        NS.set_replica_policy(getattr(options, "replica_policy", "throughput") != "bitexact")
     res = run_sharded(options, seqs, lambda: DB.Adaptor(options, device=dev), nsh, rank, int(options.seqs_per_gpu))
     if rank == 0:
         print(f"frames:{len(res['mpjpe'])} MPJPE:{np.mean(res['mpjpe'])}, PAMPJPE:{np.mean(res['pampjpe'])}, PVE:{np.mean(res['pve'])}")

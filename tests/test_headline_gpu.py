@@ -17,12 +17,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def headline_switches():
-    """bench.py Runner.__init__ for seqs > 1: rep_split = 1, everything else at its default."""
-    from dynaboa_amd import _lib
+    """bench.py Runner.__init__ / the sharded driver for several sequences per GPU: native_step.set_replica_policy(True)."""
+    from dynaboa_amd import _lib, native_step as NS
     lib = _lib.load()
-    lib.dyb_set_option(b"rep_split", 1)
+    NS.set_replica_policy(True)          # rep_split = 1, throughput schedule from NS.TP_MIN_SEQUENCES (5) sequences per launch
     yield lib
     lib.dyb_set_option(b"rep_split", 0)
+    lib.dyb_set_option(b"tp_min", 8)
 
 
 def _mk(r):
@@ -68,7 +69,7 @@ def _throughput_schedule_is_on(lib, S):
     return _opt(lib, b"rep_split") == 1 and S >= _opt(lib, b"tp_min") and _opt(lib, b"tp_kernel") >= 1
 
 
-@pytest.mark.parametrize("S", [8])
+@pytest.mark.parametrize("S", [8, 5])        # 5: the smallest group the drivers put on the throughput schedule (round 5: measured crossover)
 def test_headline_schedule_stream_matches_reference_and_single_runs(S, headline_switches):
     lib = headline_switches
     assert _throughput_schedule_is_on(lib, S)
