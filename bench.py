@@ -750,7 +750,7 @@ def main():
                                                  "first-order, frame losses + label term", retrieval=1, lower_level_mixtrain=1,
                                                  upper_level_mixtrain=1, sample_num=8)
             # configs[4] arms at batch 16 (one sequence): the throughput schedule (igemm_tp kernels, materialised dy) is the default from
-            # batch 16 on (switch tp_batch_min = 16); the bf16 arm runs the bf16 form of the same kernel
+            # batch 8 on (switch tp_batch_min = 8, round 5: measured crossover); the bf16 arm runs the bf16 form of the same kernel
             out["batch16_fp32_vs_bf16"] = dict(
                 fp32=sub_record(device, "b16_fp32", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, first-order, frame losses, "
                                 "fp32 MFMA (exact)", roofline_peak=PEAK_FP32_MFMA_TFLOPS),
@@ -778,7 +778,7 @@ def main():
                         device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
                         "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
                 finally:
-                    _L.load().dyb_set_option(b"tp_batch_min", 16)
+                    _L.load().dyb_set_option(b"tp_batch_min", 8)
             out["full_default_losses"] = sub_record(device, "full_default_losses", 24, 6, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
                                                     "dynamic-BOA gate)", full_losses=1)

@@ -1261,7 +1261,7 @@ extern "C" int dyb_debug_set_conv_sync(unsigned* ctr, int nwords) {
 // the throughput schedule - dy materialised once per layer, plain gradient convolutions, no single-launch 1x1 kernels),
 // "tp_kernel" (throughput schedule runs igemm_tp_kernel: 128x128-class tiles, 2 = its software-pipelined loop (default), 1 = round 2's
 // phase-separated loop; 0 = the 64x64 kernel), "tp_grid" (workgroups
-// its split-K aims for), "tp_batch_min" (16; > 0: the throughput schedule also for single-sequence launches of at least that batch:
+// its split-K aims for), "tp_batch_min" (8; > 0: the throughput schedule also for single-sequence launches of at least that batch:
 // +13.5 % at batch 16 in BENCH_r02, and the schedule the bf16 form of igemm_tp_kernel needs), "tp_gn_wgs" (workgroups a GroupNorm launch aims for over all replicas
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
@@ -1279,7 +1279,7 @@ struct DybSwitches {
     tp_kernel = env("DYB_TP_KERNEL", 2);
     tp_grid = env("DYB_TP_GRID", 512);
     tp_xcd = env("DYB_TP_XCD", 1);
-    tp_batch_min = env("DYB_TP_BATCH_MIN", 16);
+    tp_batch_min = env("DYB_TP_BATCH_MIN", 8);       // measured crossover (r05 s17): batch 6: 257.7 | 251.0, 8: 280.8 | 294.9, 12: 304.0 | 366.6, 16: 320.9 | 418.6 frames/s latency | throughput
     tp_gn_wgs = env("DYB_TP_GN_WGS", 1024);
     tp_occ = env("DYB_TP_OCC", 0);
     tp_gn_onepass = env("DYB_TP_GN_ONEPASS", 2);

@@ -438,13 +438,13 @@ def test_hmr_engine_one_image_throughput_schedule_with_onepass_groupnorm_backwar
 
 @pytest.mark.slow
 def test_hmr_engine_throughput_schedule_by_batch(be, ckpt_rand):
-    """The throughput schedule selected by the batch size of a single-sequence launch (switch tp_batch_min, 16 by default):
+    """The throughput schedule selected by the batch size of a single-sequence launch (switch tp_batch_min, 8 by default):
     the whole engine at batch 2 against the reference module's golden g3."""
     be.lib.dyb_set_option(b"tp_batch_min", 2)
     try:
         K.case_hmr_engine(be, golden, ckpt_rand)
     finally:
-        be.lib.dyb_set_option(b"tp_batch_min", 16)
+        be.lib.dyb_set_option(b"tp_batch_min", 8)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("DYB_EMU_FULL") != "1", reason="opt-in (DYB_EMU_FULL=1): minutes on the emulator")
