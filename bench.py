@@ -356,6 +356,14 @@ def timed_stream(runner, warmup, steps, stream, dist=None, per_frame=False):
         dist.barrier()
     torch.cuda.synchronize()
     evs = [] if per_frame else None
+    # The cyclic garbage collector stays out of the timed region (as `timeit` keeps it): after the ~300 adaptors this process builds
+    # for its side runs a generation-2 pass walks a large heap, and the configurations whose steps end in a host wait (the default
+    # term set's gate poll) then show the collector instead of the path - 309 - 333 frames/s as the tenth side run against 353 - 369
+    # as a fresh process (profiles/r05_sessions.txt s18).  Reference counting still frees everything a step allocates.
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         if evs is not None:
@@ -370,6 +378,8 @@ def timed_stream(runner, warmup, steps, stream, dist=None, per_frame=False):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     out = dict(dt=dt, t_issue=t_issue, metrics=metrics, run=run)
     if evs is not None:
         out["frame_ms"] = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)])
