@@ -21,6 +21,7 @@ import sys
 import time
 
 import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the runtime initialises: dynaboa_amd/__init__.py says why
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -280,6 +280,12 @@ struct Stepper {
   // the parameters) is updated on the main stream and the rest (layer3 | layer4 + regressor) on the auxiliary stream while the
   // forward's first layers run; the forward waits for each range right before its first reader (DybFwdGates)
   int upd_overlap = 1;
+  // one sequence, full term set: the history pass and the exemplar pass of a level are independent of the frame pass until their gradients
+  // are summed - they run on two streams of the stepper's own beside the chain ("par_passes"; batch-1 kernels fill a fraction of the chip)
+  int par_passes = 1;
+  hipStream_t par_stream[2] = {nullptr, nullptr};                                 // history pass | exemplar pass.  (A third stream for the teacher's
+  // forward was measured and removed: 75.7 - 76.9 frames/s against 89.4 - 92.3 with two, profiles/r05_sessions.txt s25.)
+  hipEvent_t par_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fork | hist fwd | hist head grads | hist bwd | label term | exemplar bwd
   bool out_in_main = false;        // where the latest final inference lives (dyb_stepper_output): fin, or main after an odd number of shared steps
   int share_dyn_fwd = 1;           // dynamic loop: an extra step's upper level reuses the previous step's final inference as its forward
   int upd_blocks = 0;              // > 0: workgroup cap (all replicas together) of the ranged passes on the auxiliary stream (measured: no effect, 512 .. uncapped)
@@ -432,6 +438,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   if (const char* e = getenv("DYB_UPD_BLOCKS")) S->upd_blocks = atoi(e);
   if (const char* e = getenv("DYB_SHARE_DYN_FWD")) S->share_dyn_fwd = atoi(e);
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
+  if (const char* e = getenv("DYB_PAR_PASSES")) S->par_passes = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
@@ -457,6 +464,8 @@ extern "C" void dyb_stepper_destroy(void* stepper) {
   if (S->gates.ev[0]) (void)hipEventDestroy(S->gates.ev[0]);
   if (S->gates.ev[1]) (void)hipEventDestroy(S->gates.ev[1]);
   if (S->gates.mid) (void)hipEventDestroy(S->gates.mid);
+  for (int i = 0; i < 6; ++i) if (S->par_ev[i]) (void)hipEventDestroy(S->par_ev[i]);
+  for (int i = 0; i < 2; ++i) if (S->par_stream[i]) (void)hipStreamDestroy(S->par_stream[i]);
   delete S;
 }
 
@@ -473,6 +482,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "side_thread") S->side_thread = (int)v;
   else if (k == "upd_blocks") S->upd_blocks = (int)v;
   else if (k == "share_dyn_fwd") S->share_dyn_fwd = (int)v;
+  else if (k == "par_passes") S->par_passes = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
@@ -1012,14 +1022,52 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   const int B = S.B;
   const float* image = (const float*)C.in[IN_IMAGE];
   const float* kp = (const float*)C.in[IN_KP];
-  if (!have_fwd) RUN(pass_forward(S, P, cur, image, st));
-  RUN(pass_frame_head(S, P, kp, st));
-  const float* rot = P.acts + S.off_rot;
-  const float* state = P.acts + S.off_state;
   const bool temporal = upper ? S.temporal_upper != 0 : S.temporal_lower != 0;
   const bool teacher = temporal && S.use_teacher && S.teacher;
   const bool motion = temporal && S.use_motion && C.in[IN_HIST_IMAGE] && C.in[IN_HIST_KP];
   const bool label = (upper ? S.mix_upper : S.mix_lower) != 0;
+  // One sequence: the history pass and the exemplar pass go to streams of their own.  Dependencies (events par_ev[]): both wait for
+  // the weights (0: recorded on the chain where the level starts); the motion term (chain) needs the history forward (1) and leaves
+  // the history pass's head gradients (2) for its backward; the chain's log row reads the label term's values (4); the weight update
+  // that follows the level reads all three gradient arenas (3, 5).  Their backwards run without an auxiliary stream (weight gradients
+  // in line: the engine's per-plan event set serves one two-stream backward at a time - the chain's).  Retrieval by callback
+  // synchronises with the level's own forward on the host: sequential as before.
+  const bool par = S.par_passes && S.nrep == 1 && dyb_rep_current().n == 1 && !S.retrieve && !S.retrieve_rep && (motion || label);
+  hipStream_t sB = st, sC = st;
+  if (par) {
+    for (int i = 0; i < 2; ++i)
+      if (!S.par_stream[i]) HIPOK(hipStreamCreateWithFlags(&S.par_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i)
+      if (!S.par_ev[i]) HIPOK(hipEventCreateWithFlags(&S.par_ev[i], hipEventDisableTiming));
+    sB = S.par_stream[0]; sC = S.par_stream[1];
+    HIPOK(hipEventRecord(S.par_ev[0], st));
+    if (motion) HIPOK(hipStreamWaitEvent(sB, S.par_ev[0], 0));
+    if (label) HIPOK(hipStreamWaitEvent(sC, S.par_ev[0], 0));
+  }
+  if (!have_fwd) RUN(pass_forward(S, P, cur, image, st));
+  RUN(pass_frame_head(S, P, kp, st));
+  const float* rot = P.acts + S.off_rot;
+  const float* state = P.acts + S.off_state;
+  if (par && motion) {
+    RUN(pass_forward(S, S.hist, cur, (const float*)C.in[IN_HIST_IMAGE], sB, false));
+    HIPOK(hipEventRecord(S.par_ev[1], sB));
+  }
+  auto label_pass_forward_and_term = [&](hipStream_t s, bool chain) -> int {
+    RUN(pass_forward(S, S.ex, cur, (const float*)C.in[IN_EX_IMG], s, chain));
+    RUN(dyb_rodrigues_fwd((const float*)C.in[IN_EX_POSE], S.ex_rot, B * 24, s));          // utils/geometry.py:9-24 on the exemplar pose
+    const float* es = S.ex.acts + S.off_state;
+    return dyb_aux_loss_terms(2, B, 0, (float)S.label_w, S.ex.acts + S.off_rot, es + 144, STATE_LD, es + 154, STATE_LD, S.ex.joints, nullptr,
+                              nullptr, 0, nullptr, 0, nullptr, (const float*)C.in[IN_EX_KP], nullptr, S.ex_rot,
+                              (const float*)C.in[IN_EX_BETAS], (const float*)C.in[IN_EX_POSE3D], S.vals_l, S.exg_rot, S.exg_shape, S.exg_cam,
+                              S.exg_joints, nullptr, nullptr, s);
+  };
+  if (par && label) {
+    DYB_REQUIRE(C.in[IN_EX_IMG] && C.in[IN_EX_KP] && C.in[IN_EX_POSE] && C.in[IN_EX_BETAS] && C.in[IN_EX_POSE3D], DYB_ERR_ARG);
+    RUN(label_pass_forward_and_term(sC, false));
+    HIPOK(hipEventRecord(S.par_ev[4], sC));
+    RUN(pass_backward_ext(S, S.ex, cur, S.grads3, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, sC, nullptr));
+    HIPOK(hipEventRecord(S.par_ev[5], sC));
+  }
   bool ext = false;
   if (teacher) {
     // teacher forward (no gradient): reference base_adaptor.py:324-329
@@ -1032,14 +1080,21 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   }
   if (motion) {
     // the history frame through the SAME weights, with gradient (base_adaptor.py:380-386)
-    RUN(pass_forward(S, S.hist, cur, (const float*)C.in[IN_HIST_IMAGE], st));
+    if (par) HIPOK(hipStreamWaitEvent(st, S.par_ev[1], 0));
+    else RUN(pass_forward(S, S.hist, cur, (const float*)C.in[IN_HIST_IMAGE], st));
     const float* hs = S.hist.acts + S.off_state;
     RUN(dyb_aux_loss_terms(1, B, ext ? 1 : 0, (float)S.motion_w, rot, state + 144, STATE_LD, state + 154, STATE_LD, P.joints, nullptr,
                            nullptr, 0, hs + 154, STATE_LD, S.hist.joints, kp, (const float*)C.in[IN_HIST_KP], nullptr, nullptr, nullptr,
                            S.vals_m, S.ext_rot, S.ext_shape, S.ext_cam, S.ext_joints, S.hg_cam, S.hg_joints, st));
     ext = true;
+    if (par) {
+      HIPOK(hipEventRecord(S.par_ev[2], st));
+      HIPOK(hipStreamWaitEvent(sB, S.par_ev[2], 0));
+      RUN(pass_backward_ext(S, S.hist, cur, S.grads2, false, nullptr, nullptr, S.hg_cam, S.hg_joints, sB, nullptr));
+      HIPOK(hipEventRecord(S.par_ev[3], sB));
+    }
   }
-  if (label) {
+  if (label && !par) {
     // retrieval (base_adaptor.py:82-96) happens on the host: hand it the pooled feature of this level's forward
     if (S.nrep > 1 && S.retrieve_rep) {
       DYB_REQUIRE(S.feat5_out, DYB_ERR_ARG);
@@ -1066,15 +1121,10 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
       for (int k = 0; k < 5; ++k) C.in[IN_EX_IMG + k] = exin[k];
     }
     DYB_REQUIRE(C.in[IN_EX_IMG] && C.in[IN_EX_KP] && C.in[IN_EX_POSE] && C.in[IN_EX_BETAS] && C.in[IN_EX_POSE3D], DYB_ERR_ARG);
-    RUN(pass_forward(S, S.ex, cur, (const float*)C.in[IN_EX_IMG], st));
-    RUN(dyb_rodrigues_fwd((const float*)C.in[IN_EX_POSE], S.ex_rot, B * 24, st));          // utils/geometry.py:9-24 on the exemplar pose
-    const float* es = S.ex.acts + S.off_state;
-    RUN(dyb_aux_loss_terms(2, B, 0, (float)S.label_w, S.ex.acts + S.off_rot, es + 144, STATE_LD, es + 154, STATE_LD, S.ex.joints, nullptr,
-                           nullptr, 0, nullptr, 0, nullptr, (const float*)C.in[IN_EX_KP], nullptr, S.ex_rot,
-                           (const float*)C.in[IN_EX_BETAS], (const float*)C.in[IN_EX_POSE3D], S.vals_l, S.exg_rot, S.exg_shape, S.exg_cam,
-                           S.exg_joints, nullptr, nullptr, st));
+    RUN(label_pass_forward_and_term(st, true));
   }
   if (C.losslog) {
+    if (par && label) HIPOK(hipStreamWaitEvent(st, S.par_ev[4], 0));          // the row reads the label term's values
     hipLaunchKernelGGL(level_log_kernel, dim3(1, 1, dyb_rep_current().n), dim3(64), 0, st, (const float*)P.losses,
                        teacher ? (const float*)S.vals_t : nullptr, motion ? (const float*)S.vals_m : nullptr,
                        label ? (const float*)S.vals_l : nullptr, (float)S.teacher_w, (float)S.motion_w, (float)S.label_w,
@@ -1083,19 +1133,19 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
     ++C.level_row;
   }
   // gradient of the level total: image pass (+ its external terms), history pass, exemplar pass
-  const size_t n = S.n_params;
   RUN(pass_backward_ext(S, P, cur, S.grads, true, ext ? S.ext_rot : nullptr, ext ? S.ext_shape : nullptr, ext ? S.ext_cam : nullptr,
                         ext ? S.ext_joints : nullptr, st, aux));
   // (the level's gradient = (image pass + history pass) + exemplar pass: the passes keep their own arenas and the weight update that
   // follows every level adds them while it reads them - no accumulation passes)
-  (void)n;
   S.lvl_g2 = S.lvl_g3 = nullptr;
   if (motion) {
-    RUN(pass_backward_ext(S, S.hist, cur, S.grads2, false, nullptr, nullptr, S.hg_cam, S.hg_joints, st, aux));
+    if (par) HIPOK(hipStreamWaitEvent(st, S.par_ev[3], 0));
+    else RUN(pass_backward_ext(S, S.hist, cur, S.grads2, false, nullptr, nullptr, S.hg_cam, S.hg_joints, st, aux));
     S.lvl_g2 = S.grads2;
   }
   if (label) {
-    RUN(pass_backward_ext(S, S.ex, cur, S.grads3, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, st, aux));
+    if (par) HIPOK(hipStreamWaitEvent(st, S.par_ev[5], 0));
+    else RUN(pass_backward_ext(S, S.ex, cur, S.grads3, false, S.exg_rot, S.exg_shape, S.exg_cam, S.exg_joints, st, aux));
     if (S.lvl_g2) S.lvl_g3 = S.grads3;
     else S.lvl_g2 = S.grads3;
   }

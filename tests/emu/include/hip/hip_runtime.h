@@ -140,6 +140,10 @@ static inline hipError_t hipMemcpyFromSymbolAsync(void* d, const void* sym, size
 }
 void emu_stream_synchronize(void* st);
 static inline hipError_t hipStreamSynchronize(hipStream_t st) { emu_stream_synchronize(st); return hipSuccess; }
+// streams of the library's own (the stepper's parallel passes): a stream is just a queue key here
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = malloc(8); return *s ? hipSuccess : 1; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emu::event_new(); return hipSuccess; }

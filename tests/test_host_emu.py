@@ -435,6 +435,49 @@ def test_full_term_replica_group_ranged_updates_under_adversarial_stream_order(e
             assert torch.equal(a, b)
 
 
+@pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~8 min under the emulator; set DYB_EMU_FULL=1")
+def test_full_term_parallel_passes_under_adversarial_stream_order(emu_lib, monkeypatch):
+    """One sequence, the reference's default term set: the history pass and the exemplar pass of a level run on two streams of the
+    stepper's own beside the frame pass (adapt_step.hip full_level, "par_passes").  Three frames (the third has a history frame:
+    interval 1) in the emulator's lazy stream mode, drained chain-first and in reverse: weights, Adam state, teacher and metrics of the
+    sequential run (par_passes = 0) bit for bit - every cross-stream read waits for its event."""
+    from types import SimpleNamespace
+    from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
+    from dynaboa_amd.base_adaptor import synthetic_bundle
+    raw = _lib.load()
+    frames = [assets.make_frame(s, 1, seed=22) for s in range(3)]
+    orig = NS.NativeStepper.adapt_frame_full
+    outs = []
+    for par, order in ((0, None), (1, None), (1, 0), (1, 1)):
+        used = []
+
+        def wrapped(self, *a, order=order, used=used, par=par, **kw):
+            self._aux = SimpleNamespace(cuda_stream=1)          # any non-null handle is a second stream to the emulator
+            assert self.lib.dyb_stepper_set_i(self.h, b"par_passes", par) == 0
+            if order is None:
+                return orig(self, *a, **kw)
+            raw.emu_lazy(1)
+            try:
+                return orig(self, *a, **kw)
+            finally:
+                used.append(raw.emu_flush(order))
+                raw.emu_lazy(0)
+        monkeypatch.setattr(NS.NativeStepper, "adapt_frame_full", wrapped)
+        o = DB.parser.parse_args([])
+        o.inner_step, o.interval, o.dynamic_boa, o.deferred_metrics = 1, 1, 0, 1     # (no dynamic-BOA gate: its host poll cannot run inside a lazy section)
+        ad = DB.Adaptor(o, synthetic_bundle(seed=22, identity_pose=False, randomize_norm=True), device="cpu")
+        res = ad.excute(frames, nframes=3)
+        assert ad._native is not None and ad._native.full
+        if order is not None:
+            assert used[0] >= 3 and used[-1] == 4, used          # chain + auxiliary + exemplar stream; + the history stream once there is one
+        st = ad.optimizer.state[ad.model.module.theta]
+        outs.append([ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), ad.teacher.theta.detach().clone(),
+                     torch.from_numpy(np.ravel(np.array(res["mpjpe"], np.float64)))])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
     assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None

@@ -157,3 +157,24 @@ def test_sharded_driver_on_one_gpu_matches_sequences_alone():
             got[int(gi)] = float(m)
     assert sorted(got) == list(range(sum(lens)))
     np.testing.assert_allclose([got[i] for i in range(sum(lens))], alone, rtol=2e-5)
+
+
+def test_parallel_passes_of_one_sequence_are_bit_identical_to_the_sequential_level(monkeypatch):
+    """One sequence, default term set, the dynamic loop entered (a low threshold, at most three extra steps): the history pass and the
+    exemplar pass on the stepper's own streams (par_passes 1, round 5) against the sequential level (0) - weights, Adam moments,
+    teacher, extra-step counts and metrics bit for bit over four frames (interval 2: the last two have a history frame)."""
+    frames = _frames(1, 4)[0]
+    outs = []
+    for par in ("0", "1", "1"):
+        monkeypatch.setenv("DYB_PAR_PASSES", par)           # read when the stepper is created
+        ad = _mk(0, dict(FULL, cos_sim_threshold=1.0e-4, optim_steps=3))
+        res = ad.excute(frames, nframes=4)
+        assert ad._native is not None and ad._native.full
+        st = _state(ad)
+        outs.append([st["theta"], st["m"], st["v"], st["teacher"], torch.tensor(st["steps"]),
+                     torch.tensor(np.ravel(np.array(res["mpjpe"], np.float64)))])
+        del ad
+    assert len(outs[0][4]) == 4 and int(outs[0][4].max()) >= 1, outs[0][4]       # the loop was entered
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
