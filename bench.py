@@ -21,7 +21,6 @@ import sys
 import time
 
 import numpy as np
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the runtime initialises: dynaboa_amd/__init__.py says why
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -409,9 +408,31 @@ def replica_run(device, S, steps, warmup, batch, inner_step, rank=0, **kw):
 
 
 def sub_record(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, seqs=1, **kw):
-    """One of the side configurations carried in the same JSON line (value + ms_per_step), a short run each; with
-    roofline_peak (TFLOP/s) also the conv family's in-path achieved rate against that peak (2 extra steps).  seqs > 1: that many
-    sequences in lockstep (a ReplicaGroup), value = aggregate frames/s."""
+    """One of the side configurations carried in the same JSON line, measured in a FRESH PROCESS (as a user would run it): the tenth
+    configuration of one process inherits its predecessors' state - a large Python heap (the collector), and above all the HIP streams
+    earlier steppers created, which shift how the runtime multiplexes this configuration's streams onto its hardware queues: after the
+    one-sequence default-term-set run (two pass streams of its own, round 5) the later side runs lost 8 - 50 % in the same process and
+    nothing as fresh processes (profiles/r05_sessions.txt s26 / s27).  DYB_BENCH_SUB_INPROC=1 keeps them in this process."""
+    if os.environ.get("DYB_BENCH_SUB_INPROC") == "1":
+        kw.pop("env", None)
+        return sub_record_here(device, name, steps, warmup, batch, inner_step, note, roofline_peak, seqs, **kw)
+    import subprocess
+    child_env = dict(os.environ, **{k: str(v) for k, v in (kw.pop("env", None) or {}).items()})
+    spec = dict(name=name, steps=steps, warmup=warmup, batch=batch, inner_step=inner_step, note=note, roofline_peak=roofline_peak, seqs=seqs, kw=kw)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sub_record", json.dumps(spec)], capture_output=True, text=True, timeout=900,
+                             env=child_env)
+        sys.stderr.write("".join(l + "\n" for l in out.stderr.splitlines() if l.startswith("[bench]")))
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:      # noqa: BLE001
+        return dict(value=None, error=f"side run in its own process: {type(e).__name__}: {e}", config=note)
+
+
+def sub_record_here(device, name, steps, warmup, batch, inner_step, note, roofline_peak=None, seqs=1, **kw):
+    """The side configuration itself (value + ms_per_step), a short run; with roofline_peak (TFLOP/s) also the conv family's in-path
+    achieved rate against that peak (2 extra steps).  seqs > 1: that many sequences in lockstep (a ReplicaGroup), value = aggregate
+    frames/s."""
     t_sub = time.perf_counter()
     try:
         extra = 2 if roofline_peak else 0
@@ -513,6 +534,7 @@ def main():
     ap.add_argument("--probe_out", type=str, default="")
     ap.add_argument("--conv_table", type=str, default="", help="write the per-shape conv timing table of the roofline leg (CSV) here")
     ap.add_argument("--cpu_baseline_only", action="store_true")
+    ap.add_argument("--sub_record", type=str, default="", help="(internal) one side configuration as JSON: run it here, print its record")
     ap.add_argument("--seqs_full", type=int, default=0, help="1: --seqs also applies to --full_losses 1 (lab runs / traces of the replica-batched default term set)")
     ap.add_argument("--cos_sim_threshold", type=float, default=None, help="--full_losses 1: the dynamic-BOA gate's threshold (default: the reference's 3.1e-4)")
     ap.add_argument("--all_sub_records", action="store_true",
@@ -521,6 +543,16 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args.inner_step)))
+        return
+    if args.sub_record:
+        spec = json.loads(args.sub_record)
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        if "tp_batch_min" in spec["kw"]:          # (the latency-schedule arm of the batch-16 comparison: a library switch, set in this process)
+            from dynaboa_amd import _lib as _Ls
+            _Ls.load().dyb_set_option(b"tp_batch_min", int(spec["kw"].pop("tp_batch_min")))
+        print(json.dumps(sub_record_here(dev, spec["name"], spec["steps"], spec["warmup"], spec["batch"], spec["inner_step"], spec["note"],
+                                         spec["roofline_peak"], spec["seqs"], **spec["kw"])))
         return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -783,16 +815,17 @@ def main():
                                         "(exact Hessian-vector products), frame losses, fp32", second_order=1, hvp="exact"))
             from dynaboa_amd import _lib as _L
             if args.all_sub_records:
-                try:
-                    _L.load().dyb_set_option(b"tp_batch_min", 0)
-                    out["batch16_fp32_vs_bf16"]["fp32_latency_schedule"] = sub_record(
-                        device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
-                        "GroupNorm backward in the loaders) that batches below 16 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS)
-                finally:
-                    _L.load().dyb_set_option(b"tp_batch_min", 8)
+                out["batch16_fp32_vs_bf16"]["fp32_latency_schedule"] = sub_record(
+                    device, "b16_fp32_lat", 10, 3, 16, args.inner_step, "configs[4] arm: batch 16, fp32, the latency schedule (64x64 kernel, "
+                    "GroupNorm backward in the loaders) that batches below 8 use (switch tp_batch_min = 0)", roofline_peak=PEAK_FP32_MFMA_TFLOPS,
+                    tp_batch_min=0)
+            Q8 = dict(GPU_MAX_HW_QUEUES="8")
+            q8_note = ("; GPU_MAX_HW_QUEUES=8 for this run: the chain, the weight-gradient stream and the two pass streams of a level then each have a "
+                       "hardware queue (78 frames/s with the runtime's default 4, 65 with the passes in sequence)")
             out["full_default_losses"] = sub_record(device, "full_default_losses", 24, 6, 1, 1,
                                                     "the reference's default flags (inner_step 1, teacher + motion + labelled exemplars + "
-                                                    "dynamic-BOA gate)", full_losses=1)
+                                                    "dynamic-BOA gate), ONE sequence - the configuration of the reference's published run" + q8_note,
+                                                    full_losses=1, env=Q8)
             torch.cuda.empty_cache()
             out["full_default_losses_S32"] = sub_record(
                 device, "full_default_losses_S32", 10, 3, 1, 1, "the reference's default flags (inner_step 1, teacher + motion + labelled "
@@ -805,8 +838,8 @@ def main():
                 thr, dtab = calibrate_gate_threshold(device)
                 note = ("the reference's default flags with cos_sim_threshold = %.3e (calibrated on this synthetic stream so that the dynamic-BOA "
                         "loop takes 2-3 extra upper-level steps per frame, as on real video; with the default 3.1e-4 it never opens here)" % thr)
-                out["full_default_losses_dynamic"] = sub_record(device, "full_default_losses_dynamic", 16, 4, 1, 1, note, full_losses=1,
-                                                                cos_sim_threshold=thr)
+                out["full_default_losses_dynamic"] = sub_record(device, "full_default_losses_dynamic", 16, 4, 1, 1, note + q8_note, full_losses=1,
+                                                                cos_sim_threshold=thr, env=Q8)
                 torch.cuda.empty_cache()
                 out["full_default_losses_dynamic_S32"] = sub_record(device, "full_default_losses_dynamic_S32", 8, 2, 1, 1, note + "; 32 sequences in "
                                                                     "lockstep, the gate decided per sequence", roofline_peak=None, seqs=32, full_losses=1,
