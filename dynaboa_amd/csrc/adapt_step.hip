@@ -282,7 +282,7 @@ struct Stepper {
   int upd_overlap = 1;
   // one sequence, full term set: the history pass and the exemplar pass of a level are independent of the frame pass until their gradients
   // are summed - they run on two streams of the stepper's own beside the chain ("par_passes"; batch-1 kernels fill a fraction of the chip)
-  int par_passes = 1;
+  int par_passes = 1, par_max_replicas = DYB_MAX_REPLICAS;   // measured up to 32 per launch: 16: 290 -> 316, 32: 362 -> 377 frames/s (s30)
   hipStream_t par_stream[2] = {nullptr, nullptr};                                 // history pass | exemplar pass.  (A third stream for the teacher's
   // forward was measured and removed: 75.7 - 76.9 frames/s against 89.4 - 92.3 with two, profiles/r05_sessions.txt s25.)
   hipEvent_t par_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fork | hist fwd | hist head grads | hist bwd | label term | exemplar bwd
@@ -439,6 +439,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   if (const char* e = getenv("DYB_SHARE_DYN_FWD")) S->share_dyn_fwd = atoi(e);
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
   if (const char* e = getenv("DYB_PAR_PASSES")) S->par_passes = atoi(e);
+  if (const char* e = getenv("DYB_PAR_MAX_REPLICAS")) S->par_max_replicas = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&S->e_gt, hipEventDisableTiming) != hipSuccess ||
@@ -483,6 +484,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "upd_blocks") S->upd_blocks = (int)v;
   else if (k == "share_dyn_fwd") S->share_dyn_fwd = (int)v;
   else if (k == "par_passes") S->par_passes = (int)v;
+  else if (k == "par_max_replicas") S->par_max_replicas = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
@@ -1032,7 +1034,13 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   // that follows the level reads all three gradient arenas (3, 5).  Their backwards run without an auxiliary stream (weight gradients
   // in line: the engine's per-plan event set serves one two-stream backward at a time - the chain's).  Retrieval by callback
   // synchronises with the level's own forward on the host: sequential as before.
-  const bool par = S.par_passes && S.nrep == 1 && dyb_rep_current().n == 1 && !S.retrieve && !S.retrieve_rep && (motion || label);
+  // For replica groups too (up to par_max_replicas per launch, default: all): default term set, frames/s sequential -> parallel passes at
+  // 1: 65 -> 78 (89 with 8 hardware queues), 2: 93 -> 107, 3: 116 -> 129, 4: 131 -> 145, 5: 154 -> 182, 8: 205 -> 232, 16: 290 -> 316,
+  // 32: 362 -> 377 (profiles/r05_sessions.txt s29 / s30) - a level's three passes fill each other's ramps and tails.
+  const bool par = S.par_passes && dyb_rep_current().n <= S.par_max_replicas && !S.retrieve && !S.retrieve_rep && (motion || label);
+  // a ranged weight update may still be in flight (replica groups): the chain's forward waits for each range where it first reads it,
+  // the pass streams read every weight - they wait for both range events, which exist once the chain's forward has been issued
+  const bool ranged_before = par && S.gates_pending && !have_fwd;
   hipStream_t sB = st, sC = st;
   if (par) {
     for (int i = 0; i < 2; ++i)
@@ -1048,6 +1056,13 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   RUN(pass_frame_head(S, P, kp, st));
   const float* rot = P.acts + S.off_rot;
   const float* state = P.acts + S.off_state;
+  if (ranged_before) {
+    DYB_REQUIRE(!S.gates_pending && !S.gates.late, DYB_ERR_LAUNCH);            // consumed by the chain's forward above
+    for (int k = 0; k < 2; ++k) {
+      if (motion) HIPOK(hipStreamWaitEvent(sB, S.gates.ev[k], 0));
+      if (label) HIPOK(hipStreamWaitEvent(sC, S.gates.ev[k], 0));
+    }
+  }
   if (par && motion) {
     RUN(pass_forward(S, S.hist, cur, (const float*)C.in[IN_HIST_IMAGE], sB, false));
     HIPOK(hipEventRecord(S.par_ev[1], sB));

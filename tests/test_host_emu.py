@@ -424,7 +424,7 @@ def test_full_term_replica_group_ranged_updates_under_adversarial_stream_order(e
         grp.step(frames, 0)
         grp.flush_metrics()
         if order is not None:
-            assert used == [2], used
+            assert used and used[0] >= 2, used                   # chain + auxiliary stream (+ the pass streams of a small group, round 5)
         row = []
         for r in range(S):
             st = ads[r].optimizer.state[ads[r].model.module.theta]
