@@ -364,10 +364,14 @@ def test_fused_level_node_matches_three_module_composition():
     assert torch.equal(res[("frame", 0)][1], res[("frame", 1)][1])
     m0, m1 = res[("full", 0)][1], res[("full", 1)][1]
     assert float((m0 - m1).norm() / m0.norm()) < 2e-3          # ReLU-flip noise class, see DESIGN.md 4
-    d0 = res[("full", 0)][0] - res[("full", 1)][0]
+    d0 = (res[("full", 0)][0] - res[("full", 1)][0]).abs()
     # three Adam steps of lr 3e-6: an element whose gradient is rounding noise moves by +-lr whatever its size, so two paths that differ
-    # in summation order can part by up to 2 lr per step on such elements (6.9e-6 measured); the moments above are the real check
-    assert float(d0.abs().max()) < 1.9e-5
+    # in summation order can part by up to 2 lr per step on such elements (6.9e-6 measured) - and ONLY on such elements: where
+    # the two paths' first moments agree in sign and to a quarter of their size the weights must agree to the old, tight bound
+    noise = (torch.sign(m0) != torch.sign(m1)) | ((m0 - m1).abs() > 0.25 * m0.abs())
+    assert float(noise.float().mean()) < 0.02, float(noise.float().mean())
+    assert float(d0[~noise].max()) < 5e-6, float(d0[~noise].max())
+    assert float(d0.max()) < 1.9e-5
 
 
 def test_shared_forwards_are_bit_identical():
