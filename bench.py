@@ -831,7 +831,8 @@ def main():
                 device, "full_default_losses_S32", 10, 3, 1, 1, "the reference's default flags (inner_step 1, teacher + motion + labelled "
                 "exemplars + dynamic-BOA gate decided per sequence) for 32 sequences in lockstep on this GPU: teacher forward, history-frame "
                 "pass and exemplar pass are replica-batched launches; a sequence whose gate has closed leaves the launch set of the "
-                "remaining extra steps", roofline_peak=PEAK_FP32_MFMA_TFLOPS, seqs=32, full_losses=1)
+                "remaining extra steps; GPU_MAX_HW_QUEUES=8 (the level's passes run on streams of their own: +1 % here, +9 % at 5 sequences, s32)",
+                roofline_peak=PEAK_FP32_MFMA_TFLOPS, seqs=32, full_losses=1, env=Q8)
             torch.cuda.empty_cache()
             # the same two configurations with the dynamic loop actually ENTERED: threshold calibrated on this stream
             try:
@@ -842,8 +843,8 @@ def main():
                                                                 cos_sim_threshold=thr, env=Q8)
                 torch.cuda.empty_cache()
                 out["full_default_losses_dynamic_S32"] = sub_record(device, "full_default_losses_dynamic_S32", 8, 2, 1, 1, note + "; 32 sequences in "
-                                                                    "lockstep, the gate decided per sequence", roofline_peak=None, seqs=32, full_losses=1,
-                                                                    cos_sim_threshold=thr)
+                                                                    "lockstep, the gate decided per sequence; GPU_MAX_HW_QUEUES=8 (+6.5 %, s32)", roofline_peak=None,
+                                                                    seqs=32, full_losses=1, cos_sim_threshold=thr, env=Q8)
                 out["full_default_losses_dynamic"]["calibration"] = dtab
             except Exception as e:      # noqa: BLE001
                 out["full_default_losses_dynamic"] = dict(value=None, error=f"{type(e).__name__}: {e}")
