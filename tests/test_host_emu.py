@@ -478,6 +478,28 @@ def test_full_term_parallel_passes_under_adversarial_stream_order(emu_lib, monke
             assert torch.equal(a, b)
 
 
+def test_replica_policy_switches(emu_lib):
+    """native_step.set_replica_policy (what bench.py and the sharded driver call for several sequences per GPU): the replica-aware
+    split policy and the throughput schedule from TP_MIN_SEQUENCES sequences per launch; 'bitexact' leaves the single-sequence policy."""
+    from dynaboa_amd import benchmark as DB, native_step as NS
+
+    def opt(name):
+        v = ctypes.c_int(-1)
+        assert emu_lib.dyb_get_option(name, ctypes.byref(v)) == 0
+        return v.value
+    try:
+        NS.set_replica_policy(True)
+        assert opt(b"rep_split") == 1 and opt(b"tp_min") == NS.TP_MIN_SEQUENCES == 5
+        NS.set_replica_policy(False)
+        assert opt(b"rep_split") == 0
+    finally:
+        emu_lib.dyb_set_option(b"rep_split", 0)
+        emu_lib.dyb_set_option(b"tp_min", 8)
+    assert DB.parser.parse_args([]).replica_policy == "throughput"
+    assert DB.parser.parse_args(["--replica_policy", "bitexact"]).replica_policy == "bitexact"
+    assert opt(b"tp_batch_min") == 8 and opt(b"lat_fold") == 1 and opt(b"tp_fold") == 0 and opt(b"tp_wt") == 1      # round-5 defaults
+
+
 def test_native_stepper_coverage_rules(emu_lib):
     from dynaboa_amd import benchmark as DB, native_step as NS
     assert NS.mode(DB.frame_only_options(inner_step=3)) == "frame" and NS.supported(DB.frame_only_options(inner_step=3)) is None
