@@ -291,7 +291,7 @@ class NativeStepper:
         f = self.frame
         if f >= self.loss_log.shape[1]:
             raise RuntimeError("native stepper: more frames than reset_records() announced")
-        c = lambda t: t.contiguous().float()
+        c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.contiguous().float()      # (no new view objects on the common path)
         keep = [c(batch["image"]), c(batch["smpl_j2d"]), c(batch["pose"]), c(batch["betas"]), batch["gender"].contiguous().long()]
         keep += [c(hist[0]), c(hist[1])] if hist is not None else [None, None]
         keep += [c(exemplars[k]) for k in ("img", "keypoints", "pose", "betas", "pose_3d")] if exemplars is not None else [None] * 5
@@ -332,7 +332,7 @@ class NativeStepper:
         if f >= self.loss_log.shape[1]:
             raise RuntimeError("native stepper: more frames than reset_records() announced")
         S = self.S
-        c = lambda t: t.contiguous().float()
+        c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.contiguous().float()      # (no new view objects on the common path)
         ptrs = (ctypes.c_void_p * (12 * S))()
         keep = []
         for r in getattr(self, "active", range(S)):
