@@ -35,7 +35,8 @@ from .optim import Adam, ema_update
 from .smpl import SMPL
 
 
-def synthetic_bundle(seed: int = 22, identity_pose: bool = True, randomize_norm: bool = False, smpl_seed: int = 0):
+def synthetic_bundle(seed: int = 22, identity_pose: bool = True, randomize_norm: bool = False, smpl_seed: int = 0,
+                     resident_exemplars: bool = False):
     """Everything BaseAdaptor needs, generated from seeds."""
     mp = A.make_smpl_mean_params(identity_pose=identity_pose, seed=3)
     return SimpleNamespace(
@@ -43,8 +44,11 @@ def synthetic_bundle(seed: int = 22, identity_pose: bool = True, randomize_norm:
         checkpoint=A.make_synthetic_checkpoint(seed, mp, randomize_norm=randomize_norm),
         smpl_neutral=A.make_synthetic_smpl(smpl_seed), smpl_male=A.make_synthetic_smpl(smpl_seed + 1),
         smpl_female=A.make_synthetic_smpl(smpl_seed + 2),
-        exemplars=lambda step, n: A.make_exemplars(step, n),
-        exemplars_device=lambda step, n, device: A.make_exemplars_device(step, n, device), dataloader=None, gmm_folder=None)
+        exemplars=lambda step, n: A.make_exemplars_pinned(step, n),
+        # opt-in: exemplars resident on the device and shared by every sequence of a step; off = every retrieval()
+        # uploads its own copy, as the reference does (base_adaptor.py:82-96)
+        exemplars_device=(lambda step, n, device: A.make_exemplars_device(step, n, device)) if resident_exemplars else None,
+        dataloader=None, gmm_folder=None)
 
 
 class BaseAdaptor:
@@ -189,7 +193,7 @@ class BaseAdaptor:
             for it in items[1:]:
                 for k, v in it.items():
                     batch[k] = torch.cat([batch[k], v], dim=0) if torch.is_tensor(v) else batch[k]
-        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
     # ------------------------------------------------------------------ geometry helpers
     def projection(self, cam, s3d, eps=1e-9):

@@ -285,7 +285,7 @@ struct Stepper {
   int par_passes = 1, par_max_replicas = DYB_MAX_REPLICAS;   // measured up to 32 per launch: 16: 290 -> 316, 32: 362 -> 377 frames/s (s30)
   hipStream_t par_stream[2] = {nullptr, nullptr};                                 // history pass | exemplar pass.  (A third stream for the teacher's
   // forward was measured and removed: 75.7 - 76.9 frames/s against 89.4 - 92.3 with two, profiles/r05_sessions.txt s25.)
-  hipEvent_t par_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fork | hist fwd | hist head grads | hist bwd | label term | exemplar bwd
+  hipEvent_t par_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fork | hist fwd | hist head grads | hist bwd | label term | exemplar bwd | error-path tails of the two pass streams
   bool out_in_main = false;        // where the latest final inference lives (dyb_stepper_output): fin, or main after an odd number of shared steps
   int share_dyn_fwd = 1;           // dynamic loop: an extra step's upper level reuses the previous step's final inference as its forward
   int upd_blocks = 0;              // > 0: workgroup cap (all replicas together) of the ranged passes on the auxiliary stream (measured: no effect, 512 .. uncapped)
@@ -465,7 +465,7 @@ extern "C" void dyb_stepper_destroy(void* stepper) {
   if (S->gates.ev[0]) (void)hipEventDestroy(S->gates.ev[0]);
   if (S->gates.ev[1]) (void)hipEventDestroy(S->gates.ev[1]);
   if (S->gates.mid) (void)hipEventDestroy(S->gates.mid);
-  for (int i = 0; i < 6; ++i) if (S->par_ev[i]) (void)hipEventDestroy(S->par_ev[i]);
+  for (int i = 0; i < 8; ++i) if (S->par_ev[i]) (void)hipEventDestroy(S->par_ev[i]);
   for (int i = 0; i < 2; ++i) if (S->par_stream[i]) (void)hipStreamDestroy(S->par_stream[i]);
   delete S;
 }
@@ -911,6 +911,7 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
                             hipStream_t side) {
   const bool metrics = S.metrics != 0;
   DYB_REQUIRE(!metrics || (gt_pose && gt_betas && gender), DYB_ERR_ARG);
+  S.out_in_main = false;                                  // this frame's final inference goes to `fin` (reset at every entry point)
   if (!S.use_side || side == st) side = nullptr;
   const int K = S.inner_step;
   const size_t n = S.n_params;
@@ -1016,6 +1017,19 @@ struct FullCtx {
   float* losslog;       // this frame's rows
   int level_row;
 };
+// A level that forked onto the pass streams and fails before its joins must not return with work still queued there against the
+// stepper's arenas: the caller's stream is ordered behind the CURRENT tails of both pass streams on every early return, so a
+// retry or a free on that stream cannot race them.  Disarmed once the regular joins (par_ev[3] / par_ev[5]) have been issued.
+struct ParTailGuard {
+  hipStream_t st, sB, sC;
+  hipEvent_t eB, eC;
+  bool armed;
+  ~ParTailGuard() {
+    if (!armed) return;
+    if (sB != st && hipEventRecord(eB, sB) == hipSuccess) (void)hipStreamWaitEvent(st, eB, 0);
+    if (sC != st && hipEventRecord(eC, sC) == hipSuccess) (void)hipStreamWaitEvent(st, eC, 0);
+  }
+};
 // one level (reference base_adaptor.py:222-317 lower / upper_level_adaptation) at weights `cur` through pass P: loss terms,
 // log row, and the gradient of the level total w.r.t. `cur` in S.grads
 // have_fwd: P already holds the forward of (cur, this frame's image) - the dynamic loop hands the previous step's final inference on
@@ -1045,13 +1059,14 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   if (par) {
     for (int i = 0; i < 2; ++i)
       if (!S.par_stream[i]) HIPOK(hipStreamCreateWithFlags(&S.par_stream[i], hipStreamNonBlocking));
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
       if (!S.par_ev[i]) HIPOK(hipEventCreateWithFlags(&S.par_ev[i], hipEventDisableTiming));
     sB = S.par_stream[0]; sC = S.par_stream[1];
     HIPOK(hipEventRecord(S.par_ev[0], st));
     if (motion) HIPOK(hipStreamWaitEvent(sB, S.par_ev[0], 0));
     if (label) HIPOK(hipStreamWaitEvent(sC, S.par_ev[0], 0));
   }
+  ParTailGuard tails{st, sB, sC, S.par_ev[6], S.par_ev[7], par};
   if (!have_fwd) RUN(pass_forward(S, P, cur, image, st));
   RUN(pass_frame_head(S, P, kp, st));
   const float* rot = P.acts + S.off_rot;
@@ -1164,6 +1179,7 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
     if (S.lvl_g2) S.lvl_g3 = S.grads3;
     else S.lvl_g2 = S.grads3;
   }
+  tails.armed = false;                                    // both pass streams have been joined above
   return DYB_OK;
 }
 static int adam_and_teacher(Stepper& S, hipStream_t st, hipStream_t aux) {
@@ -1269,6 +1285,7 @@ static int active_set(const Stepper& S, int* idx) {
 // back by it, and it does not take Adam steps the reference would not have taken).
 static int adapt_full_impl(Stepper& S, FullCtx& C, int record_slot, int loss_slot, int* extra, hipStream_t st, hipStream_t aux) {
   const bool metrics = S.metrics != 0;
+  S.out_in_main = false;                                  // (set again below only when a shared-forward step of the dynamic loop ends in `main`)
   DYB_REQUIRE(C.in[IN_IMAGE] && C.in[IN_KP], DYB_ERR_ARG);
   DYB_REQUIRE(!metrics || (C.in[IN_GT_POSE] && C.in[IN_GT_BETAS] && C.in[IN_GENDER]), DYB_ERR_ARG);
   const long long* gender = (const long long*)C.in[IN_GENDER];

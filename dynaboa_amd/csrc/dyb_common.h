@@ -118,6 +118,11 @@ __device__ __forceinline__ T* dyb_rb(T* p, const DybRep& R, int rep) {
   return p;
 }
 // buffer resource over [p, p + bytes) (raw, stride 0; gfx9 data-format word) and a 16-byte load through it
+// component-wise (a select between two float4 objects makes hipcc spill both to scratch and pick by address)
+__device__ __forceinline__ float4 tp_mask4(float4 v, bool ok) {
+  v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+  return v;
+}
 #define TP_OOB 0x80000000u
 typedef unsigned tp_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tp_rsrc(const float* p, size_t bytes) {

@@ -732,7 +732,8 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
       if (addp) {
         float4 a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(addp + (vo[j] != TP_OOB ? vo[j] / 4 : 0));
+        for (int j = 0; j < 4; ++j) a[j] = tp_mask4(*reinterpret_cast<const float4*>(addp + (vo[j] != TP_OOB ? vo[j] / 4 : 0)), vo[j] != TP_OOB);
+        // (pieces past the end stay exact zeros: the GroupNorm statistics below sum all four pieces - ADVICE r5)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w; }
       }
@@ -1637,6 +1638,9 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   }
   if (stats_fusable && s == 2 && switches().tp_fwd_nosplit2.load(std::memory_order_relaxed)) s = 1;
   const size_t per = (size_t)g.slab_rows * g.Ncols, ws_floats = ws ? ws_bytes / sizeof(float) : 0;
+  // the result tiles leave through 32-bit byte offsets into a buffer resource clamped to 2^31 - 1 bytes: a larger slab would alias TP_OOB
+  // and its stores would be dropped silently
+  DYB_REQUIRE(per * sizeof(float) < 0x7fffffffull, DYB_ERR_UNSUPPORTED);
   while (s > 1 && (size_t)s * per > ws_floats) --s;
   g.nsplit = s;
   g.tiles_per_split = dyb_cdiv(g.ktiles, g.nsplit);
@@ -1769,7 +1773,10 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   dim3 grid(dyb_cdiv(g.M, BM), dyb_cdiv(g.Ncols, BN), g.nsplit * R.n);
   // in-kernel split-K fold ("lat_fold": a counter region in scope; fp32 form - its epilogue goes through LDS) and, forward of one
   // image, the output's GroupNorm statistics with the tiles (one record per workgroup tile; what a layer's partial slot holds)
-  const bool lat = !dyb_bf16_current() && (size_t)g.M * g.Ncols * sizeof(float) < 0x7fffffffu && switches().lat_fold.load(std::memory_order_relaxed);
+  // the fp32 epilogue addresses a result matrix / slab through 32-bit byte offsets (TP_OOB = 2^31 marks "past the end"): larger is refused
+  // rather than silently dropped
+  DYB_REQUIRE(dyb_bf16_current() || (size_t)g.M * g.Ncols * sizeof(float) < 0x7fffffffu, DYB_ERR_UNSUPPORTED);
+  const bool lat = !dyb_bf16_current() && switches().lat_fold.load(std::memory_order_relaxed);
   // (not where the caller's next kernel folds the slabs while it reads them anyway: a gradient handed on as raw slabs)
   const bool kfold = split && lat && t_conv_sync.ctr && (long)grid.x * grid.y * R.n <= (long)t_conv_sync.nwords &&
                      !(raw_slabs_out && mode != MODE_FWD);

@@ -252,6 +252,22 @@ class NativeStepper:
         except Exception:      # noqa: BLE001
             pass
 
+    def output(self, which: int, replica: int = 0) -> torch.Tensor:
+        """The last final inference of `replica` as a view of the stepper's workspace (dyb_stepper_output): which = 0 rotmat [B][24][9],
+        1 state [B][160] (shape at 144, cam at 154), 2 vertices [B][6890][3], 3 joints [B][49][3]."""
+        self.lib.dyb_stepper_output.restype = ctypes.c_void_p
+        p = self.lib.dyb_stepper_output(self.h, int(which))
+        if not p:
+            raise RuntimeError("dyb_stepper_output: stepper not bound")
+        shape = {0: (self.B, 24, 9), 1: (self.B, 160), 2: (self.B, 6890, 3), 3: (self.B, 49, 3)}[int(which)]
+        off = int(p) - self.ws.data_ptr() + replica * (self.ws.numel() // self.S)
+        n = 1
+        for d in shape:
+            n *= d
+        if off < 0 or off % 4 or off + 4 * n > self.ws.numel():
+            raise RuntimeError("dyb_stepper_output: pointer outside the workspace")
+        return self.ws[off:off + 4 * n].view(torch.float32).view(shape)
+
     def adapt_frames(self, batches, side_stream=None):
         """One frame per replica (`batches`: list of S batch dicts).  -> (frame index, first record slot)."""
         f = self.frame

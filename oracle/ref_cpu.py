@@ -431,6 +431,7 @@ class Adapter:
             with torch.no_grad():
                 feats = hmr_forward(self._full(self.theta), image, need_feature=True)[3]
             cos = float(F.cosine_similarity(init_feats[12].flatten(), feats[12].flatten(), dim=0, eps=1e-12))
+            rec["gate_cos12"] = [cos]                                  # every check of the gate (reference: self.feat_sims[step][k][12])
             steps = 0
             while 1 - cos > o["cos_sim_threshold"]:
                 steps += 1
@@ -445,6 +446,7 @@ class Adapter:
                 with torch.no_grad():
                     feats = hmr_forward(self._full(self.theta), image, need_feature=True)[3]
                 cos = float(F.cosine_similarity(prev[12].detach().flatten(), feats[12].flatten(), dim=0, eps=1e-12))
+                rec["gate_cos12"].append(cos)
             rec["extra_steps"] = steps
         rec["pred"] = self.predict(self.theta, image)
         self.global_step += 1

@@ -52,3 +52,48 @@ def ckpt_rand():
     from dynaboa_amd import assets
     mp = assets.make_smpl_mean_params(identity_pose=False, seed=3)
     return assets.make_synthetic_checkpoint(22, mp, randomize_norm=True, prefix="")["model"]
+
+
+# ---------------------------------------------------------------------------- fp32 noise floor of the g5 streams
+def tensor_class(name):
+    """(stage, kind) of a parameter: the granularity at which the noise floor is pooled (a single tensor's measured deviation is one
+    draw of a random quantity; its class's largest deviation is a stable statistic)."""
+    top = name.split(".")[0]
+    stage = "stem" if top in ("conv1", "bn1") else top if top.startswith("layer") else "regressor"
+    if top in ("conv1",) or ".conv" in name or "downsample.0" in name:
+        kind = "conv"
+    elif top == "bn1" or ".bn" in name or "downsample.1" in name:
+        kind = "gn_" + name.rsplit(".", 1)[1]
+    else:
+        kind = "fc_" + name.rsplit(".", 1)[1] if "." in name else "fc"
+    return stage, kind
+
+
+NOISE_FACTOR = 3.0        # a bound = NOISE_FACTOR x the class's measured fp32-vs-fp64 floor (VERDICT r5 item 7)
+NOISE_MIN = {"nd": 2e-4, "cos": 2e-5}     # (never tighter than this: the golden's stored norms / slices are themselves one fp32 draw)
+
+
+def noise_bounds(tag, names, factor=NOISE_FACTOR):
+    """Per-tensor bounds for the end-of-stream state of golden g5_<tag>, derived from tests/golden/g5_<tag>_noise.npz
+    (tools/make_noise.py: the reference in fp32 and the oracle in fp32, each against the oracle in fp64 on the same stream).
+    -> {q: {"nd": array, "cos": array}} for q in m, v, d (and t = teacher drift): `nd` bounds the relative deviation of a tensor's
+    norm from the golden's, `cos` is the LOWER bound of a slice cosine.  A tensor's bound is factor x the largest deviation either
+    fp32 run shows over the tensor's class (stage x kind)."""
+    z = golden(f"g5_{tag}_noise.npz")
+    znames = [str(x) for x in z["names"]]
+    idx = {n: i for i, n in enumerate(znames)}
+    cls = [tensor_class(n) for n in znames]
+    out = {}
+    for q in ("m", "v", "d", "t"):
+        if f"{q}_nd_ref" not in z.files:
+            continue
+        nd = np.maximum(z[f"{q}_nd_ref"], z[f"{q}_nd_or"])
+        cs = 1.0 - np.minimum(z[f"{q}_cos_ref"], z[f"{q}_cos_or"])
+        cmax_nd, cmax_cs = {}, {}
+        for i, c in enumerate(cls):
+            cmax_nd[c] = max(cmax_nd.get(c, 0.0), float(nd[i]))
+            cmax_cs[c] = max(cmax_cs.get(c, 0.0), float(cs[i]))
+        out[q] = dict(nd=np.array([max(NOISE_MIN["nd"], factor * cmax_nd[tensor_class(n)]) for n in names]),
+                      cos=np.array([1.0 - max(NOISE_MIN["cos"], factor * cmax_cs[tensor_class(n)]) for n in names]),
+                      floor_nd=np.array([nd[idx[n]] for n in names]))
+    return out

@@ -98,7 +98,8 @@ def test_headline_schedule_stream_matches_reference_and_single_runs(S, headline_
         assert abs(float(np.mean(fl[0]["mpjpe"][step])) - g["mpjpe"][step]) < 1e-3 * g["mpjpe"][step]
         assert abs(float(np.mean(fl[0]["pampjpe"][step])) - g["pampjpe"][step]) < 2e-3 * g["pampjpe"][step]
         assert abs(float(np.ravel(fl[0]["pve"])[step]) - g["pve"][step]) < 1e-3 * g["pve"][step]
-    assert_final_state_matches_golden(ads[0], g, theta0, {})
+    # (the throughput schedule sums in another order than the reference AND than a sequence alone: same class-pooled fp32 floor)
+    assert_final_state_matches_golden(ads[0], g, theta0, {}, tag="fo_inner3_frameonly")
     # every replica against itself adapted alone: summation order differs (replica-aware split, chunked GroupNorm), arithmetic not
     for r in range(S):
         a = ads[r]
@@ -175,3 +176,34 @@ def test_ranged_weight_updates_beside_the_forward_change_nothing(headline_switch
         del grp, ads
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """`bench.py --gpus 2` end to end on this ONE-GPU box (DYB_BENCH_SMOKE_ONE_GPU=1: both ranks on cuda:0, gloo instead of
+    RCCL, which refuses two ranks on one device) - the self-spawn through torch.distributed.run, rank / world from the environment,
+    barrier + max-over-ranks timing, the ragged end-of-run gather of the per-frame errors (sharding.gather_frame_metrics) and the
+    3DPW operating point at ceil(37 / N) sequences per GPU.  A functional check of the N > 1 path the driver runs on an 8-GPU node,
+    never a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DYB_BENCH_SMOKE_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    seqs, steps = 3, 2
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--seqs", str(seqs),
+                          "--no_cpu_baseline", "--no_roofline", "--percentile_frames", "0"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["scaling"] == "weak"
+    cfg = rec["config"]
+    assert cfg["gathered_frames"] == steps * seqs * 2, cfg
+    assert cfg["gathered_frames_per_rank"] == [steps * seqs, steps * seqs], cfg
+    assert abs(rec["value"] - steps * seqs * 2 / (rec["ms_per_step"] * 1e-3 * steps)) < 1e-6 * rec["value"]
+    op = rec["pw3d_operating_point"]
+    assert op.get("value") and op["sequences_per_gpu"] == 19, op     # ceil(37 / 2)

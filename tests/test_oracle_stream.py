@@ -16,6 +16,9 @@ STREAMS = {
     "fo_inner1_frameonly_identity": (dict(FRAME_ONLY, inner_step=1), True),
     "fo_inner1_full": (dict(inner_step=1, interval=2, optim_steps=2), False),
     "fo_inner1_full_forced": (dict(inner_step=1, interval=2, optim_steps=2, cos_sim_threshold=-1.0), False),
+    # the dynamic-BOA loop leaving BY CONVERGENCE at the literal defaults (interval 5, optim_steps 7; threshold chosen on the reference
+    # run, stored in the golden): frame 0 takes 6 extra steps, the gate stays closed afterwards (tools/make_golden.py g5_gated)
+    "fo_inner1_full_gated": (dict(inner_step=1), False),
 }
 SLICE_PARAMS = ["conv1.weight", "layer1.0.conv2.weight", "layer2.0.conv2.weight", "layer3.5.conv1.weight",
                 "layer4.0.conv2.weight", "layer4.2.bn3.weight", "fc1.weight", "fc2.weight",
@@ -36,11 +39,19 @@ def build(opts, identity_pose, gmm_t, smpl_tabs):
 def test_stream(tag, gmm_t, smpl_tabs):
     g = golden(f"g5_{tag}.npz")
     opts, ident = STREAMS[tag]
+    if "gate_threshold" in g.files and "gated" in tag:
+        opts = dict(opts, cos_sim_threshold=float(g["gate_threshold"]))
     ad, sd0 = build(opts, ident, gmm_t, smpl_tabs)
     n = int(g["nframes"])
     torch.set_num_threads(8)
     for step in range(n):
         rec = ad.adapt_frame(assets.make_frame(step, 1, seed=22))
+        if "gated" in tag:
+            # every check of the gate: same count, and 1 - cos within a quarter of the reference run's own decision margin
+            assert len(rec["gate_cos12"]) == int(g["gate_checks"][step]), (step, rec["gate_cos12"])
+            thr, margin = float(g["gate_threshold"]), float(g["gate_margin"])
+            for k, c in enumerate(rec["gate_cos12"]):
+                assert abs((1.0 - c) - float(g["gate_1mcos12"][step, k])) < 0.25 * margin * thr, (step, k, 1.0 - c)
         # the reference's logged 'ul/unlabelloss' aliases the in-place-accumulated TOTAL upper loss
         assert abs(ad.log["ul/total"] - g["upper_loss"][step]) < 2e-5 * abs(g["upper_loss"][step])
         assert rec["extra_steps"] == int(g["extra_steps"][step])

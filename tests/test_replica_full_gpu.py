@@ -178,3 +178,70 @@ def test_parallel_passes_of_one_sequence_are_bit_identical_to_the_sequential_lev
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_forward_shared_across_dynamic_loop_steps_is_bit_identical_to_the_literal_two_forwards(monkeypatch):
+    """an extra step of the dynamic-BOA loop reuses the previous step's final inference as its upper level's forward
+    (share_dyn_fwd 1, the default) - against the literal schedule (0: the upper level runs its own forward,
+    dynaboa_benchmark.py:170-181) weights, Adam moments, teacher, step counts and metrics must agree bit for bit, and
+    dyb_stepper_output must hand out the LAST final inference whichever arena it ended in (odd and even step counts occur)."""
+    frames = _frames(1, 4)[0]
+    outs = []
+    for share in ("0", "1"):
+        monkeypatch.setenv("DYB_SHARE_DYN_FWD", share)      # read when the stepper is created
+        ad = _mk(0, dict(FULL, cos_sim_threshold=1.0e-4, optim_steps=3))
+        res = ad.excute(frames, nframes=4)
+        assert ad._native is not None and ad._native.full
+        st = _state(ad)
+        final = [ad._native.output(w).clone() for w in range(4)] if hasattr(ad._native, "output") else []
+        outs.append([st["theta"], st["m"], st["v"], st["teacher"], torch.tensor(st["steps"]),
+                     torch.tensor(np.ravel(np.array(res["mpjpe"], np.float64)))] + final)
+        del ad
+    steps = outs[0][4]
+    assert int(steps.max()) >= 1, steps
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["fo_inner1_full_gated", "fo_inner1_full_gated_b"])
+def test_gated_reference_stream_as_replica_0_of_a_group_of_8(tag):
+    """VERDICT r5 item 1, replica form: eight sequences with the reference's literal default flags in lockstep under the drivers'
+    replica policy (rep_split 1: every launch on the throughput schedule, the gate decided per sequence, a converged sequence leaving
+    the launch set).  Replica 0 carries the checkpoint and frames of the reference-generated golden `g5_<tag>` (tools/make_golden.py
+    g5_gated: the dynamic-BOA loop leaves by convergence / never opens / runs into the cut-off, every decision >= gate_margin away
+    from the threshold) and must reproduce the reference's step counts, every check's cosines, and its final Adam state - with a
+    different summation order than the reference's and than a sequence alone."""
+    from conftest import golden
+    from test_adaptation_gpu import assert_final_state_matches_golden, assert_gate_matches_golden
+    from dynaboa_amd import assets, native_step as NS, _lib
+    g = golden(f"g5_{tag}.npz")
+    S, NF = 8, int(g["nframes"])
+    opts = dict(inner_step=1, cos_sim_threshold=float(g["gate_threshold"]))
+    frames = [[{k: v.to("cuda:0") for k, v in assets.make_frame((100 * r + s) if r else s, 1, seed=22).items()} for s in range(NF)]
+              for r in range(S)]
+    lib = _lib.load()
+    NS.set_replica_policy(True)
+    try:
+        ads = [_mk(r, opts) for r in range(S)]
+        assert ads[0].options.interval == 5 and ads[0].options.optim_steps == 7
+        theta0 = ads[0].model.module.theta.detach().clone()
+        grp = NS.ReplicaGroup(ads, NF)
+        assert grp.stepper.full and grp.stepper.S == S
+        worst = 0.0
+        for s in range(NF):
+            grp.step([frames[r][s] for r in range(S)], s)
+            worst = max(worst, assert_gate_matches_golden(ads[0], g, s))
+            up = float(ads[0].fit_losses["ul/total"])
+            assert abs(up - g["upper_loss"][s]) < 1e-4 * abs(g["upper_loss"][s]), (s, up, g["upper_loss"][s])
+        fl = grp.flush_metrics()
+    finally:
+        lib.dyb_set_option(b"rep_split", 0)
+        lib.dyb_set_option(b"tp_min", 8)
+    print("gate %s, replica 0 of 8: worst |d(1 - cos12)| / threshold %.2e (margin %.2e)" % (tag, worst, float(g["gate_margin"])))
+    steps = [int(x) for x in g["extra_steps"]]
+    assert list(ads[0].optim_step_record) == steps
+    assert len({tuple(a.optim_step_record) for a in ads}) > 1           # the sequences of the group took different paths
+    for s in range(NF):
+        assert abs(float(np.mean(fl[0]["mpjpe"][s])) - g["mpjpe"][s]) < 1e-3 * g["mpjpe"][s]
+        assert abs(float(np.mean(fl[0]["pampjpe"][s])) - g["pampjpe"][s]) < 2e-3 * g["pampjpe"][s]
+    assert_final_state_matches_golden(ads[0], g, theta0, dict(inner_step=1), tag=tag)
