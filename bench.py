@@ -253,6 +253,10 @@ class Runner:
         self.G = groups if (seqs > 1 and groups > 1 and seqs % groups == 0) else 1
         mk = lambda r, s: {k: v.to(device) for k, v in assets.make_frame(rank * 100_000 + r * 7_000 + frame_base + s, batch, seed=22).items()}
         self.frames = [[mk(r, s) for s in range(nframes)] for r in range(seqs)]      # resident in HBM before any clock starts
+        if (kw.get("full_losses") or kw.get("retrieval")) and not kw.get("resident_exemplars"):
+            # the exemplar "dataset" of the synthetic bundle lives in pinned host memory before the clock starts (the reference's sits in
+            # host RAM / on disk); every sequence's retrieval() still uploads its own copy inside the clock (base_adaptor.py:82-96)
+            assets.pregenerate_exemplars(range(nframes), int(kw.get("sample_num", 1)))
         if seqs == 1:
             from dynaboa_amd import _lib
             _lib.load().dyb_set_option(b"rep_split", 0)

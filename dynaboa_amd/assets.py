@@ -259,24 +259,36 @@ def make_exemplars_device(step: int, sample_num: int, device, seed: int = 22, ke
 
 
 _EX_HOST_CACHE: Dict[tuple, Dict[str, torch.Tensor]] = {}
+EX_HOST_CACHE_BYTES = 512 << 20     # pinned host memory the exemplar cache may hold (oldest entries leave first)
 
 
-def make_exemplars_pinned(step: int, sample_num: int, seed: int = 22, keep_steps: int = 4) -> Dict[str, torch.Tensor]:
-    """`make_exemplars` kept in (pinned, where CUDA is up) HOST memory for the last few steps: the stand-in for the reference's
-    exemplar dataset living in host RAM.  Every caller still pays its own host-to-device upload (what `retrieval()` does per
-    sequence and level); only the synthetic generation - which has no counterpart in the reference - is shared."""
-    fam = (int(sample_num), int(seed))
-    key = (int(step),) + fam
+def make_exemplars_pinned(step: int, sample_num: int, seed: int = 22, max_bytes: int = EX_HOST_CACHE_BYTES) -> Dict[str, torch.Tensor]:
+    """`make_exemplars` kept in (pinned, where CUDA is up) HOST memory: the stand-in for the reference's exemplar dataset living in host RAM
+    (base_adaptor.py:55,82-96).  Every caller still pays its own host-to-device upload per retrieval (what the reference does per sequence
+    and level); only the synthetic generation - which has no counterpart in the reference - is cached, and `pregenerate_exemplars` moves it
+    out of a timed region altogether.  Pinning goes through torch's caching host allocator (an evicted entry's block is recycled, and the
+    allocator itself keeps a block alive while an asynchronous copy from it is in flight).  Bounded by `max_bytes`."""
+    key = (int(step), int(sample_num), int(seed))
     hit = _EX_HOST_CACHE.get(key)
     if hit is None:
         ex = make_exemplars(step, sample_num, seed)
         if torch.cuda.is_available():
             ex = {k: v.pin_memory() for k, v in ex.items()}
         hit = _EX_HOST_CACHE[key] = ex
-        mine = [k for k in _EX_HOST_CACHE if k[1:] == fam]
-        for k in mine[:max(0, len(mine) - keep_steps)]:
-            del _EX_HOST_CACHE[k]
+        size = lambda e: sum(v.numel() * v.element_size() for v in e.values())
+        total = sum(size(e) for e in _EX_HOST_CACHE.values())
+        for k in list(_EX_HOST_CACHE):
+            if total <= max_bytes or k == key:
+                break
+            total -= size(_EX_HOST_CACHE.pop(k))
     return dict(hit)
+
+
+def pregenerate_exemplars(steps, sample_num: int, seed: int = 22) -> None:
+    """Fill the pinned host cache for `steps` ahead of a timed loop: generation + pinning then cost nothing inside it, the per-retrieval
+    upload still does."""
+    for s in steps:
+        make_exemplars_pinned(int(s), sample_num, seed)
 
 
 def make_exemplars(step: int, sample_num: int = 1, seed: int = 22) -> Dict[str, torch.Tensor]:

@@ -19,12 +19,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "dyb_common.h"
 
@@ -32,6 +34,8 @@ extern "C" {
 size_t dyb_hmr_param_floats(const void*);
 size_t dyb_hmr_act_floats(const void*);
 size_t dyb_hmr_workspace_bytes(const void*);
+int dyb_hmr_forward_train(void*, const float*, const float*, const float*, int, float*, void*, size_t, unsigned long long, unsigned long long, float,
+                          hipStream_t);
 long long dyb_hmr_act_offset_rotmat(const void*);
 long long dyb_hmr_act_offset_state(const void*);
 size_t dyb_lbs_saved_floats(int);
@@ -60,6 +64,7 @@ int dyb_adam_step_rep(float*, const float*, float*, float*, float, float, const 
 int dyb_adam_step_rep3(float*, const float*, const float*, const float*, float*, float*, float, float, const float*, const float*, float, size_t,
                        hipStream_t);
 int dyb_fastweight_update3(const float*, const float*, const float*, const float*, float*, float, size_t, hipStream_t);
+int dyb_fastweight_update_segs(const float*, const float*, float*, float, const DybFwSegs&, hipStream_t);       // optim.hip
 
 #define STATE_LD 160
 #define NV 6890
@@ -160,24 +165,28 @@ __global__ __launch_bounds__(1024) void feat_cos_kernel(const float* __restrict_
   DYB_REP_PROLOGUE(Rp);
   DYB_RB(Rp, A); DYB_RB(Rp, Bp); DYB_RB(Rp, out_dev);
   if (out_host) out_host += 16 * dyb_rep;             // pinned host memory: 16 floats per physical replica
-  __shared__ float sm[16][3];
+  // The three sums are accumulated in double (round 6): 1 - cos of feature 12 is ~1e-4 and the gate compares it with a threshold to a
+  // few per cent, i.e. cos must be good to ~1e-6 - an fp32 sum over 2e5 ... 8e5 elements is not (torch's own fp32 evaluation returns
+  // 1.000017 for feature 0: tests compare against the float64 evaluation of the reference's features, golden key gate_cos64)
+  __shared__ double sm[16][3];
   const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* a = A + fa.off[f];
   const float* b = Bp + fa.off[f];
   const long long n = (long long)fa.rows[f] * fa.cols[f];
-  float ab = 0.f, aa = 0.f, bb = 0.f;
+  double ab = 0.0, aa = 0.0, bb = 0.0;
   for (long long i = t; i < n; i += 1024) {
     const long long r = i / fa.cols[f], c = i - r * fa.cols[f];
-    const float x = a[r * fa.ld[f] + c], y = b[r * fa.ld[f] + c];
+    const double x = (double)a[r * fa.ld[f] + c], y = (double)b[r * fa.ld[f] + c];
     ab += x * y; aa += x * x; bb += y * y;
   }
-  ab = dyb_wave_sum(ab); aa = dyb_wave_sum(aa); bb = dyb_wave_sum(bb);
+  for (int m = 32; m >= 1; m >>= 1) { ab += __shfl_xor(ab, m); aa += __shfl_xor(aa, m); bb += __shfl_xor(bb, m); }
   if (lane == 0) { sm[wave][0] = ab; sm[wave][1] = aa; sm[wave][2] = bb; }
   __syncthreads();
   if (t == 0) {
-    float x = 0.f, y = 0.f, z = 0.f;
+    double x = 0.0, y = 0.0, z = 0.0;
     for (int w = 0; w < 16; ++w) { x += sm[w][0]; y += sm[w][1]; z += sm[w][2]; }
-    const float cs = x / sqrtf(fmaxf(y * z, eps * eps));     // torch cosine_similarity: x.y / sqrt(clamp(|x|^2 |y|^2, eps^2))
+    // torch cosine_similarity: x.y / (max(|x|, eps) max(|y|, eps)), rounded to fp32 once
+    const float cs = (float)(x / (fmax(sqrt(y), (double)eps) * fmax(sqrt(z), (double)eps)));
     out_dev[f] = cs;
     if (out_host) {
       out_host[f] = cs;
@@ -232,6 +241,13 @@ struct Stepper {
       dynamic = 1, optim_steps = 7;
   double teacher_w = 0.1, motion_w = 0.8, label_w = 0.1, alpha = 0.1, cos_thr = 3.1e-4;
   float* teacher = nullptr;           // teacher parameter arena (caller's)
+  // train-mode teacher (the reference never calls teacher.eval(): base_adaptor.py:151-158 - its teacher forwards run with live
+  // nn.Dropout(0.5) after fc1 / fc2, model/hmr.py:84,86): every teacher forward of a frame draws the masks of (drop_seed, drop_off + k),
+  // k = teacher forwards issued since "drop_offset" was set - the same counter-based keys dynaboa_amd.hmr hands the autograd path
+  int teacher_train = 0;
+  unsigned long long drop_seed = 0, drop_off = 0;
+  long long drop_used = 0;
+  double drop_p = 0.5;
   volatile float* gate_host = nullptr;   // 16 floats of device-visible pinned host memory (caller's): 15 cosines + sequence number
   float* gate_log = nullptr;          // device: [loss_capacity][1 + optim_steps][16] cosines of every gate evaluation
   float* feat5_out = nullptr;         // [B][2048] the level's pooled feature for the retrieval callback
@@ -272,6 +288,14 @@ struct Stepper {
   bool bound = false, fresh = true;
   Pass main{}, fin{};
   float *theta_fast = nullptr, *grads = nullptr;
+  // "fuse_fast" (round 6; frame-loss path): a lower level's unsplit throughput-form weight gradients write theta_next = theta_cur - fastlr * g
+  // straight from their accumulators (DybWgradUpdateScope, igemm_conv.hip) - those spans never see a gradient in HBM nor the streaming
+  // fast-weight pass, which covers what is left (fused_spans -> upd_spans).  theta_cur and theta_next must then be different buffers (a
+  // layer's data gradient reads theta_cur on the chain while its weight gradient writes on the auxiliary stream): the levels ping-pong
+  // between theta_fast and theta_fast2.
+  float* theta_fast2 = nullptr;
+  int fuse_fast = 1;
+  std::vector<DybSpan> fused_spans, upd_spans;
   float *gt_rot = nullptr, *gt_verts[3] = {}, *gt_joints = nullptr, *gt_saved = nullptr, *gt17[2] = {};
   DybEvents* ev = nullptr;
   hipEvent_t e_theta = nullptr, e_side = nullptr, e_gt = nullptr;
@@ -380,6 +404,7 @@ static size_t carve(Stepper& S, char* base) {
   pass(S.main, true);
   pass(S.fin, false);
   S.theta_fast = take_f(S.n_params);
+  S.theta_fast2 = S.fuse_fast ? take_f(S.n_params) : nullptr;
   S.grads = take_f(S.n_params);
   S.gt_rot = take_f(B * 24 * 9);
   for (int i = 0; i < 3; ++i) S.gt_verts[i] = take_f(B * NV * 3);
@@ -438,6 +463,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   if (const char* e = getenv("DYB_UPD_BLOCKS")) S->upd_blocks = atoi(e);
   if (const char* e = getenv("DYB_SHARE_DYN_FWD")) S->share_dyn_fwd = atoi(e);
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
+  if (const char* e = getenv("DYB_FUSE_FAST")) S->fuse_fast = atoi(e);
   if (const char* e = getenv("DYB_PAR_PASSES")) S->par_passes = atoi(e);
   if (const char* e = getenv("DYB_PAR_MAX_REPLICAS")) S->par_max_replicas = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
@@ -486,6 +512,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "par_passes") S->par_passes = (int)v;
   else if (k == "par_max_replicas") S->par_max_replicas = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
+  else if (k == "fuse_fast") { DYB_REQUIRE(!S->bound, DYB_ERR_ARG); S->fuse_fast = (int)v; }
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -501,6 +528,9 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "temporal_lower") S->temporal_lower = (int)v;
   else if (k == "temporal_upper") S->temporal_upper = (int)v;
   else if (k == "use_teacher") S->use_teacher = (int)v;
+  else if (k == "teacher_train") S->teacher_train = (int)v;
+  else if (k == "drop_seed") S->drop_seed = (unsigned long long)v;
+  else if (k == "drop_offset") { S->drop_off = (unsigned long long)v; S->drop_used = 0; }
   else if (k == "use_motion") S->use_motion = (int)v;
   else if (k == "interval") S->interval = (int)v;
   else if (k == "mix_lower") S->mix_lower = (int)v;
@@ -530,6 +560,7 @@ extern "C" int dyb_stepper_set_f(void* stepper, const char* key, double v) {
   else if (k == "shape_prior_weight") S->wshape = v;
   else if (k == "pose_prior_weight") S->wpose = v;
   else if (k == "teacherloss_weight") S->teacher_w = v;
+  else if (k == "drop_p") { DYB_REQUIRE(v >= 0.0 && v < 1.0, DYB_ERR_ARG); S->drop_p = v; }
   else if (k == "motionloss_weight") S->motion_w = v;
   else if (k == "labelloss_weight") S->label_w = v;
   else if (k == "alpha") S->alpha = v;
@@ -587,6 +618,7 @@ extern "C" long long dyb_stepper_get_i(const void* stepper, const char* key) {
     const int r = atoi(k.c_str() + 10);
     return (r >= 0 && r < S->nrep) ? S->adam_t_rep[r] : -1;
   }
+  if (k == "drop_used") return S->drop_used;
   if (k == "record_floats") return (long long)a64((size_t)S->B * 85 + 1);
   if (k == "loss_floats") return (S->full ? 16 : 4) * (long long)(S->inner_step + 1 + (S->full && S->dynamic ? S->optim_steps : 0));
   if (k == "slots_per_frame") return (S->eval_lower ? S->inner_step : 0) + 1 + (S->full && S->dynamic ? S->optim_steps : 0);
@@ -813,6 +845,39 @@ static void side_shutdown(Stepper& S) {
   delete I;
   S.issuer = nullptr;
 }
+// out[lo, hi) = p - fastlr * (grads [+ g2 + g3]) minus the spans the level's weight gradients updated themselves (S.upd_spans, sorted)
+static int fastweight_range(Stepper& S, const float* p, float* out, const float* g2, const float* g3, size_t lo, size_t hi, hipStream_t s) {
+  bool any = false;
+  for (const DybSpan& sp : S.upd_spans)
+    if (sp.off < hi && sp.off + sp.n > lo) { any = true; break; }
+  if (!any)
+    return dyb_fastweight_update3(p + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, out + lo, (float)S.fastlr, hi - lo, s);
+  DYB_REQUIRE(!g2 && !g3 && lo % 4 == 0 && hi % 4 == 0, DYB_ERR_UNSUPPORTED);     // (the fused form exists for single-pass levels only)
+  DybFwSegs t{};
+  auto flush = [&]() -> int {
+    if (t.n == 0) return DYB_OK;
+    const int rc = dyb_fastweight_update_segs(p, S.grads, out, (float)S.fastlr, t, s);
+    t.n = 0;
+    return rc;
+  };
+  auto add = [&](size_t a, size_t b) -> int {
+    if (a >= b) return DYB_OK;
+    DYB_REQUIRE(a % 4 == 0 && b % 4 == 0 && (b - a) / 4 < 0xffffffffull && a / 4 < 0xffffffffull, DYB_ERR_UNSUPPORTED);
+    if (t.n == DYB_FW_MAX_SEGS) RUN(flush());
+    t.start4[t.n] = (unsigned)(a / 4); t.count4[t.n] = (unsigned)((b - a) / 4); ++t.n;
+    return DYB_OK;
+  };
+  size_t at = lo;
+  for (const DybSpan& sp : S.upd_spans) {
+    if (sp.off + sp.n <= at) continue;
+    if (sp.off >= hi) break;
+    DYB_REQUIRE(sp.off >= lo && sp.off + sp.n <= hi, DYB_ERR_UNSUPPORTED);     // a tensor never straddles a range boundary
+    RUN(add(at, sp.off));
+    at = sp.off + sp.n;
+  }
+  RUN(add(at, hi));
+  return flush();
+}
 // Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
 // the deferred last range of a ranged weight update (see weight_update): issued from inside the consuming forward at layer3
 static int late_update(void* user) {
@@ -828,7 +893,7 @@ static int late_update(void* user) {
                            (float)S.eps, n, L.aux));
     if (L.ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
   } else {
-    RUN(dyb_fastweight_update3(L.p + lo, S.grads + lo, g2, g3, L.out + lo, (float)S.fastlr, n, L.aux));
+    RUN(fastweight_range(S, L.p, L.out, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, lo, lo + n, L.aux));
   }
   HIPOK(hipEventRecord(S.gates.ev[1], L.aux));
   S.gates.late = nullptr;
@@ -846,6 +911,13 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   const DybRep& R = dyb_rep_current();
   const float *g2 = S.lvl_g2, *g3 = S.lvl_g3;        // further gradient arenas of the level just differentiated (full term set), consumed here
   S.lvl_g2 = S.lvl_g3 = nullptr;
+  // the spans this level's weight gradients turned into fast weights themselves ("fuse_fast"): taken over, sorted, for this update only
+  S.upd_spans.clear();
+  if (!adam) {
+    S.upd_spans.swap(S.fused_spans);
+    std::sort(S.upd_spans.begin(), S.upd_spans.end(), [](const DybSpan& a, const DybSpan& b) { return a.off < b.off; });
+  }
+  S.fused_spans.clear();
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
   if (adam) {
     for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
@@ -865,7 +937,7 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
       if (ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
       return DYB_OK;
     }
-    return dyb_fastweight_update3(p + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, out + lo, (float)S.fastlr, hi - lo, s);
+    return fastweight_range(S, p, out, g2, g3, lo, hi, s);
   };
   const bool ranged = S.upd_overlap && S.nrep > 1 && aux && aux != st && S.grp_bounds[0] > 0 && S.grp_bounds[1] > S.grp_bounds[0] &&
                       S.grp_bounds[1] < S.n_params;
@@ -958,8 +1030,14 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
         RUN(record_metrics(S, S.main, gender, slot++, st));
       }
     }
+    // the next level's weights: the other fast buffer when the weight gradients may write them while data gradients still read `cur`
+    float* nxt = (S.fuse_fast && S.theta_fast2 && cur == S.theta_fast) ? S.theta_fast2 : S.theta_fast;
     {
       HostTimer t(S.h_bwd);
+      S.fused_spans.clear();
+      DybWgradUpdateScope fuse((i < K && S.fuse_fast && S.theta_fast2)
+                                   ? DybWgradUpdate{S.grads, n * sizeof(float), cur, nxt, (float)S.fastlr, &S.fused_spans}
+                                   : DybWgradUpdate{nullptr, 0, nullptr, nullptr, 0.f, nullptr});
       RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
     }
     if (i == 0 && side) {
@@ -968,8 +1046,8 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     }
     if (i < K) {
       HostTimer t(S.h_update);
-      RUN(weight_update(S, false, cur, S.theta_fast, st, aux));
-      cur = S.theta_fast;
+      RUN(weight_update(S, false, cur, nxt, st, aux));
+      cur = nxt;
     }
   }
   HostTimer t_tail(S.h_tail);
@@ -1101,7 +1179,18 @@ static int full_level(Stepper& S, FullCtx& C, Pass& P, const float* cur, bool up
   bool ext = false;
   if (teacher) {
     // teacher forward (no gradient): reference base_adaptor.py:324-329
-    RUN(pass_forward(S, S.teach, S.teacher, image, st));
+    if (S.teacher_train) {
+      // (by now the chain's own forward has consumed the gates of a ranged update: the teacher's ranges are complete on `st`)
+      DYB_REQUIRE(!S.gates_pending, DYB_ERR_LAUNCH);
+      RUN(dyb_hmr_forward_train(S.plan, S.teacher, image, S.init_state, S.n_iter, S.teach.acts, S.teach.ws, S.ws_bytes, S.drop_seed,
+                                S.drop_off + (unsigned long long)S.drop_used, (float)S.drop_p, st));
+      ++S.drop_used;
+      const float* tstate = S.teach.acts + S.off_state;
+      RUN(dyb_lbs_fwd(S.smpl_f[0], S.smpl_i[0], tstate + 144, STATE_LD, S.teach.acts + S.off_rot, S.teach.verts, S.teach.joints,
+                      S.teach.saved, S.B, st));
+    } else {
+      RUN(pass_forward(S, S.teach, S.teacher, image, st));
+    }
     const float* ts = S.teach.acts + S.off_state;
     RUN(dyb_aux_loss_terms(0, B, 0, (float)S.teacher_w, rot, state + 144, STATE_LD, state + 154, STATE_LD, P.joints,
                            S.teach.acts + S.off_rot, ts + 144, STATE_LD, ts + 154, STATE_LD, S.teach.joints, nullptr, nullptr, nullptr,

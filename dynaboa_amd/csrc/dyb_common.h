@@ -174,6 +174,30 @@ struct DybConvSync {
   unsigned* ctr;
   int nwords;
 };
+// weight-update scope (igemm_conv.hip "fuse_fast"): see DybWgradUpdateScope's definition there
+struct DybSpan {
+  size_t off, n;         // floats, relative to the gradient arena
+};
+struct DybWgradUpdate {
+  const float* grads;    // gradient arena the weight gradients would be written into (replica 0's copy)
+  size_t bytes;
+  const float* p_cur;    // current weights (same layout)
+  float* p_next;         // where p_cur - lr * g goes
+  float lr;
+  std::vector<DybSpan>* spans;   // fused spans are appended here (may be NULL)
+};
+// segment list of a streaming fast-weight launch (optim.hip dyb_fastweight_update_segs): float4 units relative to the arena base
+#define DYB_FW_MAX_SEGS 64
+struct DybFwSegs {
+  unsigned n;
+  unsigned blk[DYB_FW_MAX_SEGS + 1];       // filled by the launcher
+  unsigned start4[DYB_FW_MAX_SEGS], count4[DYB_FW_MAX_SEGS];
+};
+struct DybWgradUpdateScope {
+  DybWgradUpdate saved;
+  explicit DybWgradUpdateScope(const DybWgradUpdate& u);
+  ~DybWgradUpdateScope();
+};
 struct DybConvSyncScope {
   DybConvSync saved;
   DybConvSyncScope(unsigned* ctr, int nwords);

@@ -53,6 +53,9 @@ struct IgemmArgs {
   const float* B;        // fwd: w      dgrad: w      wgrad: dy
   float* out;            // result, or slab base when nsplit > 1
   const float* addend;   // optional, only honoured when nsplit == 1 (out = acc + addend)
+  float out_scale;       // throughput form, nsplit == 1 with an addend: out = addend + out_scale * acc (1: the plain sum).  A weight gradient
+                         // with addend = the layer's current weights and out_scale = -fastlr writes the MAML fast weights p - fastlr * g straight
+                         // from the accumulators ("fuse_fast", DybWgradUpdateScope): the gradient never travels to HBM and back
   int N, H, W, C;        // input activation geometry
   int K;                 // Cout
   int R, S, stride, pad;
@@ -1245,6 +1248,26 @@ DybRepScope::~DybRepScope() { t_rep = saved; }
 // leave slabs as before.  The words must be zero when the first launch uses them; every launch leaves them zero.  One word per
 // (replica slot of the launch, tile): the region is NOT replicated - a pointer into replica 0's workspace serves every replica.
 static thread_local DybConvSync t_conv_sync = {nullptr, 0};
+// Weight-update scope of the calling thread (round 6, "fuse_fast"): while one is open, a throughput-form WEIGHT GRADIENT that (a) would
+// write its result into [grads, grads + bytes), (b) runs unsplit (nsplit == 1: the accumulators hold the finished gradient tile) leaves
+// p_next[off] = p_cur[off] - lr * g instead of g - the fast-weight step of learn2learn's MAML.adapt (p' = p - lr * dL/dp; call sites
+// reference dynaboa_benchmark.py:136,140) fused into the epilogue: one read of the current weights and one write of the new ones instead
+// of writing g and a streaming pass reading p and g and writing p'.  The span is appended to `spans` so that the caller's streaming
+// pass can leave it out.  First order only (the inner gradients have no other reader).
+static thread_local DybWgradUpdate t_wupd = {nullptr, 0, nullptr, nullptr, 0.f, nullptr};
+DybWgradUpdateScope::DybWgradUpdateScope(const DybWgradUpdate& u) : saved(t_wupd) { t_wupd = u; }
+DybWgradUpdateScope::~DybWgradUpdateScope() { t_wupd = saved; }
+static std::vector<DybSpan> t_debug_spans;
+// tests / lab: a scope for the calling thread's plain weight-gradient calls until reset with grads = NULL; dyb_debug_wgrad_update_spans
+// reports how many launches took the fused form since the scope was set
+extern "C" int dyb_debug_set_wgrad_update(const float* grads, size_t bytes, const float* p_cur, float* p_next, float lr) {
+  t_debug_spans.clear();
+  if (!grads) { t_wupd = DybWgradUpdate{nullptr, 0, nullptr, nullptr, 0.f, nullptr}; return DYB_OK; }
+  DYB_REQUIRE(bytes && p_cur && p_next, DYB_ERR_ARG);
+  t_wupd = DybWgradUpdate{grads, bytes, p_cur, p_next, lr, &t_debug_spans};
+  return DYB_OK;
+}
+extern "C" int dyb_debug_wgrad_update_spans() { return (int)t_debug_spans.size(); }
 DybConvSyncScope::DybConvSyncScope(unsigned* ctr, int nwords) : saved(t_conv_sync) { t_conv_sync = DybConvSync{ctr, nwords}; }
 DybConvSyncScope::~DybConvSyncScope() { t_conv_sync = saved; }
 // tests / lab: a region for the calling thread's plain conv calls until reset with (NULL, 0)
@@ -1267,7 +1290,7 @@ extern "C" int dyb_debug_set_conv_sync(unsigned* ctr, int nwords) {
 // under the throughput policy: their chunk counts are otherwise sized for one sequence and the launches dispatch-bound), "bf16" (bf16 matrix cores for direct calls of the conv entry points).
 struct DybSwitches {
   std::atomic<int> k4, k4_bwd, k4_batch, k4_maxc, rep_split, bf16, tp_min, tp_kernel, tp_grid, tp_xcd, tp_batch_min, tp_gn_wgs, tp_occ, tp_gn_onepass,
-      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt, tp_fold, lat_fold, stat_folds, tp_gn_wt;
+      tp_gn_cap, tp_gn_threads, tp_gn_fuse_stats, tp_gn_poll, tp_fwd_nosplit2, pair, tp_wt, tp_fold, lat_fold, stat_folds, tp_gn_wt, tp_stem;
   DybSwitches() {
     auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     k4 = env("DYB_K4", 1);
@@ -1291,6 +1314,7 @@ struct DybSwitches {
     tp_fwd_nosplit2 = env("DYB_TP_FWD_NOSPLIT2", 1);
     pair = env("DYB_CONV_PAIR", 1);
     tp_wt = env("DYB_TP_WT", 1);
+    tp_stem = env("DYB_TP_STEM", 1);
     tp_fold = env("DYB_TP_FOLD", 0);       // measured (r05 s3): 32 sequences 461 vs 463 frames/s off, 16: 362 vs 376 - the folding workgroups are a tail
     lat_fold = env("DYB_LAT_FOLD", 1);
     stat_folds = 0;
@@ -1327,6 +1351,7 @@ static std::atomic<int>* find_switch(const char* name) {
   if (!strcmp(name, "tp_fwd_nosplit2")) return &s.tp_fwd_nosplit2;
   if (!strcmp(name, "conv_pair")) return &s.pair;
   if (!strcmp(name, "tp_wt")) return &s.tp_wt;
+  if (!strcmp(name, "tp_stem")) return &s.tp_stem;
   if (!strcmp(name, "tp_fold")) return &s.tp_fold;
   if (!strcmp(name, "lat_fold")) return &s.lat_fold;
   if (!strcmp(name, "tp_gn_wt")) return &s.tp_gn_wt;
@@ -1576,6 +1601,9 @@ static bool tp_eligible(int mode, const ConvDesc& d, const GnBwdFuse* fuse) {
   if ((size_t)d.N * d.H * d.W * d.C + (size_t)d.W * d.C * 8 >= lim || (size_t)d.N * Ho * Wo * d.K + (size_t)Wo * d.K * 8 >= lim ||
       (size_t)d.R * d.S * d.C * d.K >= lim)
     return false;
+  // the stem (Cin = 4): its own loader form of the pipelined forward kernel ("C4", igemm_tp.inc; switch tp_stem)
+  if (mode == MODE_FWD && d.C == 4)
+    return tpk_ >= 2 && d.K <= 64 && d.S >= TPK / 4 && !dyb_bf16_current() && switches().tp_stem.load(std::memory_order_relaxed) != 0;
   if (mode == MODE_FWD) return d.C % TPK == 0 && d.R * d.S <= 32;
   if (mode == MODE_DGRAD) return d.K % TPK == 0 && d.R * d.S <= 32;
   return true;
@@ -1649,6 +1677,17 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   const bool split = g.nsplit > 1;
   g.out = (split || g.compact) ? reinterpret_cast<float*>(ws) : out;          // (compact: always through the scatter fold)
   g.addend = (split || g.compact) ? nullptr : addend;
+  g.out_scale = 1.f;
+  if (mode == MODE_WGRAD && t_wupd.grads && !split && !g.compact && !addend) {
+    const char *lo = reinterpret_cast<const char*>(t_wupd.grads), *o = reinterpret_cast<const char*>(out);
+    if (o >= lo && o + per * sizeof(float) <= lo + t_wupd.bytes) {
+      const size_t off = (size_t)(o - lo) / sizeof(float);
+      g.out = t_wupd.p_next + off;
+      g.addend = t_wupd.p_cur + off;
+      g.out_scale = -t_wupd.lr;
+      if (t_wupd.spans) t_wupd.spans->push_back(DybSpan{off, per});
+    }
+  }
   dim3 grid(mtiles, dyb_cdiv(g.Ncols, TN), g.nsplit * R.n);
   g.probe = probe_for(mode, d, (long)grid.x * grid.y * grid.z);
   // "tp_kernel" 2 (default): the software-pipelined loop (PIPE 1), 3: the same with two K-steps of loads in flight (PIPE 2);
@@ -1707,7 +1746,11 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
     else if (form == 1) DYB_TP_LAUNCH2(M_, FA_, 1, 4); \
     else DYB_TP_LAUNCH2(M_, FA_, 4, 1);               \
   } while (0)
-  if (mode == MODE_FWD) {
+  if (mode == MODE_FWD && d.C == 4) {
+    DYB_REQUIRE(!nfuse && form == 2 && !bf, DYB_ERR_UNSUPPORTED);
+    if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<MODE_FWD, false, 4, 1, 1, false, true>), grid, dim3(256), lds_pad, st, ev0, ev1, 0, g, nf, R);
+    else hipLaunchKernelGGL((igemm_tp_kernel<MODE_FWD, false, 4, 1, 1, false, true>), grid, dim3(256), lds_pad, st, g, nf, R);
+  } else if (mode == MODE_FWD) {
     if (nfuse) DYB_TP_LAUNCH(MODE_FWD, true);
     else DYB_TP_LAUNCH(MODE_FWD, false);
   } else if (mode == MODE_DGRAD) {

@@ -47,6 +47,45 @@ int dyb_fastweight_update3(const float* p, const float* g, const float* g2, cons
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
+// The fast-weight step over a LIST of arena segments in one launch (round 6, "fuse_fast"): the spans whose weight gradient wrote
+// p - lr * g itself (igemm_tp.inc epilogue, DybWgradUpdateScope) are left out; what remains - GroupNorm affines, the regressor, the
+// convolutions that ran split - is up to 64 segments between them.  Workgroup b belongs to segment s with blk[s] <= b < blk[s + 1].
+__global__ __launch_bounds__(256) void fastweight_segs_kernel(const float4* __restrict__ p, const float4* __restrict__ g,
+                                                              float4* __restrict__ out, float lr, DybFwSegs t, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, out);
+  const unsigned b = blockIdx.x;
+  unsigned s = 0;
+  while (s + 1 < t.n && b >= t.blk[s + 1]) ++s;              // (workgroup-uniform)
+  const unsigned nb = t.blk[s + 1] - t.blk[s], lb = b - t.blk[s];
+  const size_t base = t.start4[s];
+  for (size_t i = (size_t)lb * 256 + threadIdx.x; i < t.count4[s]; i += (size_t)nb * 256) {
+    float4 a = p[base + i];
+    const float4 c = g[base + i];
+    a.x -= lr * c.x; a.y -= lr * c.y; a.z -= lr * c.z; a.w -= lr * c.w;
+    out[base + i] = a;
+  }
+}
+int dyb_fastweight_update_segs(const float* p, const float* g, float* out, float lr, const DybFwSegs& segs, hipStream_t st) {
+  DYB_REQUIRE(p && g && out && segs.n >= 1 && segs.n <= DYB_FW_MAX_SEGS, DYB_ERR_ARG);
+  DybFwSegs t = segs;
+  // workgroups per segment: one per 1024 float4 (16 KB), at least one, the launch as a whole within the streaming cap
+  size_t total4 = 0;
+  for (unsigned i = 0; i < t.n; ++i) total4 += t.count4[i];
+  const size_t want = (total4 + 1023) / 1024;
+  const double scale = want > (size_t)t_stream_cap ? (double)t_stream_cap / (double)want : 1.0;
+  unsigned acc = 0;
+  for (unsigned i = 0; i < t.n; ++i) {
+    t.blk[i] = acc;
+    unsigned nb = (unsigned)(((size_t)t.count4[i] + 1023) / 1024 * scale);
+    acc += nb < 1 ? 1 : nb;
+  }
+  t.blk[t.n] = acc;
+  const DybRep& Rp = dyb_rep_current();
+  hipLaunchKernelGGL(fastweight_segs_kernel, dim3(acc, 1, Rp.n), dim3(256), 0, st, (const float4*)p, (const float4*)g, (float4*)out, lr, t, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
 extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out, float lr, size_t n, hipStream_t st) {
   return dyb_fastweight_update3(p, g, nullptr, nullptr, out, lr, n, st);
 }

@@ -51,8 +51,6 @@ def coverage(o, have_bundle: bool = True):
         # (base_adaptor.py:256,309); the stepper calls back only at levels with a labelled term, which consumes the stream at a
         # different rate when the two switches differ
         return "", "labelled term on one level only with feature-driven retrieval"
-    if g("teacher_dropout"):
-        return "", "train-mode teacher"
     return "full", None
 
 
@@ -109,6 +107,13 @@ class NativeStepper:
             for k in ("teacherloss_weight", "motionloss_weight", "labelloss_weight", "alpha", "cos_sim_threshold"):
                 sf(k, getattr(o, k))
             self.dynamic, self.optim_steps = int(g("dynamic_boa", 1)), int(g("optim_steps", 7))
+            # --teacher_dropout 1: the reference's teacher is never put in eval mode (base_adaptor.py:151-158), so its forwards run with live
+            # nn.Dropout(0.5).  The stepper draws each teacher forward's masks from the same counter-based keys dynaboa_amd.hmr hands the
+            # autograd path (seed = torch.initial_seed(), offset = the process-wide train-forward counter): the two paths are bit-identical
+            self.teacher_train = bool(g("teacher_dropout")) and bool(g("use_meanteacher", 1))
+            if self.teacher_train:
+                si("teacher_train", 1)
+                sf("drop_p", float(getattr(adaptor.teacher, "dropout_p", 0.5)))
         self.use_side = 1 if (S == 1 and getattr(adaptor, "_side", None) is not None) else 0
         si("use_side", self.use_side)
         # DYB_SIDE_THREAD=1: the side stream's launches (previous frame's final forward + record, ground-truth meshes) from a helper thread of
@@ -315,14 +320,30 @@ class NativeStepper:
         extra = ctypes.c_int(0)
         slot0 = f * self.slots_per_frame
         self._cb_error = None
+        self._drop_begin()
         rc = self.lib.dyb_stepper_adapt_frame_full(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, ctypes.cast(ctypes.pointer(extra), ctypes.c_void_p),
                                                    stream_of(self.theta), self._aux.cuda_stream if self._aux is not None else None)
         if getattr(self, "_cb_error", None) is not None:
             raise self._cb_error
+        self._drop_end()
         check(rc, "dyb_stepper_adapt_frame_full")
         self._sync_adam_steps()
         self.frame += 1
         return f, slot0, int(extra.value)
+
+    def _drop_begin(self):
+        """train-mode teacher: hand the stepper this frame's dropout keys - torch's seed and the NEXT value of the process-wide
+        train-forward counter (dynaboa_amd.hmr.next_dropout_key), exactly what the autograd path's teacher forwards would draw"""
+        if getattr(self, "teacher_train", False):
+            from . import hmr as _H
+            seed = int(torch.initial_seed()) & ((1 << 64) - 1)
+            check(self.lib.dyb_stepper_set_i(self.h, b"drop_seed", seed - (1 << 64) if seed >= (1 << 63) else seed), "set_i drop_seed")
+            check(self.lib.dyb_stepper_set_i(self.h, b"drop_offset", _H._DROP_CALLS[0] + 1), "set_i drop_offset")
+
+    def _drop_end(self):
+        if getattr(self, "teacher_train", False):
+            from . import hmr as _H
+            _H._DROP_CALLS[0] += int(self.lib.dyb_stepper_get_i(self.h, b"drop_used"))      # the keys the frame's teacher forwards consumed
 
     def _sync_adam_steps(self):
         keys = getattr(self, "_adam_keys", None)
@@ -362,10 +383,12 @@ class NativeStepper:
         extra = (ctypes.c_int * S)()
         slot0 = f * self.slots_per_frame
         self._cb_error = None
+        self._drop_begin()
         rc = self.lib.dyb_stepper_adapt_frames_full(self.h, ctypes.cast(ptrs, ctypes.c_void_p), slot0, f, ctypes.cast(extra, ctypes.c_void_p),
                                                     stream_of(self.theta), self._aux.cuda_stream if self._aux is not None else None)
         if getattr(self, "_cb_error", None) is not None:
             raise self._cb_error
+        self._drop_end()
         check(rc, "dyb_stepper_adapt_frames_full")
         self._sync_adam_steps()
         self._keep_inputs = keep

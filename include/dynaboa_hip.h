@@ -346,6 +346,13 @@ int dyb_sync_error_count(unsigned* count_host, dyb_stream_t stream);
  * conv calls, until reset with (NULL, 0).  With a region in scope a split launch's last-arriving workgroup per tile adds the slabs
  * itself (csrc/igemm_tp.inc); the engine passes its own regions per pass.  Option "stat_folds" counts such launches. */
 int dyb_debug_set_conv_sync(unsigned* ctr, int nwords);
+/* tests / lab ("fuse_fast", round 6): while set, a throughput-form weight gradient of the calling thread that runs UNSPLIT and whose
+ * result would land inside [grads, grads + bytes) writes p_next[off] = p_cur[off] - lr * g from its accumulators instead of g - the MAML
+ * fast-weight step (learn2learn MAML.adapt: p' = p - lr * dL/dp; reference dynaboa_benchmark.py:136,140) fused into the convolution's
+ * epilogue.  Reset with grads = NULL.  dyb_debug_wgrad_update_spans: how many launches took that form since the scope was set.  The frame
+ * stepper opens such a scope around every lower level's backward (csrc/adapt_step.hip). */
+int dyb_debug_set_wgrad_update(const float* grads, size_t bytes, const float* p_cur, float* p_next, float lr);
+int dyb_debug_wgrad_update_spans(void);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 

@@ -59,7 +59,9 @@ def tensor_class(name):
     """(stage, kind) of a parameter: the granularity at which the noise floor is pooled (a single tensor's measured deviation is one
     draw of a random quantity; its class's largest deviation is a stable statistic)."""
     top = name.split(".")[0]
-    stage = "stem" if top in ("conv1", "bn1") else top if top.startswith("layer") else "regressor"
+    # (the stem has ONE tensor per kind - no pool to speak of -: it shares layer1's classes, whose GroupNorm affines sit right behind it
+    # and collect the same ReLU-flip noise of the whole network above)
+    stage = "layer1" if top in ("conv1", "bn1") else top if top.startswith("layer") else "regressor"
     if top in ("conv1",) or ".conv" in name or "downsample.0" in name:
         kind = "conv"
     elif top == "bn1" or ".bn" in name or "downsample.1" in name:
@@ -70,12 +72,19 @@ def tensor_class(name):
 
 
 NOISE_FACTOR = 3.0        # a bound = NOISE_FACTOR x the class's measured fp32-vs-fp64 floor
-NOISE_MIN = {"nd": 2e-4, "cos": 2e-5}     # (never tighter than this: the golden's stored norms / slices are themselves one fp32 draw)
+NOISE_MIN = {"nd": 5e-4, "cos": 2e-5}     # (never tighter than this: the golden's stored norms / slices are themselves one fp32 draw, and
+#                                           the regressor's bias classes have five tensors - their measured floor is 5e-5 ... 1e-4)
+# theta_after - theta_before (and the teacher's drift) are sums of ADAM-NORMALISED steps: an element whose gradient is rounding noise still
+# moves by ~lr per step, with the sign of the noise.  One such element of a 256-element slice flipping its step moves the slice cosine by up
+# to 2 / 256 whatever the implementation, so the slice bound of those two quantities is never tighter than that (a first-principles floor
+# the three CPU draws - which share most of their kernels - underestimate; measured on the GPU's throughput schedule: 1.9e-3 on conv1)
+ADAM_SLICE_FLIP = 2.0 / 256.0
 
 
 def noise_bounds(tag, names, factor=NOISE_FACTOR):
     """Per-tensor bounds for the end-of-stream state of golden g5_<tag>, derived from tests/golden/g5_<tag>_noise.npz
-    (tools/make_noise.py: the reference in fp32 and the oracle in fp32, each against the oracle in fp64 on the same stream).
+    (tools/make_noise.py: the reference in fp32 and the oracle in fp32 - with and without oneDNN -, each against the oracle in fp64 on the
+    same stream).
     -> {q: {"nd": array, "cos": array}} for q in m, v, d (and t = teacher drift): `nd` bounds the relative deviation of a tensor's
     norm from the golden's, `cos` is the LOWER bound of a slice cosine.  A tensor's bound is factor x the largest deviation either
     fp32 run shows over the tensor's class (stage x kind)."""
@@ -87,13 +96,15 @@ def noise_bounds(tag, names, factor=NOISE_FACTOR):
     for q in ("m", "v", "d", "t"):
         if f"{q}_nd_ref" not in z.files:
             continue
-        nd = np.maximum(z[f"{q}_nd_ref"], z[f"{q}_nd_or"])
-        cs = 1.0 - np.minimum(z[f"{q}_cos_ref"], z[f"{q}_cos_or"])
+        draws = [d for d in ("ref", "or", "o2") if f"{q}_nd_{d}" in z.files]      # the fp32 evaluations the file holds (tools/make_noise.py)
+        nd = np.max([z[f"{q}_nd_{d}"] for d in draws], axis=0)
+        cs = 1.0 - np.min([z[f"{q}_cos_{d}"] for d in draws], axis=0)
         cmax_nd, cmax_cs = {}, {}
         for i, c in enumerate(cls):
             cmax_nd[c] = max(cmax_nd.get(c, 0.0), float(nd[i]))
             cmax_cs[c] = max(cmax_cs.get(c, 0.0), float(cs[i]))
+        cmin = ADAM_SLICE_FLIP if q in ("d", "t") else NOISE_MIN["cos"]
         out[q] = dict(nd=np.array([max(NOISE_MIN["nd"], factor * cmax_nd[tensor_class(n)]) for n in names]),
-                      cos=np.array([1.0 - max(NOISE_MIN["cos"], factor * cmax_cs[tensor_class(n)]) for n in names]),
+                      cos=np.array([1.0 - max(cmin, factor * cmax_cs[tensor_class(n)]) for n in names]),
                       floor_nd=np.array([nd[idx[n]] for n in names]))
     return out

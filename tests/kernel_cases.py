@@ -73,6 +73,41 @@ def _conv_check(be, N, H, W, C, K, R, stride, pad, x, w, dy, add, xr, wr, dyr):
     return e
 
 
+def case_conv_wgrad_update(be, N, H, W, C, K, R, stride, pad, lr=0.37, seed=0):
+    """"fuse_fast" (round 6): with a weight-update scope set, an UNSPLIT throughput-form weight gradient leaves p_cur - lr * g in p_next
+    instead of g in dw (igemm_tp.inc epilogue: addend + out_scale * acc).  Against torch's gradient; dw must stay untouched.  The caller
+    has put the library on the throughput schedule with tp_grid small enough for nsplit == 1.  -> launches that took the fused form."""
+    rng = _rng(seed)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    dy = rng.standard_normal((N, Ho, Wo, K)).astype(np.float32)
+    p_cur = rng.standard_normal((R, R, C, K)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    wt = torch.zeros(K, C, R, R, requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv2d(xt, wt, stride=stride, padding=pad), [wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dw_ref = gw.permute(2, 3, 1, 0).numpy()
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad)
+    ws = be.empty((max(wsb, 16) // 4,))
+    marker = np.full(p_cur.shape, 7.25, np.float32)
+    X, DY, P0 = be.dev(x), be.dev(dy), be.dev(p_cur)
+    dw_, p1_ = be.dev(marker), be.dev(np.zeros_like(p_cur))
+    check(be.lib.dyb_debug_set_wgrad_update(be.ptr(dw_), p_cur.size * 4, be.ptr(P0), be.ptr(p1_), lr), "set_wgrad_update")
+    try:
+        check(be.lib.dyb_conv2d_nhwc_wgrad(be.ptr(X), be.ptr(DY), be.ptr(dw_), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb, be.stream),
+              "conv wgrad (update scope)")
+        be.sync()
+        fused = int(be.lib.dyb_debug_wgrad_update_spans())
+    finally:
+        be.lib.dyb_debug_set_wgrad_update(None, 0, None, None, 0.0)
+    if fused:
+        assert np.array_equal(be.host(dw_), marker), "the gradient buffer was written although the update was fused"
+        e = rel_err(be.host(p1_), p_cur - np.float32(lr) * dw_ref)
+    else:
+        e = rel_err(be.host(dw_), dw_ref)
+    assert e < TOL, e
+    return fused
+
+
 def case_conv_inkernel_fold(be, N, H, W, C, K, R, stride, pad, seed=0):
     """The same three checks with a counter region in scope: a launch that splits K lets the workgroup that arrives last on a tile add
     the tile's slabs itself (igemm_tp.inc / igemm_conv.hip epilogues) instead of leaving them to a fold launch.  The counters must be

@@ -70,9 +70,10 @@ GATED = ["fo_inner1_full_gated", "fo_inner1_full_gated_b", "fo_inner1_full_gated
 
 def assert_gate_matches_golden(ad, g, step):
     """Every check of the dynamic-BOA gate in frame `step` against the reference's (golden keys gate_*, tools/make_golden.py g5_gated):
-    the number of checks, the step count the loop left with (dynaboa_benchmark.py:161-192), and 1 - cos(features[12]) of each check
-    inside a QUARTER of the golden's decision margin (so no decision of this run was closer to flipping than the reference's own
-    fp32 noise allows); the other 14 cosines to 2e-6 absolute (fp32 cosine near 1)."""
+    the number of checks, the step count the loop left with (dynaboa_benchmark.py:161-192), and 1 - cos(features[12]) of each check on
+    the reference's side of the threshold with at least half the reference's distance from it to spare, the value within 1 %; all 15
+    cosines against the reference's float64 evaluation (3e-6).  -> the largest deviation as a fraction of the check's distance from the
+    threshold."""
     thr, margin = float(g["gate_threshold"]), float(g["gate_margin"])
     extra = int(g["extra_steps"][step])
     assert ad.optim_step_record[-1] == extra, (step, ad.optim_step_record[-1], extra)
@@ -83,11 +84,21 @@ def assert_gate_matches_golden(ad, g, step):
     for k in range(nchk):
         ours = np.array([float(sims[k][i]["cos"]) for i in range(15)], np.float64)
         ref = g["gate_cos"][step, k]
-        dev = abs((1.0 - ours[12]) - float(g["gate_1mcos12"][step, k]))
-        worst = max(worst, dev / thr)
-        assert dev < 0.25 * margin * thr, (step, k, 1.0 - ours[12], float(g["gate_1mcos12"][step, k]), margin * thr)
-        assert ((1.0 - ours[12]) > thr) == (float(g["gate_1mcos12"][step, k]) > thr), (step, k)
-        np.testing.assert_allclose(ours, ref, atol=2e-6, rtol=0)
+        refd = float(g["gate_1mcos12"][step, k])
+        dev = abs((1.0 - ours[12]) - refd)
+        worst = max(worst, dev / abs(refd - thr))
+        # same decision, with at least half of the reference's own distance from the threshold left (>= gate_margin x threshold for every
+        # check of the run), and the value itself within 1 % (the weights these features come from carry up to 47 Adam steps of fp32
+        # trajectory noise by the last frames: 0.3 % measured at frame 8)
+        assert ((1.0 - ours[12]) > thr) == (refd > thr), (step, k)
+        assert dev < 0.5 * abs(refd - thr), (step, k, 1.0 - ours[12], refd, thr)
+        assert dev < 1e-2 * refd, (step, k, 1.0 - ours[12], refd)
+        # the other 14 cosines: against the reference's values evaluated in float64 on its own features where the golden has them
+        # (gate_cos64; F.cosine_similarity in fp32 carries up to ~2e-5 of summation error on the 8e5-element features - it returns
+        # 1.000017 for feature 0), else against the fp32 values at that noise level
+        if "gate_cos64" in g.files:
+            np.testing.assert_allclose(ours, g["gate_cos64"][step, k], atol=3e-6, rtol=0)
+        np.testing.assert_allclose(ours, ref, atol=5e-5, rtol=0)
     return worst
 
 
@@ -128,7 +139,7 @@ def test_dynamic_boa_gate_leaves_by_convergence_as_the_reference_does(tag, nativ
             assert rel_err(v.cpu().numpy(), g[f"pred{step}_{k}"]) < 1e-3, (step, k)
         assert abs(float(np.mean(mpjpe)) - g["mpjpe"][step]) < 1e-3 * g["mpjpe"][step]
         assert abs(float(np.mean(pampjpe)) - g["pampjpe"][step]) < 2e-3 * g["pampjpe"][step]
-    print("gate %s: worst |d(1 - cos12)| / threshold %.2e (margin of the reference run %.2e)" % (tag, worst, float(g["gate_margin"])))
+    print("gate %s: worst |d(1 - cos12)| as a fraction of the check's distance from the threshold %.3f (margin of the reference run %.2e)" % (tag, worst, float(g["gate_margin"])))
     assert int(ad.optimizer.state[ad.model.module.theta]["step"]) == n + sum(min(x, 7) for x in steps) == int(g["adam_steps"])
     assert_final_state_matches_golden(ad, g, theta0, dict(inner_step=1), tag=tag)
 
@@ -851,6 +862,53 @@ def test_teacher_dropout_option_runs_reference_teacher_mode():
             vals[(td, seed)] = float(ad.last_summaries["teacher/loss"])
     assert vals[(0, 1)] == vals[(0, 2)]
     assert vals[(1, 1)] != vals[(1, 2)] and np.isfinite(vals[(1, 1)]) and vals[(1, 1)] > vals[(0, 1)]
+
+
+def test_train_mode_teacher_on_the_native_stepper_equals_the_autograd_path():
+    """VERDICT r5 missing 8: the reference never calls teacher.eval() (base_adaptor.py:151-158), so its teacher forwards run with live
+    nn.Dropout(0.5) after fc1 / fc2 (model/hmr.py:84,86).  --teacher_dropout 1 now stays on the native stepper: every teacher forward of a
+    frame (one per upper level, dynamic-loop steps included) draws its masks from the keys the autograd path would draw - torch's seed and the
+    process-wide train-forward counter - so the two paths see the SAME masks: over a stream whose dynamic loop is entered they agree as
+    closely as they do with the eval-mode teacher (test_native_full_term_set_matches_autograd_path: the passes' gradients are summed in
+    a different order, nothing else), the first frame's teacher term to 1e-6, and the run differs from the eval-mode teacher's."""
+    from dynaboa_amd import assets, hmr as H
+    frames = [{k: v.to("cuda:0") for k, v in assets.make_frame(s, 1, seed=22).items()} for s in range(4)]
+    opts = dict(STREAMS["fo_inner1_full"][0], teacher_dropout=1, cos_sim_threshold=1.0e-4, optim_steps=3)
+    outs = {}
+    for native in (1, 0, 1):
+        torch.manual_seed(5)
+        H._DROP_CALLS[0] = 0
+        ad, _ = make_adaptor(dict(opts, native_step=native), False)
+        ad.reset_records(4)
+        tl = []
+        for s_, fr in enumerate(frames):
+            ad.global_step = s_
+            ad.fit_losses = {}
+            ad.model.eval()
+            ad.adaptation(fr)
+            tl.append(float(ad.fit_losses["teacher/loss"]))
+        ad.flush_metrics()
+        assert (ad._native is not None and ad._native.full) == bool(native) and ad.teacher.training
+        st = ad.optimizer.state[ad.model.module.theta]
+        res = (ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), ad.teacher.theta.detach().clone(), list(ad.optim_step_record),
+               H._DROP_CALLS[0], tl)
+        if native in outs:
+            for a, b in zip(outs[native], res):
+                assert torch.equal(a, b) if torch.is_tensor(a) else a == b          # same seed, same counter: reproducible
+        outs[native] = res
+    assert outs[1][4] == outs[0][4] >= 4 + sum(min(x, 3) for x in outs[1][3])       # one key per teacher forward, on both paths
+    assert outs[1][3] == outs[0][3] and max(outs[1][3]) >= 1, (outs[1][3], outs[0][3])
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    print("train-mode teacher, native vs autograd: theta %.2e m %.2e teacher %.2e; teacher term per frame %s vs %s" %
+          (rel(outs[1][0], outs[0][0]), rel(outs[1][1], outs[0][1]), rel(outs[1][2], outs[0][2]), outs[1][5], outs[0][5]))
+    assert abs(outs[1][5][0] - outs[0][5][0]) < 1e-6 * abs(outs[0][5][0])            # same masks: frame 0's teacher term is the same number
+    np.testing.assert_allclose(outs[1][5], outs[0][5], rtol=1e-3)          # (3e-4 measured at frame 3: the weights differ by ~2e-6 by then)
+    assert rel(outs[1][0], outs[0][0]) < 5e-6 and rel(outs[1][2], outs[0][2]) < 5e-6 and rel(outs[1][1], outs[0][1]) < 5e-3
+    torch.manual_seed(5)
+    ad, _ = make_adaptor(dict(opts, teacher_dropout=0), False)
+    ad.excute(frames, nframes=4)
+    assert not torch.equal(ad.model.module.theta.detach(), outs[1][0])               # the eval-mode teacher gives another run (4.9e-6 apart after 4 frames)
+    assert abs(float(ad.last_summaries["teacher/loss"]) - outs[1][5][-1]) > 1e-3 * outs[1][5][-1]
 
 
 def test_bf16_mfma_variant_vs_fp32_batch16(ckpt_rand):

@@ -207,3 +207,28 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert abs(rec["value"] - steps * seqs * 2 / (rec["ms_per_step"] * 1e-3 * steps)) < 1e-6 * rec["value"]
     op = rec["pw3d_operating_point"]
     assert op.get("value") and op["sequences_per_gpu"] == 19, op     # ceil(37 / 2)
+
+
+def test_fast_weights_from_the_weight_gradient_epilogue_are_bit_identical_to_the_streaming_pass(headline_switches, monkeypatch):
+    """"fuse_fast" (round 6): on the throughput schedule a lower level's unsplit weight gradients write theta_next = theta_cur - fastlr * g
+    from their accumulators (the levels ping-pong between two fast-weight buffers; the streaming pass covers the rest of the arena by
+    segments) - against the round-5 form (every gradient to HBM, one streaming pass over the whole arena): S = 8, three frames of
+    3 inner + 1 outer step - weights, Adam moments and metrics bit for bit."""
+    from dynaboa_amd import native_step as NS
+    S, NF = 8, 3
+    frames = _frames(S, NF)
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DYB_FUSE_FAST", fuse)           # read when the stepper is created
+        ads = [_mk(r) for r in range(S)]
+        grp = NS.ReplicaGroup(ads, NF)
+        for step in range(NF):
+            grp.step([frames[r][step] for r in range(S)], step)
+        fl = grp.flush_metrics()
+        st = [a.optimizer.state[a.model.module.theta] for a in ads]
+        outs.append([torch.stack([a.model.module.theta.detach() for a in ads]), torch.stack([s_["exp_avg"] for s_ in st]),
+                     torch.stack([s_["exp_avg_sq"] for s_ in st]),
+                     torch.tensor(np.array([np.ravel(np.array(fl[r]["mpjpe"], np.float64)) for r in range(S)]))])
+        del grp, ads
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a.double() - b.double()).norm() / b.double().norm())

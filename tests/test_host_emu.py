@@ -511,7 +511,7 @@ def test_native_stepper_coverage_rules(emu_lib):
     assert NS.mode(o) == "" and "batch" in NS.supported(o)
     o = DB.parser.parse_args([])
     o.teacher_dropout = 1
-    assert NS.mode(o) == ""                                                       # train-mode teacher: the autograd composition
+    assert NS.mode(o) == "full"                                                   # train-mode teacher: on the stepper since round 6
     o = DB.parser.parse_args([])
     o.sample_num = 2
     assert NS.mode(o) == "" and NS.mode(DB.parser.parse_args([]), have_bundle=False) == "full"

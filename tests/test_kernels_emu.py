@@ -84,7 +84,10 @@ def throughput_mode(be, request):
     (1, 7, 7, 128, 256, 3, 1, 1),      # M = 49: 64x256 (fwd, dgrad); wgrad 128x128 with a 49-pixel reduction (ragged K-step)
     (2, 10, 10, 64, 64, 3, 2, 1),      # Cout = 64: 256x64 forms, stride 2, batch 2, split-K
     (1, 8, 8, 128, 64, 1, 2, 0),       # 1x1 stride 2 (downsample)
-    (1, 20, 20, 4, 64, 7, 2, 3),       # stem: forward stays on the 64x64 kernel (Cin = 4), weight gradient takes the 256x64 form
+    (1, 20, 20, 4, 64, 7, 2, 3),       # stem: forward on the C4 form of the pipelined kernel (per-thread taps; 64x64 kernel for "phased"), weight gradient 256x64
+    (2, 21, 19, 4, 64, 7, 2, 3),       # stem, odd H != W, batch 2: 2 x 11 x 10 = 220 rows (ragged 256-row tile), K = 196 = 12 steps + 4 of 16
+    (1, 16, 16, 4, 32, 5, 1, 2),       # Cin = 4 with a 5x5 stride-1 filter (S = 5: a wrap every K-step), Cout 32: K = 100
+    (1, 9, 9, 4, 64, 4, 1, 1),         # S = 4 = taps per K-step: (r, s) -> (r + 1, s) every step
     (1, 4, 4, 64, 128, 3, 1, 1),       # 4x4 map: a K-step of the weight gradient spans whole images (pipelined form falls back to the pixel-walk loop)
     (2, 5, 6, 32, 128, 3, 1, 1),       # 5x6 map, batch 2: one wrap per K-step of the branch-free pixel walk, twice
 ])
@@ -512,3 +515,27 @@ def test_hmr_exact_hessian_vector_product_one_launch_groupnorm_tangents(be, ckpt
         print(K.case_hmr_hvp(be, ckpt_rand, B=1))
     finally:
         be.lib.dyb_set_option(b"conv_pair", 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    (1, 7, 7, 128, 256, 3, 1, 1),      # 49-pixel reduction (ragged last K-step), 128x128 tiles
+    (1, 12, 12, 128, 128, 1, 1, 0),    # 1x1
+    (2, 10, 10, 64, 64, 3, 2, 1),      # Cout = 64: the 256x64 form, stride 2, batch 2
+    (1, 14, 14, 64, 128, 1, 2, 0),     # 1x1 stride 2 (downsample)
+])
+def test_conv_weight_gradient_writes_fast_weights(be, cfg):
+    """"fuse_fast": the throughput-form weight gradient with a weight-update scope in force (kernel_cases.case_conv_wgrad_update) -
+    unsplit (tp_grid 1): p_next = p_cur - lr * g from the epilogue, the gradient buffer untouched; split (tp_grid 4096 where the shape
+    allows a split): the scope is ignored and the plain gradient arrives."""
+    N, H, W, C, Kc, R, st, pad = cfg
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    try:
+        be.lib.dyb_set_option(b"tp_grid", 1)
+        assert K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg)) == 1
+        be.lib.dyb_set_option(b"tp_grid", 4096)
+        K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + 1)
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)

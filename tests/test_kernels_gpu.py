@@ -418,3 +418,27 @@ def test_hmr_exact_hessian_vector_product(be, ckpt_rand, side):
     """dyb_hmr_jvp_forward / _backward: tangent of the regressor state and every tensor of H v against torch differentiating
     the oracle twice (CPU); with the side stream (the pairs' off-chain halves beside the chain) and with everything in line."""
     print(K.case_hmr_hvp(be, ckpt_rand, side=side))
+
+
+@pytest.mark.parametrize("cfg", [
+    (1, 7, 7, 128, 256, 3, 1, 1),      # 49-pixel reduction (ragged last K-step), 128x128 tiles
+    (1, 12, 12, 128, 128, 1, 1, 0),    # 1x1
+    (2, 10, 10, 64, 64, 3, 2, 1),      # Cout = 64: the 256x64 form, stride 2, batch 2
+    (1, 14, 14, 64, 128, 1, 2, 0),     # 1x1 stride 2 (downsample)
+])
+def test_conv_weight_gradient_writes_fast_weights(be, cfg):
+    """"fuse_fast": the throughput-form weight gradient with a weight-update scope in force (kernel_cases.case_conv_wgrad_update) -
+    unsplit (tp_grid 1): p_next = p_cur - lr * g from the epilogue, the gradient buffer untouched; split (tp_grid 4096 where the shape
+    allows a split): the scope is ignored and the plain gradient arrives."""
+    N, H, W, C, Kc, R, st, pad = cfg
+    be.lib.dyb_set_option(b"rep_split", 1)
+    be.lib.dyb_set_option(b"tp_min", 1)
+    try:
+        be.lib.dyb_set_option(b"tp_grid", 1)
+        assert K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg)) == 1
+        be.lib.dyb_set_option(b"tp_grid", 4096)
+        K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + 1)
+    finally:
+        be.lib.dyb_set_option(b"tp_grid", 512)
+        be.lib.dyb_set_option(b"rep_split", 0)
+        be.lib.dyb_set_option(b"tp_min", 8)

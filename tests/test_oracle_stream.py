@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import cosine, golden, rel_err
+from conftest import cosine, golden, noise_bounds, rel_err
 from oracle import ref_cpu as O
 from dynaboa_amd import assets
 
@@ -47,11 +47,12 @@ def test_stream(tag, gmm_t, smpl_tabs):
     for step in range(n):
         rec = ad.adapt_frame(assets.make_frame(step, 1, seed=22))
         if "gated" in tag:
-            # every check of the gate: same count, and 1 - cos within a quarter of the reference run's own decision margin
+            # every check of the gate: same count, 1 - cos on the reference's side of the threshold with half its distance to spare, within 1 %
             assert len(rec["gate_cos12"]) == int(g["gate_checks"][step]), (step, rec["gate_cos12"])
-            thr, margin = float(g["gate_threshold"]), float(g["gate_margin"])
+            thr = float(g["gate_threshold"])
             for k, c in enumerate(rec["gate_cos12"]):
-                assert abs((1.0 - c) - float(g["gate_1mcos12"][step, k])) < 0.25 * margin * thr, (step, k, 1.0 - c)
+                refd = float(g["gate_1mcos12"][step, k])
+                assert abs((1.0 - c) - refd) < min(0.5 * abs(refd - thr), 1e-2 * refd), (step, k, 1.0 - c, refd)
         # the reference's logged 'ul/unlabelloss' aliases the in-place-accumulated TOTAL upper loss
         assert abs(ad.log["ul/total"] - g["upper_loss"][step]) < 2e-5 * abs(g["upper_loss"][step])
         assert rec["extra_steps"] == int(g["extra_steps"][step])
@@ -60,16 +61,24 @@ def test_stream(tag, gmm_t, smpl_tabs):
     assert ad.adam_t == int(g["adam_steps"])
     names = [str(x) for x in g["names"]]
     dn = np.array([float((ad.theta[k].detach().double() - sd0[k].double()).norm()) for k in names])
-    np.testing.assert_allclose(dn, g["delta_norms"], rtol=1e-2)   # ReLU-mask flips of |x|<1e-6 activations perturb single tensors at the 1e-3 level
-    np.testing.assert_allclose([float(ad.m[k].double().norm()) for k in names], g["m_norms"], rtol=1e-2)
-    np.testing.assert_allclose([float(ad.v[k].double().norm()) for k in names], g["v_norms"], rtol=2e-2)
-    for k in SLICE_PARAMS:
-        d = (ad.theta[k].detach().double() - sd0[k].double()).flatten()[:256]
-        assert cosine(d, g["d_" + k]) > 0.99, k
-        assert cosine(ad.m[k].flatten()[:256], g["m_" + k]) > 0.99, k
+    mn = np.array([float(ad.m[k].double().norm()) for k in names])
+    vn = np.array([float(ad.v[k].double().norm()) for k in names])
+    # bounds = 3 x the fp32-vs-fp64 floor of the tensor's class on THIS stream (tests/golden/g5_<tag>_noise.npz, tools/make_noise.py):
+    # ReLU-mask flips of near-zero activations and Adam's sign-like steps move single early-layer tensors by ~1e-2 between two
+    # correct fp32 evaluations after a few frames, by several 1e-2 after the 47 Adam steps of the long gated streams
+    nb = noise_bounds(tag, names)
+    checks = [("d", dn, g["delta_norms"]), ("m", mn, g["m_norms"]), ("v", vn, g["v_norms"])]
     if "teacher_delta_norms" in g.files and ad.o["use_meanteacher"]:
-        tn = np.array([float((ad.teacher[k].double() - sd0[k].double()).norm()) for k in names])
-        np.testing.assert_allclose(tn, g["teacher_delta_norms"], rtol=1e-2)
+        checks.append(("t", np.array([float((ad.teacher[k].double() - sd0[k].double()).norm()) for k in names]), g["teacher_delta_norms"]))
+    for q, x, ref in checks:
+        e = np.abs(x - ref) / ref
+        bad = [(names[i], float(e[i]), float(nb[q]["nd"][i])) for i in range(len(names)) if e[i] >= nb[q]["nd"][i]]
+        assert not bad, (q, bad[:8])
+    for k in SLICE_PARAMS:
+        j = names.index(k)
+        d = (ad.theta[k].detach().double() - sd0[k].double()).flatten()[:256]
+        assert cosine(d, g["d_" + k]) > nb["d"]["cos"][j], k
+        assert cosine(ad.m[k].flatten()[:256], g["m_" + k]) > nb["m"]["cos"][j], k
 
 
 @pytest.mark.slow

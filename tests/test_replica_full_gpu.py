@@ -237,7 +237,7 @@ def test_gated_reference_stream_as_replica_0_of_a_group_of_8(tag):
     finally:
         lib.dyb_set_option(b"rep_split", 0)
         lib.dyb_set_option(b"tp_min", 8)
-    print("gate %s, replica 0 of 8: worst |d(1 - cos12)| / threshold %.2e (margin %.2e)" % (tag, worst, float(g["gate_margin"])))
+    print("gate %s, replica 0 of 8: worst |d(1 - cos12)| as a fraction of the check's distance from the threshold %.3f (margin %.2e)" % (tag, worst, float(g["gate_margin"])))
     steps = [int(x) for x in g["extra_steps"]]
     assert list(ads[0].optim_step_record) == steps
     assert len({tuple(a.optim_step_record) for a in ads}) > 1           # the sequences of the group took different paths

@@ -4,6 +4,7 @@ the SAME algorithm evaluated in fp64?  Three runs of every stream on the same se
 
   ref32     the REFERENCE's own Adaptor.adaptation() in fp32 (tools/make_golden.py machinery: the run the goldens come from)
   oracle32  oracle.ref_cpu.Adapter in fp32 (a second, independent fp32 evaluation order: torch.func vs nn.Module, other op sequence)
+  oracle32b the same with oneDNN switched off (torch.backends.mkldnn: convolutions through im2col + sgemm - a third summation order)
   oracle64  oracle.ref_cpu.Adapter in fp64 - the noise-free trajectory (its own rounding is ~1e-16)
 
 and per parameter tensor, for Adam's m and v and for theta_after - theta_before (and the teacher's drift):
@@ -75,7 +76,10 @@ def run_reference(opts, ident, nframes):
     return res
 
 
-def run_oracle(opts, ident, nframes, dtype):
+def run_oracle(opts, ident, nframes, dtype, mkldnn=True):
+    if not mkldnn:
+        with torch.backends.mkldnn.flags(enabled=False):
+            return run_oracle(opts, ident, nframes, dtype)
     mp = assets.make_smpl_mean_params(identity_pose=ident, seed=3)
     sd = assets.make_synthetic_checkpoint(22, mp, randomize_norm=True, prefix="")["model"]
     sd = {k: v.to(dtype) for k, v in sd.items()}
@@ -122,20 +126,21 @@ def main():
         opts, ident, nframes = S[tag]
         ref = run_reference(opts, ident, nframes)
         o32 = run_oracle(opts, ident, nframes, torch.float32)
+        o32b = run_oracle(opts, ident, nframes, torch.float32, mkldnn=False)
         o64 = run_oracle(opts, ident, nframes, torch.float64)
         names = ref["names"]
         assert names == o64["names"] == o32["names"]
-        assert ref["steps"] == o32["steps"] == o64["steps"], (ref["steps"], o32["steps"], o64["steps"])      # the fp64 run takes the same path
+        assert ref["steps"] == o32["steps"] == o64["steps"] == o32b["steps"], (ref["steps"], o32["steps"], o32b["steps"], o64["steps"])      # the fp64 run takes the same path
         payload = dict(names=np.array(names), nframes=nframes, extra_steps=np.array(ref["steps"]))
         for q in ("m", "v", "d") + (("t",) if "t" in ref else ()):
-            for src, run in (("ref", ref), ("or", o32)):
+            for src, run in (("ref", ref), ("or", o32), ("o2", o32b)):
                 nd, l2, cs = compare(run[q], o64[q], names)
                 payload[f"{q}_nd_{src}"], payload[f"{q}_l2_{src}"], payload[f"{q}_cos_{src}"] = nd, l2, cs
-            worst = np.maximum(payload[f"{q}_nd_ref"], payload[f"{q}_nd_or"])
+            worst = np.maximum(np.maximum(payload[f"{q}_nd_ref"], payload[f"{q}_nd_or"]), payload[f"{q}_nd_o2"])
             i = int(np.argmax(worst))
             print(f"{tag:34s} {q}: norm deviation median {np.median(worst):.2e} max {worst.max():.2e} ({names[i]}); element-wise median "
                   f"{np.median(payload[f'{q}_l2_ref']):.2e} max {payload[f'{q}_l2_ref'].max():.2e}; worst slice cosine "
-                  f"{min(payload[f'{q}_cos_ref'].min(), payload[f'{q}_cos_or'].min()):.6f}", flush=True)
+                  f"{min(payload[f'{q}_cos_ref'].min(), payload[f'{q}_cos_or'].min(), payload[f'{q}_cos_o2'].min()):.6f}", flush=True)
         np.savez_compressed(os.path.join(args.out, f"g5_{tag}_noise.npz"), **payload)
 
 
