@@ -65,6 +65,8 @@ int dyb_adam_step_rep3(float*, const float*, const float*, const float*, float*,
                        hipStream_t);
 int dyb_fastweight_update3(const float*, const float*, const float*, const float*, float*, float, size_t, hipStream_t);
 int dyb_fastweight_update_segs(const float*, const float*, float*, float, const DybFwSegs&, hipStream_t);       // optim.hip
+int dyb_adam_step_segs(float*, const float*, float*, float*, float, float, const float*, const float*, float, const DybFwSegs&, hipStream_t);
+int dyb_adam_write_scalars(float*, const float*, const float*, hipStream_t);
 
 #define STATE_LD 160
 #define NV 6890
@@ -296,6 +298,14 @@ struct Stepper {
   float* theta_fast2 = nullptr;
   int fuse_fast = 1;
   std::vector<DybSpan> fused_spans, upd_spans;
+  // "fuse_adam" (round 6; frame-loss path, replica groups, inner_step >= 1): the OUTER level's unsplit throughput-form weight gradients apply
+  // Adam to theta / exp_avg / exp_avg_sq in place from their accumulators (igemm_tp.inc; the level is differentiated at the fast weights,
+  // nobody reads theta meanwhile); the streaming Adam pass covers what is left.  The step's bias corrections are fixed BEFORE that
+  // backward (adam_prepare) and live, per replica, in adam_sc (two floats of every replica's workspace copy).
+  int fuse_adam = 1;
+  float* adam_sc = nullptr;
+  bool adam_prepared = false;
+  float pre_ss[DYB_MAX_REPLICAS], pre_bc[DYB_MAX_REPLICAS];
   float *gt_rot = nullptr, *gt_verts[3] = {}, *gt_joints = nullptr, *gt_saved = nullptr, *gt17[2] = {};
   DybEvents* ev = nullptr;
   hipEvent_t e_theta = nullptr, e_side = nullptr, e_gt = nullptr;
@@ -405,6 +415,7 @@ static size_t carve(Stepper& S, char* base) {
   pass(S.fin, false);
   S.theta_fast = take_f(S.n_params);
   S.theta_fast2 = S.fuse_fast ? take_f(S.n_params) : nullptr;
+  S.adam_sc = take_f(64);
   S.grads = take_f(S.n_params);
   S.gt_rot = take_f(B * 24 * 9);
   for (int i = 0; i < 3; ++i) S.gt_verts[i] = take_f(B * NV * 3);
@@ -464,6 +475,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   if (const char* e = getenv("DYB_SHARE_DYN_FWD")) S->share_dyn_fwd = atoi(e);
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
   if (const char* e = getenv("DYB_FUSE_FAST")) S->fuse_fast = atoi(e);
+  if (const char* e = getenv("DYB_FUSE_ADAM")) S->fuse_adam = atoi(e);
   if (const char* e = getenv("DYB_PAR_PASSES")) S->par_passes = atoi(e);
   if (const char* e = getenv("DYB_PAR_MAX_REPLICAS")) S->par_max_replicas = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
@@ -513,6 +525,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "par_max_replicas") S->par_max_replicas = (int)v;
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "fuse_fast") { DYB_REQUIRE(!S->bound, DYB_ERR_ARG); S->fuse_fast = (int)v; }
+  else if (k == "fuse_adam") S->fuse_adam = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -878,6 +891,55 @@ static int fastweight_range(Stepper& S, const float* p, float* out, const float*
   RUN(add(at, hi));
   return flush();
 }
+// Adam over [lo, hi) minus the spans the outer level's weight gradients updated themselves (S.upd_spans, sorted)
+static int adam_range(Stepper& S, const float* g2, const float* g3, const float* ss, const float* bc, size_t lo, size_t hi, hipStream_t s) {
+  bool any = false;
+  for (const DybSpan& sp : S.upd_spans)
+    if (sp.off < hi && sp.off + sp.n > lo) { any = true; break; }
+  if (!any)
+    return dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, S.adam_m + lo, S.adam_v + lo,
+                              (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, hi - lo, s);
+  DYB_REQUIRE(!g2 && !g3 && lo % 4 == 0 && hi % 4 == 0, DYB_ERR_UNSUPPORTED);
+  DybFwSegs t{};
+  auto flush = [&]() -> int {
+    if (t.n == 0) return DYB_OK;
+    const int rc = dyb_adam_step_segs(S.theta, S.grads, S.adam_m, S.adam_v, (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, t, s);
+    t.n = 0;
+    return rc;
+  };
+  auto add = [&](size_t a, size_t b) -> int {
+    if (a >= b) return DYB_OK;
+    DYB_REQUIRE(a % 4 == 0 && b % 4 == 0 && (b - a) / 4 < 0xffffffffull && a / 4 < 0xffffffffull, DYB_ERR_UNSUPPORTED);
+    if (t.n == DYB_FW_MAX_SEGS) RUN(flush());
+    t.start4[t.n] = (unsigned)(a / 4); t.count4[t.n] = (unsigned)((b - a) / 4); ++t.n;
+    return DYB_OK;
+  };
+  size_t at = lo;
+  for (const DybSpan& sp : S.upd_spans) {
+    if (sp.off + sp.n <= at) continue;
+    if (sp.off >= hi) break;
+    DYB_REQUIRE(sp.off >= lo && sp.off + sp.n <= hi, DYB_ERR_UNSUPPORTED);
+    RUN(add(at, sp.off));
+    at = sp.off + sp.n;
+  }
+  RUN(add(at, hi));
+  return flush();
+}
+// this step's Adam bias corrections for every replica of the current scope (step counts advance HERE), kept for weight_update(adam) and
+// written into each replica's adam_sc on `st` for the weight-gradient epilogues that apply Adam themselves
+static int adam_prepare(Stepper& S, hipStream_t st) {
+  const DybRep& R = dyb_rep_current();
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { S.pre_ss[r] = 0.f; S.pre_bc[r] = 1.f; }
+  for (int i = 0; i < R.n; ++i) {
+    const int r = dyb_rep_phys(R, i);
+    const double t = (double)(++S.adam_t_rep[r]);
+    S.pre_ss[r] = (float)(S.lr / (1.0 - pow(S.beta1, t)));
+    S.pre_bc[r] = (float)sqrt(1.0 - pow(S.beta2, t));
+    if (S.adam_t_rep[r] > S.adam_t) S.adam_t = S.adam_t_rep[r];
+  }
+  S.adam_prepared = true;
+  return dyb_adam_write_scalars(S.adam_sc, S.pre_ss, S.pre_bc, st);
+}
 // Adam on every replica of the current launch scope, each with its own step count (bias corrections per physical replica)
 // the deferred last range of a ranged weight update (see weight_update): issued from inside the consuming forward at layer3
 static int late_update(void* user) {
@@ -889,8 +951,7 @@ static int late_update(void* user) {
   DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / L.scope.n > 0 ? S.upd_blocks / L.scope.n : 1) : 0);
   const float *g2 = L.g2 ? L.g2 + lo : nullptr, *g3 = L.g3 ? L.g3 + lo : nullptr;
   if (L.adam) {
-    RUN(dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2, g3, S.adam_m + lo, S.adam_v + lo, (float)S.beta1, (float)S.beta2, L.ss, L.bc,
-                           (float)S.eps, n, L.aux));
+    RUN(adam_range(S, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, L.ss, L.bc, lo, lo + n, L.aux));
     if (L.ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
   } else {
     RUN(fastweight_range(S, L.p, L.out, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, lo, lo + n, L.aux));
@@ -913,13 +974,14 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   S.lvl_g2 = S.lvl_g3 = nullptr;
   // the spans this level's weight gradients turned into fast weights themselves ("fuse_fast"): taken over, sorted, for this update only
   S.upd_spans.clear();
-  if (!adam) {
-    S.upd_spans.swap(S.fused_spans);
-    std::sort(S.upd_spans.begin(), S.upd_spans.end(), [](const DybSpan& a, const DybSpan& b) { return a.off < b.off; });
-  }
+  S.upd_spans.swap(S.fused_spans);
+  std::sort(S.upd_spans.begin(), S.upd_spans.end(), [](const DybSpan& a, const DybSpan& b) { return a.off < b.off; });
   S.fused_spans.clear();
   float ss[DYB_MAX_REPLICAS], bc[DYB_MAX_REPLICAS];
-  if (adam) {
+  if (adam && S.adam_prepared) {                       // fixed before the outer backward (adam_prepare): the epilogues used the same numbers
+    for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = S.pre_ss[r]; bc[r] = S.pre_bc[r]; }
+    S.adam_prepared = false;
+  } else if (adam) {
     for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { ss[r] = 0.f; bc[r] = 1.f; }
     for (int i = 0; i < R.n; ++i) {
       const int r = dyb_rep_phys(R, i);
@@ -931,8 +993,7 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   }
   auto range = [&](size_t lo, size_t hi, hipStream_t s) -> int {
     if (adam) {
-      RUN(dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, S.adam_m + lo, S.adam_v + lo,
-                             (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, hi - lo, s));
+      RUN(adam_range(S, g2, g3, ss, bc, lo, hi, s));
       // update_teacher (base_adaptor.py:193-201) of the same range right behind it: the teacher's next reader is a forward too
       if (ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
       return DYB_OK;
@@ -1035,9 +1096,18 @@ static int adapt_frame_impl(Stepper& S, const float* image, const float* kp2d, c
     {
       HostTimer t(S.h_bwd);
       S.fused_spans.clear();
-      DybWgradUpdateScope fuse((i < K && S.fuse_fast && S.theta_fast2)
-                                   ? DybWgradUpdate{S.grads, n * sizeof(float), cur, nxt, (float)S.fastlr, &S.fused_spans}
-                                   : DybWgradUpdate{nullptr, 0, nullptr, nullptr, 0.f, nullptr});
+      DybWgradUpdate upd{};
+      if (i < K && S.fuse_fast && S.theta_fast2) {
+        upd = DybWgradUpdate{S.grads, n * sizeof(float), cur, nxt, (float)S.fastlr, &S.fused_spans};
+      } else if (i == K && S.fuse_adam && cur != S.theta && !side && S.nrep > 1) {
+        // the outer level is differentiated at the fast weights: theta has no reader until the final inference - Adam may be applied
+        // layer by layer as the weight gradients finish (replica groups: no side stream whose tail would still read theta)
+        RUN(adam_prepare(S, st));
+        upd = DybWgradUpdate{S.grads, n * sizeof(float), S.theta, S.theta, 0.f, &S.fused_spans};
+        upd.adam_m = S.adam_m; upd.adam_v = S.adam_v; upd.adam_sc = S.adam_sc;
+        upd.b1 = (float)S.beta1; upd.b2 = (float)S.beta2; upd.eps = (float)S.eps;
+      }
+      DybWgradUpdateScope fuse(upd);
       RUN(pass_backward(S, S.main, cur, S.grads, st, aux));
     }
     if (i == 0 && side) {

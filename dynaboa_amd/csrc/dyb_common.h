@@ -174,7 +174,21 @@ struct DybConvSync {
   unsigned* ctr;
   int nwords;
 };
-// weight-update scope (igemm_conv.hip "fuse_fast"): see DybWgradUpdateScope's definition there
+// torch.optim.Adam, single tensor, no amsgrad / weight decay (reference base_adaptor.py:126, dynaboa_benchmark.py:149-151):
+// exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size).
+// ONE definition for the streaming kernels (optim.hip) and the weight-gradient epilogue (igemm_tp.inc "fuse_adam"): the two must round alike.
+// Every rounding is spelled out (contraction off, the three multiply-adds as explicit fmaf): left to the compiler's contraction pass the
+// same source rounded differently in the two call sites (1 ulp on a few elements per million: 4e-8 of |theta| after three frames, s7).
+__device__ __forceinline__ void dyb_adam_one(float& p, float g, float& m, float& v, float b1, float b2, float step_size, float bc2_sqrt,
+                                             float eps) {
+#pragma clang fp contract(off)
+  m = fmaf(1.f - b1, g - m, m);
+  const float g1 = (1.f - b2) * g;
+  v = fmaf(g1, g, v * b2);
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = fmaf(-step_size, m / denom, p);
+}
+// weight-update scope (igemm_conv.hip "fuse_fast" / "fuse_adam"): see DybWgradUpdateScope's definition there
 struct DybSpan {
   size_t off, n;         // floats, relative to the gradient arena
 };
@@ -185,6 +199,12 @@ struct DybWgradUpdate {
   float* p_next;         // where p_cur - lr * g goes
   float lr;
   std::vector<DybSpan>* spans;   // fused spans are appended here (may be NULL)
+  // Adam instead of the fast-weight step ("fuse_adam"): p_next == p_cur = theta, updated in place from the accumulators together with
+  // the moments; adam_sc = two floats (step_size, bc2_sqrt) inside a PER-REPLICA arena (each replica's own bias corrections)
+  float* adam_m = nullptr;
+  float* adam_v = nullptr;
+  const float* adam_sc = nullptr;
+  float b1 = 0.f, b2 = 0.f, eps = 0.f;
 };
 // segment list of a streaming fast-weight launch (optim.hip dyb_fastweight_update_segs): float4 units relative to the arena base
 #define DYB_FW_MAX_SEGS 64

@@ -73,6 +73,10 @@ struct IgemmArgs {
   const float* A2;       // operand PAIR (latency form, no fused loaders): out = A (x) B + A2 (x) B2 as ONE K loop - K-tiles [0, ktiles1)
   const float* B2;       // read (A, B), K-tiles [ktiles1, ktiles) read (A2, B2) at tile index - ktiles1.  The tangent passes of the exact
   int ktiles1;           // Hessian-vector product are made of such pairs (hvp_engine.inc); ktiles1 == ktiles: a plain conv
+  float* adam_m;         // throughput weight gradient, nsplit == 1, addend = out = the layer's weights ("fuse_adam"): Adam applied from the
+  float* adam_v;         // accumulators - the moments (same offsets as out) and the weights updated in place, adam_sc = (step_size, bc2_sqrt)
+  const float* adam_sc;  // of THIS replica (a per-replica arena); NULL: no Adam
+  float adam_b1, adam_b2, adam_eps;
   float* fold_out;       // in-kernel split-K fold (nsplit > 1, a counter region in scope): the workgroup that arrives LAST on a tile's counter adds
   const float* fold_addend;  // the tile's nsplit slabs in split order (+ fold_addend) into fold_out and, forward, leaves the tile's GroupNorm
   unsigned* fold_ctr;    // statistics in gn_part; NULL: slabs are left for a fold launch / the consumer.  fold_ctr: one word per tile, zero
@@ -290,6 +294,7 @@ __device__ __forceinline__ void rebase(IgemmArgs& g, const DybRep& R, int rep) {
   g.A = dyb_rb(g.A, R, rep); g.B = dyb_rb(g.B, R, rep); g.out = dyb_rb(g.out, R, rep); g.addend = dyb_rb(g.addend, R, rep);
   g.gn_part = dyb_rb(g.gn_part, R, rep); g.A2 = dyb_rb(g.A2, R, rep); g.B2 = dyb_rb(g.B2, R, rep);
   g.fold_out = dyb_rb(g.fold_out, R, rep); g.fold_addend = dyb_rb(g.fold_addend, R, rep);     // (fold_ctr is shared: indexed by the launch's replica slot)
+  g.adam_m = dyb_rb(g.adam_m, R, rep); g.adam_v = dyb_rb(g.adam_v, R, rep); g.adam_sc = dyb_rb(g.adam_sc, R, rep);
 }
 __device__ __forceinline__ void rebase(GnBwdFuse& f, const DybRep& R, int rep) {
   f.y = dyb_rb(f.y, R, rep); f.stats = dyb_rb(f.stats, R, rep); f.gpart = dyb_rb(f.gpart, R, rep); f.gamma = dyb_rb(f.gamma, R, rep);
@@ -1254,7 +1259,7 @@ static thread_local DybConvSync t_conv_sync = {nullptr, 0};
 // reference dynaboa_benchmark.py:136,140) fused into the epilogue: one read of the current weights and one write of the new ones instead
 // of writing g and a streaming pass reading p and g and writing p'.  The span is appended to `spans` so that the caller's streaming
 // pass can leave it out.  First order only (the inner gradients have no other reader).
-static thread_local DybWgradUpdate t_wupd = {nullptr, 0, nullptr, nullptr, 0.f, nullptr};
+static thread_local DybWgradUpdate t_wupd = {};
 DybWgradUpdateScope::DybWgradUpdateScope(const DybWgradUpdate& u) : saved(t_wupd) { t_wupd = u; }
 DybWgradUpdateScope::~DybWgradUpdateScope() { t_wupd = saved; }
 static std::vector<DybSpan> t_debug_spans;
@@ -1262,9 +1267,18 @@ static std::vector<DybSpan> t_debug_spans;
 // reports how many launches took the fused form since the scope was set
 extern "C" int dyb_debug_set_wgrad_update(const float* grads, size_t bytes, const float* p_cur, float* p_next, float lr) {
   t_debug_spans.clear();
-  if (!grads) { t_wupd = DybWgradUpdate{nullptr, 0, nullptr, nullptr, 0.f, nullptr}; return DYB_OK; }
+  if (!grads) { t_wupd = DybWgradUpdate{}; return DYB_OK; }
   DYB_REQUIRE(bytes && p_cur && p_next, DYB_ERR_ARG);
   t_wupd = DybWgradUpdate{grads, bytes, p_cur, p_next, lr, &t_debug_spans};
+  return DYB_OK;
+}
+// the same for Adam ("fuse_adam"): theta / m / v updated in place from the accumulators; sc = device pointer to (step_size, bc2_sqrt)
+extern "C" int dyb_debug_set_wgrad_adam(const float* grads, size_t bytes, float* theta, float* m, float* v, const float* sc, float b1, float b2,
+                                        float eps) {
+  t_debug_spans.clear();
+  DYB_REQUIRE(grads && bytes && theta && m && v && sc, DYB_ERR_ARG);
+  t_wupd = DybWgradUpdate{grads, bytes, theta, theta, 0.f, &t_debug_spans};
+  t_wupd.adam_m = m; t_wupd.adam_v = v; t_wupd.adam_sc = sc; t_wupd.b1 = b1; t_wupd.b2 = b2; t_wupd.eps = eps;
   return DYB_OK;
 }
 extern "C" int dyb_debug_wgrad_update_spans() { return (int)t_debug_spans.size(); }
@@ -1516,7 +1530,7 @@ extern "C" size_t dyb_conv_timing_table(char* buf, size_t cap) {
 }
 
 // a (start, stop) event pair + the launch's algorithmic flop / bytes booked, when a timing scope is open
-static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, char tag = '?', int nsplit = 1) {
+static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, char tag = '?', int nsplit = 1, int fused_update = 0) {
   if (!g_timing) return;                      // unlocked fast path when no scope is open
   std::lock_guard<std::mutex> lock(g_timing_mu);
   if (!g_timing || g_timing->used + 2 > g_timing->ev.size()) return;
@@ -1529,7 +1543,10 @@ static void timing_acquire(const ConvDesc& d, hipEvent_t* ev0, hipEvent_t* ev1, 
   const double fl = nrep * 2.0 * px * d.K * d.R * d.S * creal;
   g_timing->rec.push_back(IgemmTimingRec{tag, nsplit, (int)nrep, d, fl});
   g_timing->flop += fl;
-  g_timing->bytes += nrep * 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K + px * d.K);
+  // operands once + result once; a weight gradient that writes the fast weights itself ("fuse_fast", 1) also reads the current weights, one
+  // that applies Adam ("fuse_adam", 2) reads and writes the weights and both moments instead of writing the gradient
+  const double wpass = fused_update == 2 ? 6.0 : fused_update == 1 ? 2.0 : 1.0;
+  g_timing->bytes += nrep * 4.0 * ((double)d.N * d.H * d.W * creal + (double)d.R * d.S * creal * d.K * wpass + px * d.K);
 }
 
 // ---- phase probe of the throughput kernel (tools/tp_probe.py) ------------------------------------------------------------
@@ -1685,6 +1702,11 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
       g.out = t_wupd.p_next + off;
       g.addend = t_wupd.p_cur + off;
       g.out_scale = -t_wupd.lr;
+      if (t_wupd.adam_m) {
+        g.adam_m = t_wupd.adam_m + off; g.adam_v = t_wupd.adam_v + off; g.adam_sc = t_wupd.adam_sc;
+        g.adam_b1 = t_wupd.b1; g.adam_b2 = t_wupd.b2; g.adam_eps = t_wupd.eps;
+        g.out_scale = 0.f;                  // (only marks the launch as a fused update for the byte accounting)
+      }
       if (t_wupd.spans) t_wupd.spans->push_back(DybSpan{off, per});
     }
   }
@@ -1711,6 +1733,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   }
   const bool bf = dyb_bf16_current();
   DYB_REQUIRE(!bf || pipe != 0, DYB_ERR_UNSUPPORTED);
+  DYB_REQUIRE(!g.adam_m || pipe != 0, DYB_ERR_UNSUPPORTED);        // (the Adam epilogue lives in the pipelined forms)
   GnFwdFuse nf{};
   if (nfuse) nf = *nfuse;
   DYB_REQUIRE(!nfuse || d.N <= 64, DYB_ERR_UNSUPPORTED);
@@ -1722,7 +1745,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
     if (want > lds_static) lds_pad = want - lds_static;
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 't' : mode == MODE_DGRAD ? 'u' : 'v', g.nsplit);
+  timing_acquire(d, &ev0, &ev1, mode == MODE_FWD ? 't' : mode == MODE_DGRAD ? 'u' : 'v', g.nsplit, g.adam_m ? 2 : (g.out_scale != 1.f ? 1 : 0));
 #define DYB_TP_LAUNCH3(M_, FA_, WM_, WN_, P_)                                                                                      \
   do {                                                                                                                             \
     if (ev0) hipExtLaunchKernelGGL((igemm_tp_kernel<M_, FA_, WM_, WN_, P_>), grid, dim3(256), lds_pad, st, ev0, ev1, 0, g, nf, R); \

@@ -66,10 +66,7 @@ __global__ __launch_bounds__(256) void fastweight_segs_kernel(const float4* __re
     out[base + i] = a;
   }
 }
-int dyb_fastweight_update_segs(const float* p, const float* g, float* out, float lr, const DybFwSegs& segs, hipStream_t st) {
-  DYB_REQUIRE(p && g && out && segs.n >= 1 && segs.n <= DYB_FW_MAX_SEGS, DYB_ERR_ARG);
-  DybFwSegs t = segs;
-  // workgroups per segment: one per 1024 float4 (16 KB), at least one, the launch as a whole within the streaming cap
+static void fw_segs_blocks(DybFwSegs& t) {
   size_t total4 = 0;
   for (unsigned i = 0; i < t.n; ++i) total4 += t.count4[i];
   const size_t want = (total4 + 1023) / 1024;
@@ -81,8 +78,14 @@ int dyb_fastweight_update_segs(const float* p, const float* g, float* out, float
     acc += nb < 1 ? 1 : nb;
   }
   t.blk[t.n] = acc;
+}
+int dyb_fastweight_update_segs(const float* p, const float* g, float* out, float lr, const DybFwSegs& segs, hipStream_t st) {
+  DYB_REQUIRE(p && g && out && segs.n >= 1 && segs.n <= DYB_FW_MAX_SEGS, DYB_ERR_ARG);
+  DybFwSegs t = segs;
+  // workgroups per segment: one per 1024 float4 (16 KB), at least one, the launch as a whole within the streaming cap
+  fw_segs_blocks(t);
   const DybRep& Rp = dyb_rep_current();
-  hipLaunchKernelGGL(fastweight_segs_kernel, dim3(acc, 1, Rp.n), dim3(256), 0, st, (const float4*)p, (const float4*)g, (float4*)out, lr, t, Rp);
+  hipLaunchKernelGGL(fastweight_segs_kernel, dim3(t.blk[t.n], 1, Rp.n), dim3(256), 0, st, (const float4*)p, (const float4*)g, (float4*)out, lr, t, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
@@ -90,15 +93,7 @@ extern "C" int dyb_fastweight_update(const float* p, const float* g, float* out,
   return dyb_fastweight_update3(p, g, nullptr, nullptr, out, lr, n, st);
 }
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float step_size,
-                                         float bc2_sqrt, float eps) {
-  // exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
-  // denom = sqrt(v)/bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size)
-  m = m + (1.f - b1) * (g - m);
-  v = v * b2 + (1.f - b2) * g * g;
-  float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - step_size * (m / denom);
-}
+#define adam_one dyb_adam_one      // (dyb_common.h: shared with the weight-gradient epilogue)
 // bias corrections per PHYSICAL replica: sequence replicas stepped in lockstep may have taken different numbers of Adam steps
 // (the dynamic-BOA loop repeats the outer step for some of them only; sequences of different lengths)
 struct AdamRepScal {
@@ -121,6 +116,55 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2_sqrt, eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
   }
+}
+// Adam over a LIST of arena segments (see fastweight_segs_kernel): the spans whose weight gradient applied Adam itself ("fuse_adam") left out
+__global__ __launch_bounds__(256) void adam_segs_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                        float4* __restrict__ v, float b1, float b2, AdamRepScal sc, float eps, DybFwSegs t,
+                                                        DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, m); DYB_RB(Rp, v);
+  const float step_size = sc.step_size[dyb_rep], bc2_sqrt = sc.bc2_sqrt[dyb_rep];
+  const unsigned b = blockIdx.x;
+  unsigned s = 0;
+  while (s + 1 < t.n && b >= t.blk[s + 1]) ++s;
+  const unsigned nb = t.blk[s + 1] - t.blk[s], lb = b - t.blk[s];
+  const size_t base = t.start4[s];
+  for (size_t i = (size_t)lb * 256 + threadIdx.x; i < t.count4[s]; i += (size_t)nb * 256) {
+    float4 pp = p[base + i], gg = g[base + i], mm = m[base + i], vv = v[base + i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2_sqrt, eps);
+    adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2_sqrt, eps);
+    p[base + i] = pp; m[base + i] = mm; v[base + i] = vv;
+  }
+}
+int dyb_adam_step_segs(float* p, const float* g, float* m, float* v, float beta1, float beta2, const float* step_size, const float* bc2_sqrt,
+                       float eps, const DybFwSegs& segs, hipStream_t st) {
+  DYB_REQUIRE(p && g && m && v && step_size && bc2_sqrt && segs.n >= 1 && segs.n <= DYB_FW_MAX_SEGS, DYB_ERR_ARG);
+  DybFwSegs t = segs;
+  fw_segs_blocks(t);
+  const DybRep& Rp = dyb_rep_current();
+  AdamRepScal sc;
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size[r]; sc.bc2_sqrt[r] = bc2_sqrt[r]; }
+  hipLaunchKernelGGL(adam_segs_kernel, dim3(t.blk[t.n], 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, beta1,
+                     beta2, sc, eps, t, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
+}
+// each replica's (step_size, bc2_sqrt) into dst[0..1] of ITS copy of a per-replica arena: what a weight-gradient epilogue that applies Adam reads
+__global__ void adam_scalars_kernel(float* __restrict__ dst, AdamRepScal sc, DybRep Rp) {
+  DYB_REP_PROLOGUE(Rp);
+  DYB_RB(Rp, dst);
+  if (threadIdx.x == 0) { dst[0] = sc.step_size[dyb_rep]; dst[1] = sc.bc2_sqrt[dyb_rep]; }
+}
+int dyb_adam_write_scalars(float* dst, const float* step_size, const float* bc2_sqrt, hipStream_t st) {
+  DYB_REQUIRE(dst && step_size && bc2_sqrt, DYB_ERR_ARG);
+  const DybRep& Rp = dyb_rep_current();
+  AdamRepScal sc;
+  for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size[r]; sc.bc2_sqrt[r] = bc2_sqrt[r]; }
+  hipLaunchKernelGGL(adam_scalars_kernel, dim3(1, 1, Rp.n), dim3(64), 0, st, dst, sc, Rp);
+  DYB_CHECK_LAUNCH();
+  return DYB_OK;
 }
 // Adam on a gradient that is still in two pieces, g - alpha * h: the last accumulation of the second-order outer gradient
 // (v_0 = v_1 - lr * H v_1, dynaboa_amd/maml.py) is formed here instead of in a pass of its own, so the outer step of the

@@ -353,6 +353,12 @@ int dyb_debug_set_conv_sync(unsigned* ctr, int nwords);
  * stepper opens such a scope around every lower level's backward (csrc/adapt_step.hip). */
 int dyb_debug_set_wgrad_update(const float* grads, size_t bytes, const float* p_cur, float* p_next, float lr);
 int dyb_debug_wgrad_update_spans(void);
+/* the same for Adam ("fuse_adam"): an unsplit throughput-form weight gradient whose result would land inside [grads, grads + bytes) applies
+ * torch.optim.Adam's single-tensor step (reference base_adaptor.py:126, dynaboa_benchmark.py:149-151) to theta / m / v IN PLACE at the same
+ * offset from its accumulators; sc = device pointer to (step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)).  Reset with
+ * dyb_debug_set_wgrad_update(NULL, ...).  The frame stepper opens such a scope around the outer level's backward of a replica group. */
+int dyb_debug_set_wgrad_adam(const float* grads, size_t bytes, float* theta, float* m, float* v, const float* sc, float beta1, float beta2,
+                             float eps);
 int dyb_set_option(const char* name, int value);
 int dyb_get_option(const char* name, int* value);
 

@@ -108,6 +108,54 @@ def case_conv_wgrad_update(be, N, H, W, C, K, R, stride, pad, lr=0.37, seed=0):
     return fused
 
 
+def case_conv_wgrad_adam(be, N, H, W, C, K, R, stride, pad, seed=0, t_step=3):
+    """"fuse_adam" (round 6): with an Adam scope set, an UNSPLIT throughput-form weight gradient applies torch.optim.Adam's step to theta /
+    exp_avg / exp_avg_sq in place from its accumulators (igemm_tp.inc).  Against torch.optim.Adam itself on torch's gradient (step
+    t_step: bias corrections as the stepper computes them); the gradient buffer must stay untouched.  -> launches that took the form."""
+    rng = _rng(seed)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    dy = (rng.standard_normal((N, Ho, Wo, K)) * 0.1).astype(np.float32)
+    theta = rng.standard_normal((R, R, C, K)).astype(np.float32)
+    m0 = (rng.standard_normal(theta.shape) * 0.05).astype(np.float32)
+    v0 = (rng.random(theta.shape) * 0.01).astype(np.float32)
+    lr, b1, b2, eps = 3e-3, 0.5, 0.9, 1e-8
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    wt = torch.zeros(K, C, R, R, requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv2d(xt, wt, stride=stride, padding=pad), [wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+    g = gw.permute(2, 3, 1, 0).contiguous()
+    # torch.optim.Adam at step t_step with these moments (single-tensor formula)
+    p = torch.nn.Parameter(torch.from_numpy(theta.copy()))
+    opt = torch.optim.Adam([p], lr=lr, betas=(b1, b2), eps=eps, foreach=False)
+    opt.state[p] = dict(step=torch.tensor(float(t_step - 1)), exp_avg=torch.from_numpy(m0.copy()), exp_avg_sq=torch.from_numpy(v0.copy()))
+    p.grad = g.clone()
+    opt.step()
+    sc = np.array([lr / (1.0 - b1 ** t_step), np.sqrt(1.0 - b2 ** t_step)], np.float32)
+    wsb = be.lib.dyb_conv2d_workspace_bytes(N, H, W, C, K, R, R, stride, pad)
+    ws = be.empty((max(wsb, 16) // 4,))
+    marker = np.full(theta.shape, 7.25, np.float32)
+    X, DY, TH, M, V, SC = be.dev(x), be.dev(dy), be.dev(theta), be.dev(m0), be.dev(v0), be.dev(sc)
+    dw_ = be.dev(marker)
+    check(be.lib.dyb_debug_set_wgrad_adam(be.ptr(dw_), theta.size * 4, be.ptr(TH), be.ptr(M), be.ptr(V), be.ptr(SC), b1, b2, eps), "set_wgrad_adam")
+    try:
+        check(be.lib.dyb_conv2d_nhwc_wgrad(be.ptr(X), be.ptr(DY), be.ptr(dw_), N, H, W, C, K, R, R, stride, pad, be.ptr(ws), wsb, be.stream),
+              "conv wgrad (Adam scope)")
+        be.sync()
+        fused = int(be.lib.dyb_debug_wgrad_update_spans())
+    finally:
+        be.lib.dyb_debug_set_wgrad_update(None, 0, None, None, 0.0)
+    if fused:
+        assert np.array_equal(be.host(dw_), marker), "the gradient buffer was written although Adam was fused"
+        st = opt.state[p]
+        e = dict(theta=rel_err(be.host(TH) - theta, p.detach().numpy() - theta), m=rel_err(be.host(M), st["exp_avg"].numpy()),
+                 v=rel_err(be.host(V), st["exp_avg_sq"].numpy()))
+        assert max(e.values()) < 5 * TOL, e
+    else:
+        assert rel_err(be.host(dw_), g.numpy()) < TOL
+        assert np.array_equal(be.host(TH), theta)
+    return fused
+
+
 def case_conv_inkernel_fold(be, N, H, W, C, K, R, stride, pad, seed=0):
     """The same three checks with a counter region in scope: a launch that splits K lets the workgroup that arrives last on a tile add
     the tile's slabs itself (igemm_tp.inc / igemm_conv.hip epilogues) instead of leaving them to a fold launch.  The counters must be

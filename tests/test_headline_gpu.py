@@ -213,13 +213,16 @@ def test_fast_weights_from_the_weight_gradient_epilogue_are_bit_identical_to_the
     """"fuse_fast" (round 6): on the throughput schedule a lower level's unsplit weight gradients write theta_next = theta_cur - fastlr * g
     from their accumulators (the levels ping-pong between two fast-weight buffers; the streaming pass covers the rest of the arena by
     segments) - against the round-5 form (every gradient to HBM, one streaming pass over the whole arena): S = 8, three frames of
-    3 inner + 1 outer step - weights, Adam moments and metrics bit for bit."""
+    3 inner + 1 outer step - weights, Adam moments and metrics bit for bit.  The same for "fuse_adam": the OUTER level's unsplit weight
+    gradients apply Adam to theta / exp_avg / exp_avg_sq in place from their accumulators (dyb_adam_one, shared with the streaming kernel),
+    the streaming Adam pass covers the remaining segments - all four combinations of the two switches must agree bit for bit."""
     from dynaboa_amd import native_step as NS
     S, NF = 8, 3
     frames = _frames(S, NF)
     outs = []
-    for fuse in ("0", "1"):
+    for fuse, adam in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
         monkeypatch.setenv("DYB_FUSE_FAST", fuse)           # read when the stepper is created
+        monkeypatch.setenv("DYB_FUSE_ADAM", adam)           # the outer level's weight gradients apply Adam themselves
         ads = [_mk(r) for r in range(S)]
         grp = NS.ReplicaGroup(ads, NF)
         for step in range(NF):
@@ -230,5 +233,6 @@ def test_fast_weights_from_the_weight_gradient_epilogue_are_bit_identical_to_the
                      torch.stack([s_["exp_avg_sq"] for s_ in st]),
                      torch.tensor(np.array([np.ravel(np.array(fl[r]["mpjpe"], np.float64)) for r in range(S)]))])
         del grp, ads
-    for a, b in zip(*outs):
-        assert torch.equal(a, b), float((a.double() - b.double()).norm() / b.double().norm())
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b), float((a.double() - b.double()).norm() / b.double().norm())

@@ -436,8 +436,10 @@ def test_conv_weight_gradient_writes_fast_weights(be, cfg):
     try:
         be.lib.dyb_set_option(b"tp_grid", 1)
         assert K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg)) == 1
+        assert K.case_conv_wgrad_adam(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + 2) == 1       # "fuse_adam": Adam from the accumulators
         be.lib.dyb_set_option(b"tp_grid", 4096)
         K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + 1)
+        K.case_conv_wgrad_adam(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + 3)
     finally:
         be.lib.dyb_set_option(b"tp_grid", 512)
         be.lib.dyb_set_option(b"rep_split", 0)
