@@ -188,6 +188,8 @@ __device__ __forceinline__ void dyb_adam_one(float& p, float g, float& m, float&
   const float denom = sqrtf(v) / bc2_sqrt + eps;
   p = fmaf(-step_size, m / denom, p);
 }
+// the MAML fast-weight step p' = p - lr * g as ONE fused multiply-add everywhere (streaming kernels, conv and linear weight-gradient epilogues)
+__device__ __forceinline__ float dyb_fast_one(float p, float g, float lr) { return fmaf(-lr, g, p); }
 // weight-update scope (igemm_conv.hip "fuse_fast" / "fuse_adam"): see DybWgradUpdateScope's definition there
 struct DybSpan {
   size_t off, n;         // floats, relative to the gradient arena
@@ -213,6 +215,7 @@ struct DybFwSegs {
   unsigned blk[DYB_FW_MAX_SEGS + 1];       // filled by the launcher
   unsigned start4[DYB_FW_MAX_SEGS], count4[DYB_FW_MAX_SEGS];
 };
+const DybWgradUpdate& dyb_wgrad_update_current();      // the calling thread's scope (grads == NULL: none)
 struct DybWgradUpdateScope {
   DybWgradUpdate saved;
   explicit DybWgradUpdateScope(const DybWgradUpdate& u);

@@ -743,7 +743,10 @@ __global__ __launch_bounds__(256) void igemm_mfma_kernel(IgemmArgs g, GnBwdFuse 
         for (int j = 0; j < 4; ++j) a[j] = tp_mask4(*reinterpret_cast<const float4*>(addp + (vo[j] != TP_OOB ? vo[j] / 4 : 0)), vo[j] != TP_OOB);
         // (pieces past the end stay exact zeros: the GroupNorm statistics below sum all four pieces - ADVICE r5)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w; }
+        for (int j = 0; j < 4; ++j) {                    // addend + out_scale * tile (out_scale 1: the plain sum, bit for bit)
+          v[j].x = fmaf(g.out_scale, v[j].x, a[j].x); v[j].y = fmaf(g.out_scale, v[j].y, a[j].y);
+          v[j].z = fmaf(g.out_scale, v[j].z, a[j].z); v[j].w = fmaf(g.out_scale, v[j].w, a[j].w);
+        }
       }
       if constexpr (MODE == MODE_FWD) {
         if (g.gn_part != nullptr && (g.nsplit == 1 || fold)) {
@@ -1166,8 +1169,10 @@ __global__ __launch_bounds__(256) void igemm_k4_dgrad_kernel(K4DgradArgs g, GnBw
 }
 
 // out[i] = sum_z slab[z][i] (+ addend[i]);  n4 = element count / 4
+// out = addend + scale * sum_z slabs[z] (scale 1: the plain fold; -fastlr with addend = the current weights: the fast-weight step of a
+// SPLIT weight gradient, "fuse_fast")
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ slabs, const float4* __restrict__ addend,
-                                                             float4* __restrict__ out, int nsplit, size_t n4, DybRep R) {
+                                                             float4* __restrict__ out, int nsplit, size_t n4, DybRep R, float scale) {
   DYB_REP_PROLOGUE(R);
   DYB_RB(R, slabs); DYB_RB(R, addend); DYB_RB(R, out);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1189,7 +1194,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
     }
     if (addend) {
       float4 t = addend[i];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      s.x = fmaf(scale, s.x, t.x); s.y = fmaf(scale, s.y, t.y); s.z = fmaf(scale, s.z, t.z); s.w = fmaf(scale, s.w, t.w);
     }
     out[i] = s;
   }
@@ -1206,6 +1211,7 @@ static int fill_args(IgemmArgs& g, const ConvDesc& d, int mode) {
   DYB_REQUIRE(d.stride == 1 || d.stride == 2, DYB_ERR_UNSUPPORTED);
   g.N = d.N; g.H = d.H; g.W = d.W; g.C = d.C; g.K = d.K; g.R = d.R; g.S = d.S;
   g.stride = d.stride; g.pad = d.pad;
+  g.out_scale = 1.f;
   g.Ho = conv_out_dim(d.H, d.R, d.stride, d.pad);
   g.Wo = conv_out_dim(d.W, d.S, d.stride, d.pad);
   g.logC = dyb_ilog2(d.C); g.logK = dyb_ilog2(d.K);
@@ -1262,6 +1268,7 @@ static thread_local DybConvSync t_conv_sync = {nullptr, 0};
 static thread_local DybWgradUpdate t_wupd = {};
 DybWgradUpdateScope::DybWgradUpdateScope(const DybWgradUpdate& u) : saved(t_wupd) { t_wupd = u; }
 DybWgradUpdateScope::~DybWgradUpdateScope() { t_wupd = saved; }
+const DybWgradUpdate& dyb_wgrad_update_current() { return t_wupd; }
 static std::vector<DybSpan> t_debug_spans;
 // tests / lab: a scope for the calling thread's plain weight-gradient calls until reset with grads = NULL; dyb_debug_wgrad_update_spans
 // reports how many launches took the fused form since the scope was set
@@ -1695,6 +1702,19 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
   g.out = (split || g.compact) ? reinterpret_cast<float*>(ws) : out;          // (compact: always through the scatter fold)
   g.addend = (split || g.compact) ? nullptr : addend;
   g.out_scale = 1.f;
+  // (a SPLIT weight gradient whose slabs the fold launch below adds: the fast-weight step rides in that launch - not Adam, not the in-kernel fold)
+  const float* red_addend = addend;
+  float* red_out = out;
+  float red_scale = 1.f;
+  if (mode == MODE_WGRAD && t_wupd.grads && !t_wupd.adam_m && split && !g.compact && !addend && !raw_slabs_out &&
+      !((switches().tp_fold.load(std::memory_order_relaxed) >> mode) & 1)) {
+    const char *lo = reinterpret_cast<const char*>(t_wupd.grads), *o = reinterpret_cast<const char*>(out);
+    if (o >= lo && o + per * sizeof(float) <= lo + t_wupd.bytes) {
+      const size_t off = (size_t)(o - lo) / sizeof(float);
+      red_out = t_wupd.p_next + off; red_addend = t_wupd.p_cur + off; red_scale = -t_wupd.lr;
+      if (t_wupd.spans) t_wupd.spans->push_back(DybSpan{off, per});
+    }
+  }
   if (mode == MODE_WGRAD && t_wupd.grads && !split && !g.compact && !addend) {
     const char *lo = reinterpret_cast<const char*>(t_wupd.grads), *o = reinterpret_cast<const char*>(out);
     if (o >= lo && o + per * sizeof(float) <= lo + t_wupd.bytes) {
@@ -1804,7 +1824,7 @@ static int run_igemm_tp(int mode, const ConvDesc& d, IgemmArgs g, float* out, co
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
-                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4, R);
+                       reinterpret_cast<const float4*>(red_addend), reinterpret_cast<float4*>(red_out), g.nsplit, n4, R, red_scale);
     DYB_CHECK_LAUNCH();
   }
   return DYB_OK;
@@ -1850,6 +1870,22 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
   if (kfold) {
     g.fold_out = out; g.fold_addend = addend; g.fold_ctr = t_conv_sync.ctr;
     switches().stat_folds.fetch_add(1, std::memory_order_relaxed);
+  }
+  // "fuse_fast" in the latency form (one sequence): the finished weight-gradient tile - unsplit, or folded in-kernel by the last workgroup
+  // to arrive, or folded by the fold launch below - leaves p_next = p_cur - lr * g instead of g (see DybWgradUpdateScope)
+  const float* red_addend = addend;
+  float* red_out = out;
+  float red_scale = 1.f;
+  if (mode == MODE_WGRAD && t_wupd.grads && !t_wupd.adam_m && !dyb_bf16_current() && !A2 && !addend && !raw_slabs_out) {
+    const char *lo = reinterpret_cast<const char*>(t_wupd.grads), *o = reinterpret_cast<const char*>(out);
+    const size_t cnt = (size_t)g.M * g.Ncols;
+    if (o >= lo && o + cnt * sizeof(float) <= lo + t_wupd.bytes) {
+      const size_t off = (size_t)(o - lo) / sizeof(float);
+      if (!split) { g.out = t_wupd.p_next + off; g.addend = t_wupd.p_cur + off; g.out_scale = -t_wupd.lr; }
+      else if (kfold) { g.fold_out = t_wupd.p_next + off; g.fold_addend = t_wupd.p_cur + off; g.out_scale = -t_wupd.lr; }
+      else { red_out = t_wupd.p_next + off; red_addend = t_wupd.p_cur + off; red_scale = -t_wupd.lr; }
+      if (t_wupd.spans) t_wupd.spans->push_back(DybSpan{off, cnt});
+    }
   }
   g.gn_part = nullptr;
   if (mode == MODE_FWD && stats_part && stats_nrec && lat && d.N == 1 && (!split || kfold) && d.K >= 64 && d.K % 64 == 0 && dyb_is_pow2(d.K) &&
@@ -1900,7 +1936,7 @@ static int run_igemm(int mode, const ConvDesc& d, const float* A, const float* B
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(ws),
-                       reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), g.nsplit, n4, R);
+                       reinterpret_cast<const float4*>(red_addend), reinterpret_cast<float4*>(red_out), g.nsplit, n4, R, red_scale);
     DYB_CHECK_LAUNCH();
   }
   return DYB_OK;
@@ -2112,7 +2148,7 @@ int dyb_splitk_fold(const float* slabs, int nslabs, size_t n, const float* adden
   if (blocks > 2048) blocks = 2048;
   const DybRep& R = dyb_rep_current();
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, R.n), dim3(256), 0, st, reinterpret_cast<const float4*>(slabs),
-                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4, R);
+                     reinterpret_cast<const float4*>(addend), reinterpret_cast<float4*>(out), nslabs, n4, R, 1.f);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

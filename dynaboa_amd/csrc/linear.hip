@@ -9,6 +9,8 @@
 //
 // Weight layout is the reference's (out_features, in_features) row-major with the row stride
 // `ldw` padded to a multiple of 4 floats (fc1: 2205 -> 2208); pad columns are kept at zero.
+#include <stdlib.h>
+
 #include "dyb_common.h"
 
 #define LIN_BT 4   // batch tile held in registers
@@ -220,10 +222,22 @@ struct OuterArgs {
 // profiles/r02_s5_kernel_stats_S32.csv).  Eight rows per thread = 8x fewer workgroups, x loaded once per (t, b) instead of
 // once per row; every output element still sums its (t, b) terms in the same order: results unchanged bit for bit.
 #define OUTER_ROWS 8
+// The weight update of the calling thread's scope (DybWgradUpdateScope, round 6) applied to the finished gradient element instead of storing
+// it: kind 1 = MAML fast weights p_next = p_cur - lr * g, kind 2 = Adam on (p, m, v) in place (dyb_adam_one) - the regressor's fc1 / fc2 /
+// decoder matrices are 13 % of the parameters, each of their gradient elements is complete in ONE work-item here.  Biases keep the streaming pass.
+struct OuterUpd {
+  int kind;
+  const float* p_cur;
+  float *p_next, *m, *v;
+  const float* sc;
+  float lr, b1, b2, eps;
+};
 __global__ __launch_bounds__(256) void linear_outer_kernel(OuterArgs a, int T, int B, int I, int O, float* __restrict__ dw,
-                                                           int ldw, float* __restrict__ db, DybRep R) {
+                                                           int ldw, float* __restrict__ db, OuterUpd u, DybRep R) {
   DYB_REP_PROLOGUE(R);
   DYB_RB(R, dw); DYB_RB(R, db);
+  if (u.kind) { u.p_cur = dyb_rb(u.p_cur, R, dyb_rep); u.p_next = dyb_rb(u.p_next, R, dyb_rep); u.m = dyb_rb(u.m, R, dyb_rep);
+                u.v = dyb_rb(u.v, R, dyb_rep); u.sc = dyb_rb(u.sc, R, dyb_rep); }
   if (dyb_rep) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) { a.dy[t] = dyb_rb(a.dy[t], R, dyb_rep); a.x[t] = dyb_rb(a.x[t], R, dyb_rep); }
@@ -255,9 +269,34 @@ __global__ __launch_bounds__(256) void linear_outer_kernel(OuterArgs a, int T, i
   for (int j = 0; j < OUTER_ROWS; ++j) {
     const int o = o0 + 4 * j;
     if (o >= O) continue;
-    if (live) *reinterpret_cast<float4*>(dw + (size_t)o * ldw + (size_t)i4 * 4) = acc[j];
+    const size_t e = (size_t)o * ldw + (size_t)i4 * 4;
+    if (live) {
+      if (u.kind == 1) {
+        float4 p = *reinterpret_cast<const float4*>(u.p_cur + e);
+        p.x = dyb_fast_one(p.x, acc[j].x, u.lr); p.y = dyb_fast_one(p.y, acc[j].y, u.lr);
+        p.z = dyb_fast_one(p.z, acc[j].z, u.lr); p.w = dyb_fast_one(p.w, acc[j].w, u.lr);
+        *reinterpret_cast<float4*>(u.p_next + e) = p;
+      } else if (u.kind == 2) {
+        float4 p = *reinterpret_cast<const float4*>(u.p_cur + e), m = *reinterpret_cast<const float4*>(u.m + e),
+               v = *reinterpret_cast<const float4*>(u.v + e);
+        const float ss = u.sc[0], bc = u.sc[1];
+        dyb_adam_one(p.x, acc[j].x, m.x, v.x, u.b1, u.b2, ss, bc, u.eps);
+        dyb_adam_one(p.y, acc[j].y, m.y, v.y, u.b1, u.b2, ss, bc, u.eps);
+        dyb_adam_one(p.z, acc[j].z, m.z, v.z, u.b1, u.b2, ss, bc, u.eps);
+        dyb_adam_one(p.w, acc[j].w, m.w, v.w, u.b1, u.b2, ss, bc, u.eps);
+        *reinterpret_cast<float4*>(u.p_next + e) = p;
+        *reinterpret_cast<float4*>(u.m + e) = m;
+        *reinterpret_cast<float4*>(u.v + e) = v;
+      } else {
+        *reinterpret_cast<float4*>(dw + e) = acc[j];
+      }
+    }
     if (blockIdx.x == 0 && tx == 0) db[o] = bs[j];
   }
+}
+static bool switches_linear_fuse() {
+  static const int on = [] { const char* e = getenv("DYB_FUSE_LINEAR"); return e ? atoi(e) : 1; }();
+  return on != 0;
 }
 extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, const float* const* xs, const int* ldxs,
                                  int T, int B, int I, int O, float* dw, int ldw, float* db, hipStream_t st) {
@@ -269,8 +308,23 @@ extern "C" int dyb_linear_bwd_dw(const float* const* dys, const int* lddys, cons
     DYB_REQUIRE(a.ldx[t] % 4 == 0, DYB_ERR_UNSUPPORTED);
   }
   const DybRep& R = dyb_rep_current();
+  // a weight-update scope of the calling thread (stepper: a lower level's fast-weight step / the outer level's Adam): the matrix [O][ldw]
+  // is one contiguous tensor of the arena (I == ldw for fc1 / fc2 / the decoder) - updated here, its span reported like a convolution's
+  OuterUpd u{};
+  const DybWgradUpdate& W = dyb_wgrad_update_current();
+  if (W.grads && I == ldw && switches_linear_fuse()) {
+    const char *lo = reinterpret_cast<const char*>(W.grads), *o = reinterpret_cast<const char*>(dw);
+    const size_t cnt = (size_t)O * ldw;
+    if (o >= lo && o + cnt * sizeof(float) <= lo + W.bytes) {
+      const size_t off = (size_t)(o - lo) / sizeof(float);
+      u.kind = W.adam_m ? 2 : 1;
+      u.p_cur = W.p_cur + off; u.p_next = W.p_next + off; u.lr = W.lr;
+      if (W.adam_m) { u.m = W.adam_m + off; u.v = W.adam_v + off; u.sc = W.adam_sc; u.b1 = W.b1; u.b2 = W.b2; u.eps = W.eps; }
+      if (W.spans) W.spans->push_back(DybSpan{off, cnt});
+    }
+  }
   hipLaunchKernelGGL(linear_outer_kernel, dim3(dyb_cdiv(I / 4, 64), dyb_cdiv(O, 4 * OUTER_ROWS), R.n), dim3(256), 0, st, a, T, B, I, O, dw,
-                     ldw, db, R);
+                     ldw, db, u, R);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }

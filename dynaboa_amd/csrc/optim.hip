@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void fastweight_kernel(const float4* __restric
     float4 a = p[i], b = g[i];
     if (g2) { const float4 c = g2[i]; b.x = c.x + b.x; b.y = c.y + b.y; b.z = c.z + b.z; b.w = c.w + b.w; }
     if (g3) { const float4 c = g3[i]; b.x = c.x + b.x; b.y = c.y + b.y; b.z = c.z + b.z; b.w = c.w + b.w; }
-    a.x -= lr * b.x; a.y -= lr * b.y; a.z -= lr * b.z; a.w -= lr * b.w;
+    a.x = dyb_fast_one(a.x, b.x, lr); a.y = dyb_fast_one(a.y, b.y, lr); a.z = dyb_fast_one(a.z, b.z, lr); a.w = dyb_fast_one(a.w, b.w, lr);
     out[i] = a;
   }
 }
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void fastweight_segs_kernel(const float4* __re
   for (size_t i = (size_t)lb * 256 + threadIdx.x; i < t.count4[s]; i += (size_t)nb * 256) {
     float4 a = p[base + i];
     const float4 c = g[base + i];
-    a.x -= lr * c.x; a.y -= lr * c.y; a.z -= lr * c.z; a.w -= lr * c.w;
+    a.x = dyb_fast_one(a.x, c.x, lr); a.y = dyb_fast_one(a.y, c.y, lr); a.z = dyb_fast_one(a.z, c.z, lr); a.w = dyb_fast_one(a.w, c.w, lr);
     out[base + i] = a;
   }
 }

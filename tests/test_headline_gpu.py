@@ -223,6 +223,8 @@ def test_fast_weights_from_the_weight_gradient_epilogue_are_bit_identical_to_the
     for fuse, adam in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
         monkeypatch.setenv("DYB_FUSE_FAST", fuse)           # read when the stepper is created
         monkeypatch.setenv("DYB_FUSE_ADAM", adam)           # the outer level's weight gradients apply Adam themselves
+        # (the regressor's fc1 / fc2 / decoder matrices - 13 % of the parameters - take the same updates in linear_outer_kernel's epilogue
+        # whenever a scope is open: covered by the same comparison against the ("0", "0") run)
         ads = [_mk(r) for r in range(S)]
         grp = NS.ReplicaGroup(ads, NF)
         for step in range(NF):
@@ -236,3 +238,22 @@ def test_fast_weights_from_the_weight_gradient_epilogue_are_bit_identical_to_the
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b), float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def test_fast_weights_from_the_weight_gradient_epilogue_one_sequence(monkeypatch):
+    """"fuse_fast" on the latency schedule (ONE sequence, the literal bs=1 stream): every lower-level weight gradient - unsplit, folded
+    in-kernel or by the fold launch - and the regressor's matrices write the fast weights themselves; against the streaming pass over the
+    whole arena (DYB_FUSE_FAST=0, DYB_FUSE_LINEAR=0): three frames of 3 inner + 1 outer step, weights / Adam moments / metrics bit for bit."""
+    frames = _frames(1, 3)[0]
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DYB_FUSE_FAST", fuse)
+        ad = _mk(0)
+        res = ad.excute(frames, nframes=3)
+        assert ad._native is not None
+        st = ad.optimizer.state[ad.model.module.theta]
+        outs.append([ad.model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                     torch.tensor(np.ravel(np.array(res["mpjpe"], np.float64)))])
+        del ad
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a.double() - b.double()).norm() / b.double().norm())

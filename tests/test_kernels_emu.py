@@ -541,3 +541,26 @@ def test_conv_weight_gradient_writes_fast_weights(be, cfg):
         be.lib.dyb_set_option(b"tp_grid", 512)
         be.lib.dyb_set_option(b"rep_split", 0)
         be.lib.dyb_set_option(b"tp_min", 8)
+
+
+@pytest.mark.parametrize("sync", [0, 1], ids=["fold_launch_or_unsplit", "in_kernel_fold"])
+@pytest.mark.parametrize("cfg", [
+    (1, 7, 7, 128, 256, 3, 1, 1),      # deep reduction over taps: split by the latency policy
+    (1, 14, 14, 64, 64, 1, 1, 0),      # small 1x1
+    (1, 20, 20, 4, 64, 7, 2, 3),       # stem
+    (2, 10, 10, 64, 64, 3, 2, 1),      # stride 2, batch 2
+])
+def test_conv_weight_gradient_writes_fast_weights_latency_form(be, cfg, sync):
+    """"fuse_fast" for ONE sequence (latency form, igemm_mfma_kernel): the finished weight-gradient tile - unsplit, folded by the fold launch
+    (splitk_reduce_kernel: addend + scale * sum of slabs) or, with a counter region in scope, folded in-kernel by the last workgroup to
+    arrive - leaves p_next = p_cur - lr * g; the gradient buffer stays untouched."""
+    import numpy as np
+    N, H, W, C, Kc, R, st, pad = cfg
+    ctr = be.zeros((4096,), dtype=np.uint32)
+    if sync:
+        assert be.lib.dyb_debug_set_conv_sync(be.ptr(ctr), 4096) == 0
+    try:
+        assert K.case_conv_wgrad_update(be, N, H, W, C, Kc, R, st, pad, seed=sum(cfg) + sync) == 1
+    finally:
+        be.lib.dyb_debug_set_conv_sync(None, 0)
+    assert not np.asarray(be.host(ctr)).any()
