@@ -65,6 +65,8 @@ int dyb_adam_step_rep3(float*, const float*, const float*, const float*, float*,
                        hipStream_t);
 int dyb_fastweight_update3(const float*, const float*, const float*, const float*, float*, float, size_t, hipStream_t);
 int dyb_fastweight_update_segs(const float*, const float*, float*, float, const DybFwSegs&, hipStream_t);       // optim.hip
+int dyb_adam_step_rep3_ema(float*, const float*, const float*, const float*, float*, float*, float, float, const float*, const float*, float, size_t,
+                           float*, float, hipStream_t);
 int dyb_adam_step_segs(float*, const float*, float*, float*, float, float, const float*, const float*, float, const DybFwSegs&, hipStream_t);
 int dyb_adam_write_scalars(float*, const float*, const float*, hipStream_t);
 
@@ -303,6 +305,7 @@ struct Stepper {
   // nobody reads theta meanwhile); the streaming Adam pass covers what is left.  The step's bias corrections are fixed BEFORE that
   // backward (adam_prepare) and live, per replica, in adam_sc (two floats of every replica's workspace copy).
   int fuse_adam = 1;
+  int fuse_ema = 1;                // the teacher's EMA inside the Adam pass (default term set)
   float* adam_sc = nullptr;
   bool adam_prepared = false;
   float pre_ss[DYB_MAX_REPLICAS], pre_bc[DYB_MAX_REPLICAS];
@@ -476,6 +479,7 @@ extern "C" int dyb_stepper_create(void* plan, int B, int H, int W, void** out) {
   if (const char* e = getenv("DYB_UPD_LATE")) S->upd_late = atoi(e);
   if (const char* e = getenv("DYB_FUSE_FAST")) S->fuse_fast = atoi(e);
   if (const char* e = getenv("DYB_FUSE_ADAM")) S->fuse_adam = atoi(e);
+  if (const char* e = getenv("DYB_FUSE_EMA")) S->fuse_ema = atoi(e);
   if (const char* e = getenv("DYB_PAR_PASSES")) S->par_passes = atoi(e);
   if (const char* e = getenv("DYB_PAR_MAX_REPLICAS")) S->par_max_replicas = atoi(e);
   if (!S->ev || hipEventCreateWithFlags(&S->e_theta, hipEventDisableTiming) != hipSuccess ||
@@ -526,6 +530,7 @@ extern "C" int dyb_stepper_set_i(void* stepper, const char* key, long long v) {
   else if (k == "upd_late") S->upd_late = (int)v;
   else if (k == "fuse_fast") { DYB_REQUIRE(!S->bound, DYB_ERR_ARG); S->fuse_fast = (int)v; }
   else if (k == "fuse_adam") S->fuse_adam = (int)v;
+  else if (k == "fuse_ema") S->fuse_ema = (int)v;
   else if (k == "metrics") S->metrics = (int)v;
   else if (k == "adam_step") {
     S->adam_t = v;
@@ -892,13 +897,15 @@ static int fastweight_range(Stepper& S, const float* p, float* out, const float*
   return flush();
 }
 // Adam over [lo, hi) minus the spans the outer level's weight gradients updated themselves (S.upd_spans, sorted)
-static int adam_range(Stepper& S, const float* g2, const float* g3, const float* ss, const float* bc, size_t lo, size_t hi, hipStream_t s) {
+static int adam_range(Stepper& S, const float* g2, const float* g3, const float* ss, const float* bc, size_t lo, size_t hi, hipStream_t s,
+                      bool ema = false) {
   bool any = false;
   for (const DybSpan& sp : S.upd_spans)
     if (sp.off < hi && sp.off + sp.n > lo) { any = true; break; }
-  if (!any)
-    return dyb_adam_step_rep3(S.theta + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, S.adam_m + lo, S.adam_v + lo,
-                              (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, hi - lo, s);
+  if (!any)      // (ema: the teacher's EMA of the range in the same pass - "fuse_ema", default term set)
+    return dyb_adam_step_rep3_ema(S.theta + lo, S.grads + lo, g2 ? g2 + lo : nullptr, g3 ? g3 + lo : nullptr, S.adam_m + lo, S.adam_v + lo,
+                                  (float)S.beta1, (float)S.beta2, ss, bc, (float)S.eps, hi - lo, ema ? S.teacher + lo : nullptr, (float)S.alpha, s);
+  DYB_REQUIRE(!ema, DYB_ERR_UNSUPPORTED);
   DYB_REQUIRE(!g2 && !g3 && lo % 4 == 0 && hi % 4 == 0, DYB_ERR_UNSUPPORTED);
   DybFwSegs t{};
   auto flush = [&]() -> int {
@@ -951,8 +958,9 @@ static int late_update(void* user) {
   DybStreamCapScope cap(S.upd_blocks > 0 ? (S.upd_blocks / L.scope.n > 0 ? S.upd_blocks / L.scope.n : 1) : 0);
   const float *g2 = L.g2 ? L.g2 + lo : nullptr, *g3 = L.g3 ? L.g3 + lo : nullptr;
   if (L.adam) {
-    RUN(adam_range(S, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, L.ss, L.bc, lo, lo + n, L.aux));
-    if (L.ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
+    const bool fe = L.ema && S.fuse_ema;
+    RUN(adam_range(S, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, L.ss, L.bc, lo, lo + n, L.aux, fe));
+    if (L.ema && !fe) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, n, L.aux));
   } else {
     RUN(fastweight_range(S, L.p, L.out, g2 ? L.g2 : nullptr, g3 ? L.g3 : nullptr, lo, lo + n, L.aux));
   }
@@ -993,9 +1001,10 @@ static int weight_update(Stepper& S, bool adam, const float* p, float* out, hipS
   }
   auto range = [&](size_t lo, size_t hi, hipStream_t s) -> int {
     if (adam) {
-      RUN(adam_range(S, g2, g3, ss, bc, lo, hi, s));
-      // update_teacher (base_adaptor.py:193-201) of the same range right behind it: the teacher's next reader is a forward too
-      if (ema) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
+      // update_teacher (base_adaptor.py:193-201) of the same range: inside the Adam pass ("fuse_ema"), or right behind it
+      const bool fe = ema && S.fuse_ema;
+      RUN(adam_range(S, g2, g3, ss, bc, lo, hi, s, fe));
+      if (ema && !fe) RUN(dyb_ema_update(S.teacher + lo, S.theta + lo, (float)S.alpha, hi - lo, s));
       return DYB_OK;
     }
     return fastweight_range(S, p, out, g2, g3, lo, hi, s);

@@ -190,6 +190,9 @@ __device__ __forceinline__ void dyb_adam_one(float& p, float g, float& m, float&
 }
 // the MAML fast-weight step p' = p - lr * g as ONE fused multiply-add everywhere (streaming kernels, conv and linear weight-gradient epilogues)
 __device__ __forceinline__ float dyb_fast_one(float p, float g, float lr) { return fmaf(-lr, g, p); }
+// update_teacher (reference base_adaptor.py:193-201): t = alpha * t + (1 - alpha) * p, one rounding of alpha * t and one fused multiply-add,
+// the same in the EMA launch and in the Adam kernel that carries the EMA of the element it has just updated
+__device__ __forceinline__ float dyb_ema_one(float t, float p, float alpha, float om) { return fmaf(om, p, t * alpha); }
 // weight-update scope (igemm_conv.hip "fuse_fast" / "fuse_adam"): see DybWgradUpdateScope's definition there
 struct DybSpan {
   size_t off, n;         // floats, relative to the gradient arena

@@ -102,9 +102,12 @@ struct AdamRepScal {
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, const float4* __restrict__ g2,
                                                    const float4* __restrict__ g3, float4* __restrict__ m,
                                                    float4* __restrict__ v, float b1, float b2, AdamRepScal sc, float eps, size_t n4,
-                                                   DybRep Rp) {
+                                                   float4* __restrict__ teacher, float alpha, DybRep Rp) {
+  // teacher != NULL (round 6): the mean teacher's EMA of the element just updated rides in the same pass (update_teacher follows
+  // optimizer.step() in the reference, dynaboa_benchmark.py:149-153): theta is not streamed a second time
   DYB_REP_PROLOGUE(Rp);
-  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, g2); DYB_RB(Rp, g3); DYB_RB(Rp, m); DYB_RB(Rp, v);
+  DYB_RB(Rp, p); DYB_RB(Rp, g); DYB_RB(Rp, g2); DYB_RB(Rp, g3); DYB_RB(Rp, m); DYB_RB(Rp, v); DYB_RB(Rp, teacher);
+  const float om = 1.f - alpha;
   const float step_size = sc.step_size[dyb_rep], bc2_sqrt = sc.bc2_sqrt[dyb_rep];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
@@ -115,6 +118,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2_sqrt, eps);
     adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2_sqrt, eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
+    if (teacher) {
+      float4 t = teacher[i];
+      t.x = dyb_ema_one(t.x, pp.x, alpha, om); t.y = dyb_ema_one(t.y, pp.y, alpha, om);
+      t.z = dyb_ema_one(t.z, pp.z, alpha, om); t.w = dyb_ema_one(t.w, pp.w, alpha, om);
+      teacher[i] = t;
+    }
   }
 }
 // Adam over a LIST of arena segments (see fastweight_segs_kernel): the spans whose weight gradient applied Adam itself ("fuse_adam") left out
@@ -202,22 +211,26 @@ extern "C" int dyb_adam_step(float* p, const float* g, float* m, float* v, float
   AdamRepScal sc;
   for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size; sc.bc2_sqrt[r] = bc2_sqrt; }
   hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (const float4*)nullptr,
-                     (const float4*)nullptr, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
+                     (const float4*)nullptr, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, (float4*)nullptr, 0.f, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
 }
 // the same with the two bias-correction scalars given per physical replica (host arrays of DYB_MAX_REPLICAS = 64 floats; entries of
 // replicas outside the current launch scope are ignored)
-int dyb_adam_step_rep3(float* p, const float* g, const float* g2, const float* g3, float* m, float* v, float beta1, float beta2,
-                       const float* step_size, const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
+int dyb_adam_step_rep3_ema(float* p, const float* g, const float* g2, const float* g3, float* m, float* v, float beta1, float beta2,
+                           const float* step_size, const float* bc2_sqrt, float eps, size_t n, float* teacher, float alpha, hipStream_t st) {
   DYB_REQUIRE(p && g && m && v && step_size && bc2_sqrt && n % 4 == 0, DYB_ERR_ARG);
   const DybRep& Rp = dyb_rep_current();
   AdamRepScal sc;
   for (int r = 0; r < DYB_MAX_REPLICAS; ++r) { sc.step_size[r] = step_size[r]; sc.bc2_sqrt[r] = bc2_sqrt[r]; }
   hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n / 4), 1, Rp.n), dim3(256), 0, st, (float4*)p, (const float4*)g, (const float4*)g2,
-                     (const float4*)g3, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, Rp);
+                     (const float4*)g3, (float4*)m, (float4*)v, beta1, beta2, sc, eps, n / 4, (float4*)teacher, alpha, Rp);
   DYB_CHECK_LAUNCH();
   return DYB_OK;
+}
+int dyb_adam_step_rep3(float* p, const float* g, const float* g2, const float* g3, float* m, float* v, float beta1, float beta2,
+                       const float* step_size, const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
+  return dyb_adam_step_rep3_ema(p, g, g2, g3, m, v, beta1, beta2, step_size, bc2_sqrt, eps, n, nullptr, 0.f, st);
 }
 int dyb_adam_step_rep(float* p, const float* g, float* m, float* v, float beta1, float beta2, const float* step_size,
                       const float* bc2_sqrt, float eps, size_t n, hipStream_t st) {
@@ -231,8 +244,8 @@ __global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const 
   const float om = 1.f - alpha;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 a = t[i], b = p[i];
-    a.x = a.x * alpha + om * b.x; a.y = a.y * alpha + om * b.y;
-    a.z = a.z * alpha + om * b.z; a.w = a.w * alpha + om * b.w;
+    a.x = dyb_ema_one(a.x, b.x, alpha, om); a.y = dyb_ema_one(a.y, b.y, alpha, om);
+    a.z = dyb_ema_one(a.z, b.z, alpha, om); a.w = dyb_ema_one(a.w, b.w, alpha, om);
     t[i] = a;
   }
 }

@@ -245,3 +245,32 @@ def test_gated_reference_stream_as_replica_0_of_a_group_of_8(tag):
         assert abs(float(np.mean(fl[0]["mpjpe"][s])) - g["mpjpe"][s]) < 1e-3 * g["mpjpe"][s]
         assert abs(float(np.mean(fl[0]["pampjpe"][s])) - g["pampjpe"][s]) < 2e-3 * g["pampjpe"][s]
     assert_final_state_matches_golden(ads[0], g, theta0, dict(inner_step=1), tag=tag)
+
+
+@pytest.mark.parametrize("S", [1, 4])
+def test_teacher_ema_inside_the_adam_pass_is_bit_identical(S, monkeypatch):
+    """"fuse_ema" (round 6): the mean teacher's EMA of an element is formed in the Adam pass that has just updated
+    it (update_teacher follows optimizer.step(), dynaboa_benchmark.py:149-153) instead of a pass of its own re-reading theta - against
+    the two-launch form: default term set, the dynamic loop entered, three frames, one sequence and a group of four (ranged updates):
+    weights, Adam moments, teacher and step counts bit for bit."""
+    from dynaboa_amd import native_step as NS
+    NF = 3
+    frames = _frames(S, NF)
+    opts = dict(FULL, cos_sim_threshold=1.0e-4, optim_steps=3)
+    outs = []
+    for fe in ("0", "1"):
+        monkeypatch.setenv("DYB_FUSE_EMA", fe)              # read when the stepper is created
+        ads = [_mk(r, opts) for r in range(S)]
+        if S == 1:
+            ads[0].excute(frames[0], nframes=NF)
+        else:
+            grp = NS.ReplicaGroup(ads, NF)
+            for s in range(NF):
+                grp.step([frames[r][s] for r in range(S)], s)
+            grp.flush_metrics()
+        st = [_state(a) for a in ads]
+        outs.append([torch.stack([x[k] for x in st]) for k in ("theta", "m", "v", "teacher")] + [torch.tensor([x["steps"] for x in st])])
+        del ads
+    assert int(outs[0][4].max()) >= 1
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

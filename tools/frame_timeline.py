@@ -17,7 +17,7 @@ def main(path, out):
     rows.sort()
     # a step ends with Adam: one launch, or - replica groups, ranged updates - three launches within a few hundred microseconds (the first
     # of a burst marks the boundary)
-    ad_all = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
+    ad_all = [i for i, r in enumerate(rows) if r[2].startswith(("adam_kernel", "adam_segs_kernel"))]      # (round 6: the segment-list form)
     ad = [i for n, i in enumerate(ad_all) if n == 0 or rows[i][0] - rows[ad_all[n - 1]][0] > 5_000_000]
     i0, i1 = ad[len(ad) // 2], ad[len(ad) // 2 + 1]
     seq = rows[i0:i1]
