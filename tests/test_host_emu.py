@@ -338,16 +338,24 @@ def test_native_stepper_side_stream_schedule_under_adversarial_stream_order(emu_
 
 
 @pytest.mark.skipif(not os.environ.get("DYB_EMU_FULL"), reason="~6 min under the emulator; set DYB_EMU_FULL=1")
-def test_replica_group_ranged_weight_updates_under_adversarial_stream_order(emu_lib, monkeypatch):
+@pytest.mark.parametrize("throughput", [0, 1], ids=["latency_schedule", "throughput_schedule"])
+def test_replica_group_ranged_weight_updates_under_adversarial_stream_order(emu_lib, monkeypatch, throughput):
     """Replica groups update the weights by arena ranges: [stem .. layer2] on the chain's stream, [layer3] and [layer4 + regressor] on
     the auxiliary stream beside the next forward's first layers, which waits for each range right before its first reader
     (adapt_step.hip weight_update / DybFwdGates).  One frame step of S = 2 sequences (a fast-weight step, Adam, the final inference)
     in the emulator's lazy stream mode, drained chain-first and auxiliary-stream-first: weights / Adam state / metrics of the in-line
-    run bit for bit."""
+    run bit for bit.  Round 6: the fast weights / Adam's step of most tensors are written by the weight gradients' own epilogues ON THE
+    AUXILIARY STREAM (fuse_fast / fuse_adam) - on the latency schedule (in-kernel fold / fold launch forms) and, `throughput`, on the
+    throughput schedule (rep_split 1, tp_min 1: the unsplit igemm_tp epilogues incl. Adam in place on theta) - so the readers of those
+    weights (the next forward, the final inference) must be ordered behind them by the backward's join, not by the update's events."""
     from types import SimpleNamespace
     from dynaboa_amd import _lib, assets, benchmark as DB, native_step as NS
     from dynaboa_amd.base_adaptor import synthetic_bundle
     raw = _lib.load()
+    if throughput:
+        raw.dyb_set_option(b"rep_split", 1)
+        raw.dyb_set_option(b"tp_min", 1)
+        monkeypatch.setattr(NS, "set_replica_policy", lambda *a, **k: None, raising=False)
     S = 2
     frames = [assets.make_frame(100 * r, 1, seed=22) for r in range(S)]
     orig = NS.NativeStepper.adapt_frames
@@ -382,6 +390,9 @@ def test_replica_group_ranged_weight_updates_under_adversarial_stream_order(emu_
             row += [ads[r].model.module.theta.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
                     torch.from_numpy(np.ravel(np.array(fl[r]["mpjpe"], np.float64)))]
         outs.append(row)
+    if throughput:
+        raw.dyb_set_option(b"rep_split", 0)
+        raw.dyb_set_option(b"tp_min", 8)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
