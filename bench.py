@@ -625,7 +625,9 @@ def main():
     total = args.warmup + args.steps
     n_roof = 0 if args.no_roofline else 4           # extra steps for the instrumented roofline pass (outside the clock)
     n_pct = args.percentile_frames if (args.steps < 200 and args.percentile_frames > 0) else 0
-    n_h2d = 0 if (args.no_sub_records or not simple or args.groups > 1) else 6      # extra steps of the PCIe-inclusive pass (outside the clock)
+    # extra steps of the PCIe-inclusive pass (outside the clock): as many timed steps as the headline (round 6: it used to time 5 steps, whose
+    # end-of-run metric flush and drain weighed four times as much as in the headline's 20)
+    n_h2d = 0 if (args.no_sub_records or not simple or args.groups > 1) else max(6, min(args.steps, 40) + 1)
     nfr = total + n_roof + n_pct + n_h2d
     rn = Runner(device, seqs, args.batch, args.inner_step, nfr, rank=rank, groups=args.groups, full_losses=args.full_losses,
                 second_order=args.second_order, share_forwards=args.share_forwards, overlap=args.overlap, schedule=args.schedule,
