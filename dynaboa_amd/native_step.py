@@ -450,7 +450,7 @@ class NativeStepper:
 # gradient convolutions on igemm_tp_kernel) beats the latency schedule: measured crossover, frames/s latency | throughput at
 # 4: 173.6 | 169.3, 5: 185.8 | 198.9, 6: 198.4 | 222.9, 7: 206.1 | 247.9 (profiles/r05_sessions.txt s15; the library's own default
 # is 8)
-TP_MIN_SEQUENCES = 5
+TP_MIN_SEQUENCES = int(os.environ.get("DYB_TP_MIN_SEQUENCES", "5"))       # (environment: crossover re-measurements, profiles/r06_sessions.txt s18)
 
 
 def set_replica_policy(throughput: bool = True):
