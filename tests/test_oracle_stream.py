@@ -66,7 +66,9 @@ def test_stream(tag, gmm_t, smpl_tabs):
     # bounds = 3 x the fp32-vs-fp64 floor of the tensor's class on THIS stream (tests/golden/g5_<tag>_noise.npz, tools/make_noise.py):
     # ReLU-mask flips of near-zero activations and Adam's sign-like steps move single early-layer tensors by ~1e-2 between two
     # correct fp32 evaluations after a few frames, by several 1e-2 after the 47 Adam steps of the long gated streams
-    nb = noise_bounds(tag, names)
+    # factor 5 here (the GPU tests use conftest.NOISE_FACTOR = 3): the oracle on whatever host CPU runs this suite is one more fp32 draw - another
+    # ISA dispatch of oneDNN rounds differently from the three draws the noise files were taken from on the build container
+    nb = noise_bounds(tag, names, factor=5.0)
     checks = [("d", dn, g["delta_norms"]), ("m", mn, g["m_norms"]), ("v", vn, g["v_norms"])]
     if "teacher_delta_norms" in g.files and ad.o["use_meanteacher"]:
         checks.append(("t", np.array([float((ad.teacher[k].double() - sd0[k].double()).norm()) for k in names]), g["teacher_delta_norms"]))
